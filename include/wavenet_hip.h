@@ -1,0 +1,193 @@
+/*
+ * wavenet_hip.h -- C ABI of libwavenet_hip.so (MI355X / gfx950).
+ *
+ * The reference (musyoku/wavenet) has no native boundary: its hot path sits behind a Python
+ * class API and every FLOP is executed by Chainer.  This header is the boundary the reference
+ * would bind if it had one: each entry point replaces the Chainer call sequence of the cited
+ * reference lines.  wavenet_amd/{wavenet,faster_wavenet}.py call it through ctypes and keep the
+ * reference's Python face (class / method / Params names) on top.
+ *
+ * Conventions (all entry points)
+ *   - return 0 on success; <0 on failure (WN_EARG bad argument, WN_ESHAPE unsupported shape,
+ *     WN_EHIP a HIP runtime error).  wn_last_error() gives a thread-local message.
+ *   - every tensor pointer is a DEVICE pointer owned by the caller; nothing is retained after the
+ *     call returns except by decoder handles, which copy what they need at create / load time.
+ *   - no allocation, no synchronisation: work is enqueued on `stream` (a hipStream_t; NULL = the
+ *     default stream) and the call returns immediately.
+ *   - activations are float32, time-major / channel-minor:  x[b][t][c]  == the reference's
+ *     (B, C, 1, T) tensor in channels-last memory format.
+ *   - convolution weights keep the reference's element order: a (Cout, Cin, 1, fw) or
+ *     (Cout, Cin, fw, 1) Chainer W (wavenet.py:418-424) is the same memory as W[o][c][k], tap
+ *     k = 0 the OLDEST sample.  1x1 weights are W[o][c].  A NULL bias pointer means "no bias".
+ *   - Z is the reference's zero prefix (columns t < Z of a d > 1 dilated conv are exactly 0, no
+ *     bias; wavenet.py:303-340).  The host computes it: Z = max(0, (fw-1)d - pad).  Pass 0 for the
+ *     textbook convolution.
+ */
+#ifndef WAVENET_HIP_H
+#define WAVENET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WN_ABI_VERSION 1
+#define WN_OK      0
+#define WN_EARG   -1
+#define WN_ESHAPE -2
+#define WN_EHIP   -3
+
+#define WN_ACT_NONE 0
+#define WN_ACT_RELU 1   /* wavenet.py:588 */
+#define WN_ACT_ELU  2   /* faster_wavenet.py:108 */
+
+#define WN_MAX_SRC 64   /* sources per wn_skip_sum_* launch; longer lists are chunked by the caller */
+
+int wn_abi_version(void);
+const char* wn_last_error(void);
+/* 1 if the fp32-MFMA fast path covers this residual-layer shape, 0 if the generic path runs */
+int wn_layer_fast_path(int Cr, int Cd, int fw);
+
+/* ---- A10: first causal layer on integer tokens (data.py:61-68 one-hot + wavenet.py:298-301) ----
+ * out[b,t,:] = sum_k W[:, idx[b, t-(fw-1-k)], k]  (+bias), taps with t-(fw-1-k) < 0 contribute 0.
+ * Equals DilatedConvolution1D(d=1) applied to onehot_pixel_image(idx).                        */
+int wn_embed_fwd(const int32_t* idx, const float* W, const float* bias, float* out,
+                 int B, int T, int Q, int C, int fw, void* stream);
+/* dW[o][q][k] += sum over (b,t) with idx[b,t-(fw-1-k)] == q of dout[b,t,o]; dbias += sum dout. */
+int wn_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* dbias,
+                 int B, int T, int Q, int C, int fw, void* stream);
+
+/* ---- A5: dense dilated causal convolution, any shape (DilatedConvolution1D.__call__,
+ * wavenet.py:294-342):  out[b,t,o] = sum_k sum_c W[o,c,k] x[b, t-(fw-1-k)d, c] + bias[o] for
+ * t >= Z, 0 for t < Z.  Used for dense (non one-hot) inputs and for extra causal layers.       */
+int wn_conv_fwd(const float* x, const float* W, const float* bias, float* out,
+                int B, int T, int Cin, int Cout, int fw, int d, int Z, void* stream);
+/* dx (overwritten, may be NULL), dW / dbias (accumulated, may be NULL). */
+int wn_conv_bwd(const float* x, const float* W, const float* dout, float* dx, float* dW, float* dbias,
+                int B, int T, int Cin, int Cout, int fw, int d, int Z, void* stream);
+
+/* ---- A7: fused residual layer (ResidualConvLayer.__call__, wavenet.py:358-368) -------------
+ *   a = conv(x; Wf,bf,d,Z)  g = conv(x; Wg,bg,d,Z)   z = tanh(a) * sigmoid(g)
+ *   out = Wp z + bp + x
+ * z (B,T,Cd) is always written: the skip projection Ws z is deferred to wn_skip_sum_fwd (one
+ * contraction over all layers instead of L read-modify-write passes over a (B,T,Cs) tensor).
+ * f_save / g_save (B,T,Cd), when non-NULL, receive tanh(a) and sigmoid(g) for wn_layer_bwd.    */
+int wn_layer_fwd(const float* x,
+                 const float* Wf, const float* bf, const float* Wg, const float* bg,
+                 const float* Wp, const float* bp,
+                 float* out, float* z, float* f_save, float* g_save,
+                 int B, int T, int Cr, int Cd, int fw, int d, int Z, void* stream);
+
+/* Backward of one layer (Chainer autograd through wavenet.py:358-368).
+ *   dz = Wp^T dout + dz_skip      da = dz g (1-f^2)      dg = dz f g (1-g)     (0 for t < Z)
+ *   dWp += dout z^T  dbp += dout   dWf_k += da x[t-(fw-1-k)d]^T  dbf += da   (same for g)
+ *   dx[t] = dout[t] + sum_k (Wf_k^T da + Wg_k^T dg)[t + (fw-1-k)d]
+ * dz_skip (B,T,Cd) is this layer's slice of Ws^T dskip (wn_skip_sum_bwd_dz); NULL = none.
+ * dout NULL = zero (the last layer's residual output is discarded, train_audio/train.py:72).
+ * dab_ws is caller-provided scratch of B*T*2*Cd floats.  dWp/dbp may be NULL (last layer).    */
+int wn_layer_bwd(const float* x, const float* f, const float* g,
+                 const float* Wf, const float* Wg, const float* Wp,
+                 const float* dout, const float* dz_skip,
+                 float* dx, float* dWf, float* dbf, float* dWg, float* dbg, float* dWp, float* dbp,
+                 float* dab_ws,
+                 int B, int T, int Cr, int Cd, int fw, int d, int Z, void* stream);
+
+/* ---- 1x1 convolution with the activation the reference applies BEFORE it -------------------
+ * out[n,:] = W act(x[n,:]) + b.   Head layers (wavenet.py:587-590: relu then conv; elu in
+ * faster_wavenet.py:107-110), projection_block / projection_softmax with WN_ACT_NONE.           */
+int wn_pointwise_fwd(const float* x, const float* W, const float* bias, float* out,
+                     int N, int Cin, int Cout, int act, void* stream);
+/* dx[n,:] = act'(x[n,:]) * (W^T dout[n,:]) (overwritten; NULL to skip);  dW += dout act(x)^T;
+ * dbias += sum dout. */
+int wn_pointwise_bwd(const float* x, const float* W, const float* dout, float* dx, float* dW,
+                     float* dbias, int N, int Cin, int Cout, int act, void* stream);
+
+/* ---- A11: the skip sum, deferred:  skip[b,t,:] = sum_l (Ws_l z_l[b, t_off+t, :] + bs_l) ------
+ * (wavenet.py:574-582: sum_skip_connections += projection_softmax, all blocks, all layers).
+ * z[l] is (B,T,cd[l]); skip is (B,Tw,Cs) for columns t_off .. t_off+Tw-1 (the harness keeps
+ * only the last train_width columns, train_audio/train.py:73).  accumulate != 0 adds to skip.  */
+int wn_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const float* const* bs,
+                    const int* cd, float* skip, int B, int T, int t_off, int Tw, int Cs,
+                    int accumulate, void* stream);
+/* dz[l][b,t,:] = Ws_l^T dskip[b,t-t_off,:] for t >= t_off, 0 before (dz[l] is (B,T,cd[l])). */
+int wn_skip_sum_bwd_dz(int L, const float* const* Ws, const int* cd, const float* dskip,
+                       float* const* dz, int B, int T, int t_off, int Tw, int Cs, void* stream);
+/* dWs[l] += dskip^T z_l (Cs x cd[l]);  dbs[l] += sum dskip  (either table entry may be NULL). */
+int wn_skip_sum_bwd_dw(int L, const float* const* z, const int* cd, const float* dskip,
+                       float* const* dWs, float* const* dbs, int B, int T, int t_off, int Tw, int Cs,
+                       void* stream);
+
+/* ---- softmax over the channel axis (wavenet.py:592) and A14 (wavenet.py:597-617) ------------ */
+int wn_softmax_fwd(const float* logits, float* prob, int N, int Q, void* stream);
+/* row_loss[n] = -log softmax(logits[n])[target[n]]; *loss = mean(row_loss) (device scalar);
+ * dlogits (may be NULL) = (softmax - onehot) / N.  Rows are b*Tw + t, as after the reference's
+ * transpose(0,3,2,1) + reshape.  target < 0 or >= Q -> WN_EARG is NOT checked on device.        */
+int wn_softmax_xent(const float* logits, const int32_t* target, float* loss, float* dlogits,
+                    int N, int Q, void* stream);
+
+/* ---- layout conversion at the boundary: (B,C,1,T) T-contiguous <-> (B,T,C) ------------------ */
+int wn_nchw_to_btc(const float* src, float* dst, int B, int C, int T, void* stream);
+int wn_btc_to_nchw(const float* src, float* dst, int B, int C, int T, void* stream);
+
+/* ---- A16/A17: queue-cached autoregressive decoder (faster_wavenet.py:50-113) -----------------
+ * Persistent per-layer state in HBM: a ring of (fw-1)*d input columns per residual layer (and
+ * per extra causal layer) instead of the reference's full-window caches that are rolled every
+ * step; the head runs on the newest column only.                                               */
+typedef struct WnDecoderDesc {
+    int Q, fw_causal, n_causal, fw, n_blocks, n_layers;  /* n_layers per block; dilation fw^l */
+    int Cr, Cs, n_head;
+    const int* causal_channels;       /* host, n_causal entries                                */
+    const int* cd;                    /* host, n_layers entries (per layer index in a block)    */
+    const int* head_channels;         /* host, n_head+1 entries: Cs, ..., Q                     */
+    /* device pointers to weights in creation order (wavenet.py:461-472); biases may be NULL   */
+    const float* const* causal_W; const float* const* causal_b;                 /* n_causal    */
+    const float* const* Wf; const float* const* bf;                             /* blocks*layers */
+    const float* const* Wg; const float* const* bg;
+    const float* const* Wp; const float* const* bp;
+    const float* const* Ws; const float* const* bs;
+    const float* const* head_W; const float* const* head_b;                     /* n_head      */
+    int head_act;                     /* WN_ACT_ELU for FasterWaveNet, WN_ACT_RELU for WaveNet  */
+} WnDecoderDesc;
+
+int wn_decoder_create(void** handle, const WnDecoderDesc* desc, void* stream);
+int wn_decoder_destroy(void* handle);
+/* re-copy the weights (after an optimiser step) */
+int wn_decoder_update_weights(void* handle, const WnDecoderDesc* desc, void* stream);
+/* Seed the rings from a full-window forward (faster_wavenet.py:13-47): tokens (W) are the window's
+ * tokens, causal_out[i] is (1,W,C_i) and layer_in[j] (1,W,Cr) is the INPUT of residual layer j
+ * (blocks*layers entries), all produced by the ordinary forward kernels over the same window.  */
+int wn_decoder_load_state(void* handle, const int32_t* tokens, int W,
+                          const float* const* causal_out, const float* const* layer_in, void* stream);
+/* One step (FasterWaveNet._forward_one_step): consume `token` (the newest sample), advance all
+ * rings, write the probabilities (or logits if apply_softmax == 0) of the next sample to prob (Q). */
+int wn_decoder_step(void* handle, int32_t token, float* prob, int apply_softmax, void* stream);
+/* n steps entirely on device (train_audio/generate.py:24-43 with --fast): each step consumes the
+ * previous token, computes p, draws with numpy's algorithm from uniforms[i] (float64 cumsum,
+ * normalise, searchsorted right) and appends.  first_token is the newest token of the window the
+ * state was loaded from plus one draw, i.e. the token emitted by the prefill step.  out_tokens (n)
+ * receives the n emitted tokens; prob_trace (n*Q) is optional.                                  */
+int wn_decoder_run(void* handle, int32_t first_token, const double* uniforms, int n,
+                   int32_t* out_tokens, float* prob_trace, void* stream);
+/* categorical draw with numpy's algorithm for n independent rows (generate.py:39) */
+int wn_sample_categorical(const float* prob, const double* uniforms, int32_t* out, int n, int Q,
+                          void* stream);
+
+/* ---- the step either side of backward ------------------------- */
+/* *out (device scalar, accumulated) += sum (grad*grad_mult + weight_decay*param)^2: the squared
+ * norm GradientClipping sees after the WeightDecay hook (wavenet.py:175-199, 477-480).
+ * param may be NULL when weight_decay == 0.                                                     */
+int wn_sqnorm(const float* grad, const float* param, int64_t n, float grad_mult, float weight_decay,
+              float* out, void* stream);
+/* Chainer Adam with the reference's hooks folded in, in hook order:
+ *   g = grad*grad_mult + wd*param;   g *= min(1, clip/sqrt(*sqnorm))  (sqnorm != NULL, clip > 0)
+ *   m += (1-b1)(g-m); v += (1-b2)(g^2-v); param -= lr_t * m / (sqrt(v)+eps).
+ * lr_t = alpha*sqrt(1-b2^t)/(1-b1^t) is computed by the host.                                   */
+int wn_adam_step(float* param, const float* grad, float* m, float* v, int64_t n,
+                 float lr_t, float beta1, float beta2, float eps, float weight_decay,
+                 const float* sqnorm, float clip, float grad_mult, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAVENET_HIP_H */

@@ -1,0 +1,88 @@
+"""Generate the golden fixtures under tests/golden/ from the CPU oracle (oracle/).
+
+The reference itself cannot run here (Python 2 + Chainer, neither present), so these vectors are
+outputs of the build's own restatement -- PARITY UNPINNED against Chainer, see oracle/__init__.py.
+They pin the oracle against drift and give the GPU tests fixed inputs/outputs that travel to the
+GPU box.  Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import data_ref as D          # noqa: E402
+from oracle import wavenet_ref as R       # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+
+CFG1 = dict(quantization_steps=256, causal_conv_channels=[16], residual_conv_channels=[16] * 4,
+            residual_num_blocks=1, softmax_conv_channels=[32, 256])
+
+
+def kat1():
+    x = np.mod(np.arange(40), 5).reshape(1, 4, 1, 10).astype(np.float32)
+    W = np.ones((3, 4, 4, 1), np.float32)
+    out = R.dilated_conv_literal(torch.tensor(x), torch.tensor(W), None, 4, 4).numpy()
+    np.savez(os.path.join(OUT, "kat1_dilated_conv.npz"), x=x, W=W, out=out)
+
+
+def cfg1_forward():
+    p = R.make_params(**CFG1)
+    w = R.init_weights(p, 1234)
+    idx = np.random.RandomState(0).randint(0, 256, (1, 8000)).astype(np.int32)
+    net = R.RefWaveNet(p, w)
+    with torch.no_grad():
+        x = R.onehot_t(idx, 256)
+        c = net.forward_causal_block(x)
+        rec = []
+        o, s = net.forward_residual_block(c, record=rec)
+        logits = net.forward_softmax_block(s, apply_softmax=False)
+    cols = np.unique(np.concatenate([np.arange(0, 40), np.arange(7990, 8000),
+                                     np.random.RandomState(1).randint(0, 8000, 250)]))
+    np.savez_compressed(
+        os.path.join(OUT, "cfg1_forward.npz"), idx=idx.astype(np.uint8), cols=cols.astype(np.int32),
+        logits_cols=logits.numpy()[0, :, 0, :][:, cols], skip_cols=s.numpy()[0, :, 0, :][:, cols],
+        out_cols=o.numpy()[0, :, 0, :][:, cols],
+        layer_out_sum=np.array([float(r[0].double().sum()) for r in rec]),
+        layer_skip_sum=np.array([float(r[1].double().sum()) for r in rec]),
+        logits_sum=np.array(float(logits.double().sum())), logits_abs_sum=np.array(float(logits.double().abs().sum())))
+
+
+def cfg1_train_step():
+    p = R.make_params(**CFG1)
+    w = R.init_weights(p, 1234)
+    iw = R.input_width(p)
+    tw = 600 - iw
+    idx = np.random.RandomState(5).randint(0, 256, (2, 600)).astype(np.int32)
+    tgt = np.random.RandomState(6).randint(0, 256, (2, tw)).astype(np.int32)
+    loss, logits, g = R.train_step_grads(p, w, idx, tgt)
+    np.savez_compressed(os.path.join(OUT, "cfg1_train_step.npz"), idx=idx.astype(np.uint8), target=tgt.astype(np.uint8),
+                        loss=np.array(loss, np.float64), **{"grad:" + k: v for k, v in g.items()})
+
+
+def fastgen_trace():
+    p = R.make_params(quantization_steps=256, causal_conv_channels=[16], residual_conv_channels=[16] * 4,
+                      residual_num_blocks=2, softmax_conv_channels=[32, 256])
+    w = R.init_weights(p, 1234)
+    u = np.random.RandomState(7).random_sample(64)
+    for act in ("elu", "relu"):
+        tr = []
+        toks = R.generate(p, w, 64, u, fast=True, fast_head_act=act, trace=tr)
+        np.savez_compressed(os.path.join(OUT, "fastgen_%s.npz" % act), tokens=toks.astype(np.int32),
+                            probs=np.array(tr, np.float32), uniforms=u)
+
+
+def mulaw_table():
+    q = D.mulaw_quantize_pcm16(np.arange(-32768, 32768))
+    np.savez_compressed(os.path.join(OUT, "mulaw_pcm16.npz"), table=q.astype(np.uint8))
+
+
+if __name__ == "__main__":
+    kat1(); cfg1_forward(); cfg1_train_step(); fastgen_trace(); mulaw_table()
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))

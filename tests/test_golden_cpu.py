@@ -1,0 +1,65 @@
+"""CPU: the oracle reproduces the committed golden fixtures (guards the checker against drift)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import data_ref as D
+from oracle import wavenet_ref as R
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CFG1 = dict(quantization_steps=256, causal_conv_channels=[16], residual_conv_channels=[16] * 4,
+            residual_num_blocks=1, softmax_conv_channels=[32, 256])
+
+
+def test_kat1_fixture():
+    z = np.load(os.path.join(G, "kat1_dilated_conv.npz"))
+    np.testing.assert_array_equal(z["out"][0, 0, 0], [0, 0, 0, 0, 0, 0, 12, 20, 28, 20])
+    np.testing.assert_array_equal(R.dilated_conv_closed(z["x"], z["W"], None, 4, 4), z["out"])
+
+
+def test_cfg1_forward_fixture_closed_form():
+    z = np.load(os.path.join(G, "cfg1_forward.npz"))
+    p = R.make_params(**CFG1)
+    w = R.init_weights(p, 1234)
+    idx = z["idx"].astype(np.int32)
+    np.testing.assert_array_equal(idx, np.random.RandomState(0).randint(0, 256, (1, 8000)))
+    keep = []
+    _, o, s, h = R.forward_closed(p, w, D.onehot_pixel_image(idx, 256), keep=keep)
+    cols = z["cols"]
+    np.testing.assert_allclose(h[0, :, 0, :][:, cols], z["logits_cols"], atol=2e-5)
+    np.testing.assert_allclose(s[0, :, 0, :][:, cols], z["skip_cols"], atol=2e-5)
+    np.testing.assert_allclose(o[0, :, 0, :][:, cols], z["out_cols"], atol=2e-5)
+    np.testing.assert_allclose([float(k[0].astype(np.float64).sum()) for k in keep], z["layer_out_sum"], rtol=1e-4, atol=1e-2)
+    # F3: the zero prefix is visible in the fixture (layer with d=8 leaves skip columns < 8 bias-free zero taps)
+    assert 0 in cols and 7 in cols
+
+
+def test_cfg1_train_fixture():
+    z = np.load(os.path.join(G, "cfg1_train_step.npz"))
+    p = R.make_params(**CFG1)
+    w = R.init_weights(p, 1234)
+    loss, _, g = R.train_step_grads(p, w, z["idx"].astype(np.int32), z["target"].astype(np.int32))
+    assert abs(loss - float(z["loss"])) < 1e-5
+    for k, v in g.items():
+        np.testing.assert_allclose(v, z["grad:" + k], atol=1e-6, rtol=1e-4)
+
+
+def test_fastgen_fixture():
+    p = R.make_params(quantization_steps=256, causal_conv_channels=[16], residual_conv_channels=[16] * 4,
+                      residual_num_blocks=2, softmax_conv_channels=[32, 256])
+    w = R.init_weights(p, 1234)
+    for act in ("elu", "relu"):
+        z = np.load(os.path.join(G, "fastgen_%s.npz" % act))
+        tr = []
+        toks = R.generate(p, w, 16, z["uniforms"], fast=True, fast_head_act=act, trace=tr)
+        np.testing.assert_array_equal(toks, z["tokens"][:16])
+        np.testing.assert_allclose(np.array(tr), z["probs"][:16], atol=1e-6)
+    a, b = np.load(os.path.join(G, "fastgen_elu.npz")), np.load(os.path.join(G, "fastgen_relu.npz"))
+    np.testing.assert_allclose(a["probs"][0], b["probs"][0], atol=1e-7)      # first step: ReLU path in both
+    assert np.abs(a["probs"][1:] - b["probs"][1:]).max() > 1e-5              # then ELU vs ReLU (F4)
+
+
+def test_mulaw_fixture():
+    z = np.load(os.path.join(G, "mulaw_pcm16.npz"))
+    np.testing.assert_array_equal(D.mulaw_quantize_pcm16(np.arange(-32768, 32768)), z["table"].astype(np.int32))

@@ -1,0 +1,409 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Tolerances: integer / index results bit-exact; fp32 activations and logits within 1e-4 absolute
+(BASELINE.json north_star), gradients within 1e-4 relative to the largest entry of each tensor.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import data_ref as D
+from oracle import wavenet_ref as R
+from wavenet_amd import _lib, data
+from wavenet_amd import FasterWaveNet, Params, WaveNet
+from wavenet_amd._lib import check, ptr
+
+from gpu_util import CFG1, CFG2, build, dev, btc, to_np
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ATOL = 1e-4
+
+
+def _layer_case(Cr, Cd, fw, d, B, T, bias, seed=0):
+    rs = np.random.RandomState(seed)
+    x = rs.standard_normal((B, Cr, 1, T)).astype(np.float32)
+    sh = (Cd, Cr, 1, fw) if d == 1 else (Cd, Cr, fw, 1)
+    Wf = (rs.standard_normal(sh) / np.sqrt(Cr * fw)).astype(np.float32)
+    Wg = (rs.standard_normal(sh) / np.sqrt(Cr * fw)).astype(np.float32)
+    Wp = (rs.standard_normal((Cr, Cd)) / np.sqrt(Cd)).astype(np.float32)
+    b = [(rs.standard_normal(n) * 0.3).astype(np.float32) if bias else None for n in (Cd, Cd, Cr)]
+    Z = R.conv_pad_and_prefix(T, d, fw)[1]
+    a = R.dilated_conv_closed(x, Wf, b[0], d, fw)
+    g = R.dilated_conv_closed(x, Wg, b[1], d, fw)
+    f_, g_ = np.tanh(a), R._sigmoid_n(g)
+    z = f_ * g_
+    out = np.einsum("oc,bcht->boht", Wp, z) + x
+    if bias:
+        out = out + b[2].reshape(1, -1, 1, 1)
+    return x, Wf, Wg, Wp, b, Z, out.astype(np.float32), z, f_, g_
+
+
+def _run_layer(x, Wf, Wg, Wp, b, Z, Cr, Cd, fw, d, save):
+    B, T = x.shape[0], x.shape[3]
+    xb = dev(btc(x))
+    out = torch.empty_like(xb)
+    z = torch.empty((B, T, Cd), device="cuda")
+    f = torch.empty_like(z) if save else None
+    g = torch.empty_like(z) if save else None
+    tens = [dev(Wf), None if b[0] is None else dev(b[0]), dev(Wg), None if b[1] is None else dev(b[1]), dev(Wp),
+            None if b[2] is None else dev(b[2])]
+    check(_lib.lib().wn_layer_fwd(ptr(xb), *[ptr(t) for t in tens], ptr(out), ptr(z), ptr(f), ptr(g), B, T, Cr, Cd, fw,
+                                  d, Z, None), "wn_layer_fwd")
+    torch.cuda.synchronize()
+    return out, z, f, g
+
+
+@pytest.mark.parametrize("Cr,Cd,fw,d,B,T,bias", [
+    (16, 16, 2, 1, 1, 50, False), (16, 16, 2, 8, 2, 100, True), (8, 12, 3, 9, 2, 77, True), (5, 3, 2, 4, 1, 7, False),
+    (128, 32, 2, 16, 1, 300, False), (24, 24, 2, 512, 1, 600, True), (6, 6, 4, 4, 1, 10, False)])
+def test_layer_fwd_generic(Cr, Cd, fw, d, B, T, bias):
+    assert _lib.lib().wn_layer_fast_path(Cr, Cd, fw) == 0
+    x, Wf, Wg, Wp, b, Z, out, z, f_, g_ = _layer_case(Cr, Cd, fw, d, B, T, bias)
+    o, zz, f, g = _run_layer(x, Wf, Wg, Wp, b, Z, Cr, Cd, fw, d, True)
+    np.testing.assert_allclose(to_np(o), btc(out), atol=ATOL)
+    np.testing.assert_allclose(to_np(zz), btc(z), atol=ATOL)
+    np.testing.assert_allclose(to_np(f), btc(f_), atol=ATOL)
+    np.testing.assert_allclose(to_np(g), btc(g_), atol=ATOL)
+
+
+@pytest.mark.parametrize("d,B,T,bias,save", [
+    (1, 1, 32, False, False), (1, 2, 100, True, True), (2, 3, 1000, False, True), (32, 1, 2065, True, False),
+    (512, 2, 2048, False, True), (512, 1, 4094, True, True), (256, 1, 31, False, False), (64, 8, 999, False, False)])
+def test_layer_fwd_mfma(d, B, T, bias, save):
+    """The fp32-MFMA kernel (Cr=Cd=32, fw=2): ragged T, tiles straddling t<d, zero prefix, biases."""
+    assert _lib.lib().wn_layer_fast_path(32, 32, 2) == 1
+    x, Wf, Wg, Wp, b, Z, out, z, f_, g_ = _layer_case(32, 32, 2, d, B, T, bias, seed=d + T)
+    o, zz, f, g = _run_layer(x, Wf, Wg, Wp, b, Z, 32, 32, 2, d, save)
+    np.testing.assert_allclose(to_np(o), btc(out), atol=ATOL)
+    np.testing.assert_allclose(to_np(zz), btc(z), atol=ATOL)
+    if Z > 0:
+        assert np.all(to_np(zz)[:, :min(Z, T)] == 0)       # exact zeros in the reference's zero prefix
+    if save:
+        np.testing.assert_allclose(to_np(f), btc(f_), atol=ATOL)
+        np.testing.assert_allclose(to_np(g), btc(g_), atol=ATOL)
+
+
+def test_mfma_operand_maps_with_integer_data():
+    """Exact-integer check of the MFMA lane maps: asymmetric weights, every channel distinct."""
+    Cr = Cd = 32
+    T, d = 64, 3
+    x = (np.arange(Cr * T).reshape(1, Cr, 1, T) % 7 - 3).astype(np.float32)
+    Wf = np.zeros((Cd, Cr, 2, 1), np.float32)
+    Wg = np.zeros((Cd, Cr, 2, 1), np.float32)
+    for o in range(Cd):
+        Wf[o, (o * 5 + 1) % Cr, 1, 0] = 0.03125 * (1 + o % 3)          # picks channel (5o+1)%32 of x[t]
+        Wf[o, (o * 3 + 2) % Cr, 0, 0] = -0.03125                        # and (3o+2)%32 of x[t-d]
+        Wg[o, (o * 7) % Cr, 1, 0] = 0.0625
+    Wp = np.zeros((Cr, Cd), np.float32)
+    for c in range(Cr):
+        Wp[c, (c * 11 + 3) % Cd] = 2.0
+    b = [None, None, None]
+    Z = R.conv_pad_and_prefix(T, d, 2)[1]
+    a = R.dilated_conv_closed(x, Wf, None, d, 2)
+    g = R.dilated_conv_closed(x, Wg, None, d, 2)
+    z = np.tanh(a) * R._sigmoid_n(g)
+    out = np.einsum("oc,bcht->boht", Wp, z) + x
+    o, zz, _, _ = _run_layer(x, Wf, Wg, Wp, b, Z, Cr, Cd, 2, d, False)
+    np.testing.assert_allclose(to_np(zz), btc(z), atol=2e-6)
+    np.testing.assert_allclose(to_np(o), btc(out), atol=1e-5)
+
+
+def test_embed_equals_dense_onehot_conv():
+    p, w, net = build(dict(quantization_steps=64, causal_conv_channels=[24, 20], causal_conv_filter_width=3,
+                           residual_conv_channels=[8], residual_num_blocks=1, softmax_conv_channels=[16, 64],
+                           causal_conv_no_bias=False), bias_scale=0.2)
+    idx = np.random.RandomState(0).randint(0, 64, (3, 70)).astype(np.int32)
+    with torch.no_grad():
+        a = net.forward_causal_block(idx)                                   # gather path
+        b = net.forward_causal_block(data.onehot_pixel_image(idx, 64))      # dense path, T-contiguous input
+    assert a.shape == (3, 20, 1, 70)
+    ref = R.RefWaveNet(p, w).forward_causal_block(R.onehot_t(idx, 64)).numpy()
+    np.testing.assert_allclose(to_np(a), ref, atol=ATOL)
+    np.testing.assert_allclose(to_np(b), ref, atol=ATOL)
+
+
+def _full_forward_check(over, B, T, bias_scale=0.0, seed=1234, **kw):
+    p, w, net = build(over, seed=seed, bias_scale=bias_scale, **kw)
+    Q = p["quantization_steps"]
+    idx = np.random.RandomState(2).randint(0, Q, (B, T)).astype(np.int32)
+    ref = R.RefWaveNet(p, w)
+    with torch.no_grad():
+        x = R.onehot_t(idx, Q)
+        c = ref.forward_causal_block(x)
+        o, s = ref.forward_residual_block(c)
+        lg = ref.forward_softmax_block(s, apply_softmax=False)
+        pr = ref.forward_softmax_block(s, apply_softmax=True)
+        gc = net.forward_causal_block(idx)
+        go, gs = net.forward_residual_block(gc)
+        glg = net.forward_softmax_block(gs, apply_softmax=False)
+        gpr = net.forward_one_step(idx, apply_softmax=True, as_numpy=True)
+    assert go.shape == o.shape and gs.shape == s.shape and glg.shape == lg.shape
+    np.testing.assert_allclose(to_np(gc), c.numpy(), atol=ATOL)
+    np.testing.assert_allclose(to_np(go), o.numpy(), atol=ATOL)
+    np.testing.assert_allclose(to_np(gs), s.numpy(), atol=ATOL)
+    np.testing.assert_allclose(to_np(glg), lg.numpy(), atol=ATOL)          # north star: logits within 1e-4
+    np.testing.assert_allclose(gpr, pr.numpy(), atol=1e-5)
+    return net, idx
+
+
+def test_full_forward_cfg1_topology_and_golden():
+    net, _ = _full_forward_check(CFG1, 1, 1000)
+    z = np.load(os.path.join(G, "cfg1_forward.npz"))
+    idx = z["idx"].astype(np.int32)
+    with torch.no_grad():
+        c = net.forward_causal_block(idx)
+        o, s = net.forward_residual_block(c)
+        lg = net.forward_softmax_block(s, apply_softmax=False)
+    cols = z["cols"]
+    np.testing.assert_allclose(to_np(lg)[0, :, 0, :][:, cols], z["logits_cols"], atol=ATOL)
+    np.testing.assert_allclose(to_np(s)[0, :, 0, :][:, cols], z["skip_cols"], atol=ATOL)
+    np.testing.assert_allclose(to_np(o)[0, :, 0, :][:, cols], z["out_cols"], atol=ATOL)
+    assert abs(float(lg.double().sum()) - float(z["logits_sum"])) < 1e-4 * float(z["logits_abs_sum"])
+
+
+def test_full_forward_with_biases_fw3_uneven_channels():
+    _full_forward_check(dict(quantization_steps=20, causal_conv_channels=[12, 10], causal_conv_filter_width=3,
+                             residual_conv_channels=[6, 9, 6], residual_conv_filter_width=3, residual_num_blocks=2,
+                             softmax_conv_channels=[14, 11, 20], causal_conv_no_bias=False,
+                             residual_conv_dilation_no_bias=False, residual_conv_projection_no_bias=False),
+                        2, 131, bias_scale=0.3)
+
+
+def test_full_forward_cfg2_topology_mfma_path():
+    """4 x 10 layers of 32 channels (the fp32-MFMA layer kernel), T not a multiple of 32, d up to 512."""
+    _full_forward_check(CFG2, 2, 1500)
+
+
+def test_compat_zero_prefix_off_is_textbook_conv():
+    p, w, net = build(CFG1, compat_zero_prefix=False)
+    idx = np.random.RandomState(2).randint(0, 256, (1, 200)).astype(np.int32)
+    _, _, s, h = R.forward_closed(p, w, D.onehot_pixel_image(idx, 256), compat_zero_prefix=False)
+    with torch.no_grad():
+        lg = net.forward_one_step(idx, apply_softmax=False)
+    np.testing.assert_allclose(to_np(lg), h, atol=ATOL)
+
+
+def test_single_layer_calls_and_column_forward():
+    """ResidualConvLayer.__call__/_forward and DilatedConvolution1D.__call__/_forward (wavenet.py:281-368)."""
+    p, w, net = build(CFG1, bias_scale=0.0)
+    rs = np.random.RandomState(0)
+    x = rs.standard_normal((1, 16, 1, 40)).astype(np.float32)
+    lay = net.residual_blocks[0][2]          # d = 4
+    ref = R.RefWaveNet(p, w)
+    o, s, _ = ref.residual_layer(torch.tensor(x), "residual_0_block_2_", 4)
+    go, gs = lay(x)
+    np.testing.assert_allclose(to_np(go), o.numpy(), atol=ATOL)
+    np.testing.assert_allclose(to_np(gs), s.numpy(), atol=ATOL)
+    fo, fs = lay._forward(x)
+    assert fo.shape == (1, 16, 1, 1) and fs.shape == (1, 32, 1, 1)
+    np.testing.assert_allclose(to_np(fo)[0, :, 0, 0], o.numpy()[0, :, 0, -1], atol=ATOL)
+    np.testing.assert_allclose(to_np(fs)[0, :, 0, 0], s.numpy()[0, :, 0, -1], atol=ATOL)
+    c = lay.wf(x)
+    cr = R.dilated_conv_closed(x, w["residual_0_block_2_wf/W"], None, 4, 2)
+    np.testing.assert_allclose(to_np(c), cr, atol=ATOL)
+    cc = lay.wf._forward(x)
+    np.testing.assert_allclose(to_np(cc)[0, :, 0, 0], cr[0, :, 0, -1], atol=ATOL)
+
+
+def test_softmax_xent_and_slice_pad():
+    rs = np.random.RandomState(0)
+    lg = (rs.standard_normal((3, 256, 1, 50)) * 4).astype(np.float32)
+    tg = rs.randint(0, 256, (3, 50)).astype(np.int32)
+    _, _, net = build(CFG1)
+    loss = net.cross_entropy(lg, tg)
+    want = R.RefWaveNet(R.make_params(**CFG1), R.init_weights(R.make_params(**CFG1))).cross_entropy(torch.tensor(lg), tg)
+    assert abs(float(loss) - float(want)) < 1e-5
+    with pytest.raises(Exception, match="width"):
+        net.cross_entropy(lg, tg[:, :-1])
+    x = dev(lg)
+    assert net.slice_1d(x, 7).shape == (3, 256, 1, 43)
+    assert net.padding_1d(x, 5).shape == (3, 256, 1, 55)
+    assert float(net.padding_1d(x, 5)[..., :5].abs().sum()) == 0
+
+
+def test_sampler_is_numpys_choice():
+    rs = np.random.RandomState(3)
+    n, Q = 4096, 256
+    logits = (rs.standard_normal((n, Q)) * 3).astype(np.float32)
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    prob = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    u = np.array([np.random.RandomState(i).random_sample() for i in range(n)])
+    want = np.array([np.random.RandomState(i).choice(np.arange(Q), p=prob[i]) for i in range(n)])
+    out = torch.empty((n,), dtype=torch.int32, device="cuda")
+    check(_lib.lib().wn_sample_categorical(ptr(dev(prob)), ptr(dev(u)), ptr(out), n, Q, None))
+    np.testing.assert_array_equal(to_np(out), want)          # bit-exact indices
+    # edge cases: u just below / at a cdf boundary, one-hot rows
+    p1 = np.zeros((3, Q), np.float32); p1[0, 17] = 1; p1[1, 0] = 1; p1[2, Q - 1] = 1
+    u1 = np.array([0.999999999, 0.0, 0.5])
+    check(_lib.lib().wn_sample_categorical(ptr(dev(p1)), ptr(dev(u1)), ptr(out), 3, Q, None))
+    np.testing.assert_array_equal(to_np(out)[:3], [R.choice_from_uniform(p1[i], u1[i]) for i in range(3)])
+
+
+def test_train_step_loss_and_grads_vs_oracle_and_golden():
+    z = np.load(os.path.join(G, "cfg1_train_step.npz"))
+    p, w, net = build(CFG1)
+    idx, tgt = z["idx"].astype(np.int32), z["target"].astype(np.int32)
+    tw = tgt.shape[1]
+    c = net.forward_causal_block(idx)
+    o, s = net.forward_residual_block(c)
+    s = net.slice_1d(s, s.shape[3] - tw)                       # train_audio/train.py:73
+    lg = net.forward_softmax_block(s, apply_softmax=False)
+    loss = net.cross_entropy(lg, tgt)
+    net.zero_grads()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(z["loss"])) < 1e-4
+    for ln, kind, off, n, shape in net._spans:
+        want = z["grad:%s/%s" % (ln.name, kind)]
+        got = to_np(net._grad_arena[off:off + n].view(shape))
+        scale = max(np.abs(want).max(), 1e-6)
+        assert np.abs(got - want).max() <= 1e-4 * scale + 1e-7, (ln.name, kind, np.abs(got - want).max(), scale)
+    # Q8: the last layer's projection_block receives no gradient
+    assert float(net.residual_blocks[-1][-1].projection_block.W.grad.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("over,B,T,tw,bias", [
+    (dict(quantization_steps=20, causal_conv_channels=[12, 10], causal_conv_filter_width=3,
+          residual_conv_channels=[6, 9, 6], residual_conv_filter_width=3, residual_num_blocks=2,
+          softmax_conv_channels=[14, 11, 20], causal_conv_no_bias=False, residual_conv_dilation_no_bias=False,
+          residual_conv_projection_no_bias=False), 2, 90, 30, 0.3),
+    (dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 5, residual_num_blocks=2,
+          softmax_conv_channels=[64, 256]), 2, 300, 237, 0.0)])
+def test_train_step_grads_general(over, B, T, tw, bias):
+    """fused path (t_off) and sliced path give the oracle's loss and gradients, biases included."""
+    p, w, net = build(over, bias_scale=bias)
+    Q = p["quantization_steps"]
+    idx = np.random.RandomState(5).randint(0, Q, (B, T)).astype(np.int32)
+    tgt = np.random.RandomState(6).randint(0, Q, (B, tw)).astype(np.int32)
+    loss_ref, _, g = R.train_step_grads(p, w, idx, tgt)
+    for fused in (False, True):
+        c = net.forward_causal_block(idx)
+        if fused:
+            _, s = net.forward_residual_block(c, t_off=T - tw)
+        else:
+            _, s = net.forward_residual_block(c)
+            s = net.slice_1d(s, T - tw)
+        loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt)
+        net.zero_grads()
+        loss.backward()
+        assert abs(float(loss) - loss_ref) < 1e-4
+        for ln, kind, off, n, shape in net._spans:
+            want = g["%s/%s" % (ln.name, kind)]
+            got = to_np(net._grad_arena[off:off + n].view(shape))
+            scale = max(np.abs(want).max(), 1e-6)
+            assert np.abs(got - want).max() <= 2e-4 * scale + 1e-7, (fused, ln.name, kind)
+
+
+def test_adam_step_matches_chainer_rule():
+    p, w, net = build(CFG1, gradient_clipping=0.05)
+    net.params.weight_decay = 0.01
+    net.update_laerning_rate(0.001)
+    rs = np.random.RandomState(0)
+    P0 = to_np(net._arena).astype(np.float64)
+    m = np.zeros_like(P0); v = np.zeros_like(P0)
+    P = P0.copy()
+    for t in range(1, 4):
+        g = rs.standard_normal(P.shape).astype(np.float32) * 0.01
+        net._grad_arena.copy_(dev(g))
+        net.optimizer.update(0.5)                                 # grad_mult as a 2-rank DP mean
+        gg = g.astype(np.float64) * 0.5 + 0.01 * P                # WeightDecay hook
+        nrm = np.sqrt((gg ** 2).sum())
+        if 0.05 / nrm < 1:
+            gg *= 0.05 / nrm                                      # GradientClipping hook
+        m += (1 - 0.9) * (gg - m); v += (1 - 0.999) * (gg * gg - v)
+        lr_t = 0.001 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        P -= lr_t * m / (np.sqrt(v) + 1e-8)
+        np.testing.assert_allclose(to_np(net._arena), P, atol=2e-6)
+
+
+def test_backprop_reduces_loss_on_toy_staircase():
+    """KAT-8: the _tests_/training staircase (Q=10) is learnable: forward + backward + Adam."""
+    p, w, net = build(dict(quantization_steps=10, causal_conv_channels=[32], residual_conv_channels=[16, 16],
+                           residual_conv_filter_width=3, causal_conv_filter_width=3, residual_num_blocks=1,
+                           softmax_conv_channels=[24, 10]), seed=3)
+    net.update_laerning_rate(0.01)
+    sig = np.repeat(np.arange(10), 100).astype(np.int32)
+    iw = net.input_width
+    rng = np.random.RandomState(0)
+    first = last = None
+    for it in range(150):
+        x, t = data.create_batch(sig, 16, iw, 40, rng=rng)
+        c = net.forward_causal_block(x)
+        _, s = net.forward_residual_block(c)
+        s = net.slice_1d(s, s.shape[3] - 40)
+        loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), t)
+        net.backprop(loss)
+        if it == 0:
+            first = float(loss)
+        last = float(loss)
+    assert first > 1.5 and last < 0.3 * first, (first, last)
+
+
+@pytest.mark.parametrize("act", ["elu", "relu"])
+def test_fast_generation_vs_oracle_golden(act):
+    z = np.load(os.path.join(G, "fastgen_%s.npz" % act))
+    over = dict(quantization_steps=256, causal_conv_channels=[16], residual_conv_channels=[16] * 4,
+                residual_num_blocks=2, softmax_conv_channels=[32, 256])
+    p, w, net = build(over, cls=FasterWaveNet)
+    net.fast_head_activation = act
+    toks, probs = net.generate(64, z["uniforms"], return_probs=True)
+    np.testing.assert_allclose(to_np(probs), z["probs"], atol=2e-5)
+    np.testing.assert_array_equal(to_np(toks), z["tokens"])            # bit-exact token indices
+    # the reference's call sequence, one step at a time (generate.py:24-43 with --fast)
+    net.prev_causal_outputs = None
+    iw = net.input_width
+    buf = np.full((iw,), 127, np.int32)
+    for step in range(12):
+        x = data.onehot_pixel_image(buf[-iw:].reshape(1, -1), 256)
+        sm = net._forward_one_step(x, apply_softmax=True, as_numpy=True)
+        pr = sm[0, :, 0, -1]
+        np.testing.assert_allclose(pr, z["probs"][step], atol=2e-5)
+        buf = np.append(buf, [R.choice_from_uniform(pr, z["uniforms"][step])]).astype(np.int32)
+    np.testing.assert_array_equal(buf[iw:], z["tokens"][:12])
+
+
+def test_fast_equals_slow_cfg2_topology_with_extra_causal_layer_and_fw3():
+    """KAT-6 on the GPU: incremental decode == full-window forward, same head activation."""
+    over = dict(quantization_steps=32, causal_conv_channels=[12, 8], causal_conv_filter_width=3,
+                residual_conv_channels=[8, 8, 8], residual_conv_filter_width=3, residual_num_blocks=2,
+                softmax_conv_channels=[16, 32], causal_conv_no_bias=False, residual_conv_dilation_no_bias=False,
+                residual_conv_projection_no_bias=False)
+    p, w, net = build(over, cls=FasterWaveNet, bias_scale=0.2)
+    net.fast_head_activation = "relu"
+    u = np.random.RandomState(9).random_sample(40)
+    toks, probs = net.generate(40, u, return_probs=True)
+    slow = WaveNet(net.params, seed=0); slow.load_state_dict(w); slow.to_gpu()
+    iw = net.input_width
+    buf = np.full((iw,), 16, np.int32)
+    for step in range(40):
+        pr = slow.forward_one_step(buf[-iw:].reshape(1, -1), as_numpy=True)[0, :, 0, -1]
+        np.testing.assert_allclose(to_np(probs)[step], pr, atol=2e-5)
+        buf = np.append(buf, [int(to_np(toks)[step])]).astype(np.int32)
+
+
+def test_causality_and_batch_independence_at_full_size():
+    """Size-independent properties at config 2's full size (B=8, T=16384, 4x10 layers)."""
+    p, w, net = build(CFG2)
+    sig = D.mulaw_quantize(D.synthetic_waveform(8, 16384, 16000))
+    with torch.no_grad():
+        a = net.forward_one_step(sig, apply_softmax=False)
+        sig2 = sig.copy()
+        sig2[:, 9000:] = (sig2[:, 9000:] + 37) % 256               # change the future
+        sig2[3] = sig[5]                                            # and swap a clip
+        b = net.forward_one_step(sig2, apply_softmax=False)
+    assert a.shape == (8, 256, 1, 16384)
+    assert torch.equal(a[[0, 1, 2, 4, 5, 6, 7], :, :, :9000], b[[0, 1, 2, 4, 5, 6, 7], :, :, :9000])   # causal, bit-exact
+    assert torch.equal(a[5, :, :, :9000], b[3, :, :, :9000])                                           # batch rows independent
+    assert not torch.equal(a[0, :, :, 9000:9010], b[0, :, :, 9000:9010])
+    assert torch.isfinite(a).all()
+    # spot columns against the oracle run on a short crop that covers their receptive field
+    ref = R.RefWaveNet(p, w)
+    t0 = 6000
+    crop = sig[2:3, t0 - 4100:t0 + 1]
+    with torch.no_grad():
+        r = ref.forward_one_step(R.onehot_t(crop, 256), apply_softmax=False).numpy()
+    np.testing.assert_allclose(to_np(a)[2, :, 0, t0], r[0, :, 0, -1], atol=ATOL)

@@ -1,0 +1,124 @@
+"""CPU: host logic and the C-ABI surface (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import wavenet_amd
+from wavenet_amd import _lib, data
+from wavenet_amd.wavenet import Params, WaveNet, zero_prefix
+from oracle import data_ref as D
+from oracle import wavenet_ref as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "wavenet_hip.h")).read()
+    declared = set(re.findall(r"\b(wn_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libwavenet_hip.so does not export %s" % name
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert _lib.lib().wn_abi_version() == 1
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    lib = _lib.lib()
+    rc = lib.wn_layer_fwd(None, None, None, None, None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 0, None)
+    assert rc == -1 and b"NULL" in lib.wn_last_error()
+    with pytest.raises(_lib.WaveNetHipError):
+        _lib.check(rc, "wn_layer_fwd")
+    assert lib.wn_layer_fast_path(32, 32, 2) == 1 and lib.wn_layer_fast_path(16, 16, 2) == 0
+
+
+def test_params_defaults_and_check():
+    p = Params()
+    assert p.quantization_steps == 256 and p.residual_conv_channels == [32] * 9 and p.optimizer == "adam"
+    p.check()
+    p2 = Params({"quantization_steps": 16, "softmax_conv_channels": [8, 16], "bogus": 1})
+    assert not hasattr(p2, "bogus")
+    p2.check()
+    p2.nonsense = 3
+    with pytest.raises(Exception, match="invalid parameter"):
+        p2.check()
+    p3 = Params({"quantization_steps": 10})
+    with pytest.raises(Exception, match="quantization_steps"):
+        p3.check()
+    assert set(Params().to_dict()) == set(R.DEFAULTS) | {"optimizer", "weight_decay", "momentum", "gradient_clipping"}
+
+
+@pytest.mark.parametrize("T,d,fw", [(16384, 512, 2), (16000, 512, 2), (8000, 8, 2), (7, 8, 2), (4094, 512, 2),
+                                    (100, 9, 3), (26, 27, 3), (10, 4, 4), (5, 1, 2)])
+def test_zero_prefix_matches_oracle(T, d, fw):
+    assert zero_prefix(T, d, fw) == R.conv_pad_and_prefix(T, d, fw)[1]
+
+
+def test_model_layout_matches_reference_names_and_shapes():
+    p = Params()
+    p.causal_conv_channels = [32]
+    p.residual_conv_channels = [32] * 10
+    p.residual_num_blocks = 4
+    p.softmax_conv_channels = [256, 256]
+    net = WaveNet(p, seed=0)
+    sd = net.state_dict()
+    specs = R.weight_specs(R.make_params(causal_conv_channels=[32], residual_conv_channels=[32] * 10,
+                                         residual_num_blocks=4, softmax_conv_channels=[256, 256]))
+    want = {}
+    for name, ws, bs in specs:
+        want[name + "/W"] = ws
+        if bs is not None:
+            want[name + "/b"] = bs
+    assert {k: v.shape for k, v in sd.items()} == want
+    assert net.num_parameters == 614656
+    assert net.receptive_field == 4093 and net.input_width == 4094
+    assert len(net.residual_blocks) == 4 and len(net.residual_blocks[0]) == 10
+    assert net.residual_blocks[1][3].wf.dilation == 8 and net.residual_blocks[1][3].wf.W.shape == (32, 32, 2, 1)
+    assert net.residual_blocks[1][0].wf.W.shape == (32, 32, 1, 2)
+    # round trip through the reference-keyed state dict
+    w = R.init_weights(R.make_params(causal_conv_channels=[32], residual_conv_channels=[32] * 10,
+                                     residual_num_blocks=4, softmax_conv_channels=[256, 256]))
+    net.load_state_dict(w)
+    for k, v in net.state_dict().items():
+        np.testing.assert_array_equal(v, w[k])
+    # grads are views of one flat buffer
+    assert net.residual_blocks[0][0].wf.W.grad.data_ptr() >= net._grad_arena.data_ptr()
+
+
+def test_forward_without_gpu_raises_instead_of_falling_back():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    net = WaveNet(Params({"causal_conv_channels": [8]}), seed=0)
+    with pytest.raises(wavenet_amd.WaveNetHipError):
+        net.forward_causal_block(np.zeros((1, 4), np.int32))
+    with pytest.raises(wavenet_amd.WaveNetHipError):
+        net.to_gpu()
+    with pytest.raises(Exception, match="cut cannot be less than one"):
+        net.slice_1d(torch.zeros(1, 1, 1, 4), 0)
+
+
+def test_no_product_import_of_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "wavenet_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src, "%s mentions the oracle" % f
+
+
+def test_data_formats_match_oracle():
+    idx = np.random.RandomState(0).randint(0, 256, (3, 40)).astype(np.int32)
+    np.testing.assert_array_equal(data.onehot_pixel_image(idx), D.onehot_pixel_image(idx))
+    s = np.random.RandomState(1).uniform(-1, 1, 1000)
+    np.testing.assert_array_equal(data.mulaw_encode(s), D.mulaw_quantize(s))
+    v = np.arange(-32768, 32768).astype(np.int16)
+    np.testing.assert_array_equal(data.mulaw_encode_pcm16(v), D.mulaw_quantize_pcm16(v.astype(np.int64)))
+    sig = np.arange(500, dtype=np.int32)
+    x, t = data.create_batch(sig, 4, 17, 20, rng=np.random.RandomState(3))
+    starts = np.random.RandomState(3).randint(0, 500 - 20 - 17 - 1, size=4)
+    xo, to = D.create_batch(sig, starts, 17, 20)
+    np.testing.assert_array_equal(x, xo)
+    np.testing.assert_array_equal(t, to)

@@ -1,0 +1,118 @@
+"""ctypes binding of libwavenet_hip.so (include/wavenet_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, the caller gets an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwavenet_hip.so")
+ABI_VERSION = 1
+
+WN_ACT_NONE, WN_ACT_RELU, WN_ACT_ELU = 0, 1, 2
+ACT = {"none": WN_ACT_NONE, None: WN_ACT_NONE, "relu": WN_ACT_RELU, "elu": WN_ACT_ELU}
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_i64 = C.c_int64
+_pp = C.POINTER(C.c_void_p)
+_ip = C.POINTER(C.c_int)
+
+
+class WnDecoderDesc(C.Structure):
+    _fields_ = [
+        ("Q", _i), ("fw_causal", _i), ("n_causal", _i), ("fw", _i), ("n_blocks", _i), ("n_layers", _i),
+        ("Cr", _i), ("Cs", _i), ("n_head", _i),
+        ("causal_channels", _ip), ("cd", _ip), ("head_channels", _ip),
+        ("causal_W", _pp), ("causal_b", _pp),
+        ("Wf", _pp), ("bf", _pp), ("Wg", _pp), ("bg", _pp), ("Wp", _pp), ("bp", _pp), ("Ws", _pp), ("bs", _pp),
+        ("head_W", _pp), ("head_b", _pp),
+        ("head_act", _i),
+    ]
+
+
+_SIGS = {
+    "wn_abi_version": (_i, []),
+    "wn_last_error": (C.c_char_p, []),
+    "wn_layer_fast_path": (_i, [_i, _i, _i]),
+    "wn_embed_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "wn_embed_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "wn_conv_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "wn_conv_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "wn_layer_fwd": (_i, [_p] * 11 + [_i] * 7 + [_p]),
+    "wn_layer_bwd": (_i, [_p] * 16 + [_i] * 7 + [_p]),
+    "wn_pointwise_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "wn_pointwise_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "wn_skip_sum_fwd": (_i, [_i, _pp, _pp, _pp, _ip, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "wn_skip_sum_bwd_dz": (_i, [_i, _pp, _ip, _p, _pp, _i, _i, _i, _i, _i, _p]),
+    "wn_skip_sum_bwd_dw": (_i, [_i, _pp, _ip, _p, _pp, _pp, _i, _i, _i, _i, _i, _p]),
+    "wn_softmax_fwd": (_i, [_p, _p, _i, _i, _p]),
+    "wn_softmax_xent": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "wn_nchw_to_btc": (_i, [_p, _p, _i, _i, _i, _p]),
+    "wn_btc_to_nchw": (_i, [_p, _p, _i, _i, _i, _p]),
+    "wn_decoder_create": (_i, [_pp, C.POINTER(WnDecoderDesc), _p]),
+    "wn_decoder_destroy": (_i, [_p]),
+    "wn_decoder_update_weights": (_i, [_p, C.POINTER(WnDecoderDesc), _p]),
+    "wn_decoder_load_state": (_i, [_p, _p, _i, _pp, _pp, _p]),
+    "wn_decoder_step": (_i, [_p, C.c_int32, _p, _i, _p]),
+    "wn_decoder_run": (_i, [_p, C.c_int32, _p, _i, _p, _p, _p]),
+    "wn_sample_categorical": (_i, [_p, _p, _p, _i, _i, _p]),
+    "wn_sqnorm": (_i, [_p, _p, _i64, _f, _f, _p, _p]),
+    "wn_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _f, _f, _p]),
+}
+
+EXPORTS = tuple(_SIGS)
+_lib: Optional[C.CDLL] = None
+
+
+class WaveNetHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load the library once; raise if it is absent (there is deliberately no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WaveNetHipError(
+                "%s not found: build it with `python -m wavenet_amd.build` (hipcc, gfx950)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)          # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        if l.wn_abi_version() != ABI_VERSION:
+            raise WaveNetHipError("ABI mismatch: library %d, binding %d" % (l.wn_abi_version(), ABI_VERSION))
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().wn_last_error().decode("utf-8", "replace")
+        raise WaveNetHipError("%s failed (%d): %s" % (what or "libwavenet_hip call", rc, msg))
+
+
+def ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def ptr_array(tensors: Sequence) -> "C.Array":
+    arr = (C.c_void_p * max(1, len(tensors)))()
+    for n, t in enumerate(tensors):
+        arr[n] = None if t is None else t.data_ptr()
+    return arr
+
+
+def int_array(vals: Sequence[int]) -> "C.Array":
+    return (C.c_int * max(1, len(vals)))(*[int(v) for v in vals])
+
+
+def stream_ptr() -> Optional[int]:
+    import torch
+    return torch.cuda.current_stream().cuda_stream or None

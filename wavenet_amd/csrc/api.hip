@@ -1,0 +1,181 @@
+// extern "C" surface of libwavenet_hip.so: argument checks, then dispatch to the MFMA kernels for
+// the shapes they cover and to the generic kernels for everything else.  No allocation, no sync.
+#include <string.h>
+
+#include "wn_kernels.hpp"
+
+namespace wn {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+// test hook: WAVENET_HIP_FORCE_GENERIC=1 routes every call to the generic kernels
+static bool force_generic() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("WAVENET_HIP_FORCE_GENERIC");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+}  // namespace wn
+
+using namespace wn;
+
+#define POS(x) WN_CHECK_ARG((x) > 0, "%s: %s must be positive (got %d)", __func__, #x, (int)(x))
+#define NN(p) WN_CHECK_ARG((p) != nullptr, "%s: %s is NULL", __func__, #p)
+
+extern "C" {
+
+int wn_abi_version(void) { return WN_ABI_VERSION; }
+const char* wn_last_error(void) { return g_err; }
+
+int wn_layer_fast_path(int Cr, int Cd, int fw) {
+    return (!force_generic() && mfma_layer_supported(Cr, Cd, fw)) ? 1 : 0;
+}
+
+int wn_embed_fwd(const int32_t* idx, const float* W, const float* bias, float* out, int B, int T, int Q, int C,
+                 int fw, void* stream) {
+    NN(idx); NN(W); NN(out); POS(B); POS(T); POS(Q); POS(C); POS(fw);
+    return generic_embed_fwd(idx, W, bias, out, B, T, Q, C, fw, as_stream(stream));
+}
+
+int wn_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* dbias, int B, int T, int Q, int C,
+                 int fw, void* stream) {
+    NN(idx); NN(dout); NN(dW); POS(B); POS(T); POS(Q); POS(C); POS(fw);
+    return generic_embed_bwd(idx, dout, dW, dbias, B, T, Q, C, fw, as_stream(stream));
+}
+
+int wn_conv_fwd(const float* x, const float* W, const float* bias, float* out, int B, int T, int Cin, int Cout,
+                int fw, int d, int Z, void* stream) {
+    NN(x); NN(W); NN(out); POS(B); POS(T); POS(Cin); POS(Cout); POS(fw); POS(d);
+    WN_CHECK_ARG(Z >= 0, "wn_conv_fwd: Z < 0");
+    return generic_conv_fwd(x, W, bias, out, B, T, Cin, Cout, fw, d, Z, as_stream(stream));
+}
+
+int wn_conv_bwd(const float* x, const float* W, const float* dout, float* dx, float* dW, float* dbias, int B,
+                int T, int Cin, int Cout, int fw, int d, int Z, void* stream) {
+    NN(x); NN(W); NN(dout); POS(B); POS(T); POS(Cin); POS(Cout); POS(fw); POS(d);
+    WN_CHECK_ARG(Z >= 0, "wn_conv_bwd: Z < 0");
+    return generic_conv_bwd(x, W, dout, dx, dW, dbias, B, T, Cin, Cout, fw, d, Z, as_stream(stream));
+}
+
+int wn_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg,
+                 const float* Wp, const float* bp, float* out, float* z, float* f_save, float* g_save, int B,
+                 int T, int Cr, int Cd, int fw, int d, int Z, void* stream) {
+    NN(x); NN(Wf); NN(Wg); NN(Wp); NN(out); NN(z);
+    POS(B); POS(T); POS(Cr); POS(Cd); POS(fw); POS(d);
+    WN_CHECK_ARG(Z >= 0, "wn_layer_fwd: Z < 0");
+    WN_CHECK_ARG((f_save == nullptr) == (g_save == nullptr), "wn_layer_fwd: f_save and g_save go together");
+    WN_CHECK_ARG(out != x, "wn_layer_fwd: out must not alias x (taps read x[t-d])");
+    if (wn_layer_fast_path(Cr, Cd, fw))
+        return mfma_layer_fwd(x, Wf, bf, Wg, bg, Wp, bp, out, z, f_save, g_save, B, T, d, Z, as_stream(stream));
+    return generic_layer_fwd(x, Wf, bf, Wg, bg, Wp, bp, out, z, f_save, g_save, B, T, Cr, Cd, fw, d, Z,
+                             as_stream(stream));
+}
+
+int wn_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
+                 const float* Wp, const float* dout, const float* dz_skip, float* dx, float* dWf, float* dbf,
+                 float* dWg, float* dbg, float* dWp, float* dbp, float* dab_ws, int B, int T, int Cr, int Cd,
+                 int fw, int d, int Z, void* stream) {
+    NN(x); NN(f); NN(g); NN(Wf); NN(Wg); NN(Wp); NN(dab_ws);
+    POS(B); POS(T); POS(Cr); POS(Cd); POS(fw); POS(d);
+    WN_CHECK_ARG(Z >= 0, "wn_layer_bwd: Z < 0");
+    WN_CHECK_ARG(dout || dz_skip, "wn_layer_bwd: both dout and dz_skip are NULL");
+    return generic_layer_bwd(x, f, g, Wf, Wg, Wp, dout, dz_skip, dx, dWf, dbf, dWg, dbg, dWp, dbp, dab_ws, B, T,
+                             Cr, Cd, fw, d, Z, as_stream(stream));
+}
+
+int wn_pointwise_fwd(const float* x, const float* W, const float* bias, float* out, int N, int Cin, int Cout,
+                     int act, void* stream) {
+    NN(x); NN(W); NN(out); POS(N); POS(Cin); POS(Cout);
+    WN_CHECK_ARG(act >= WN_ACT_NONE && act <= WN_ACT_ELU, "wn_pointwise_fwd: bad act %d", act);
+    return generic_pointwise_fwd(x, W, bias, out, N, Cin, Cout, act, as_stream(stream));
+}
+
+int wn_pointwise_bwd(const float* x, const float* W, const float* dout, float* dx, float* dW, float* dbias,
+                     int N, int Cin, int Cout, int act, void* stream) {
+    NN(x); NN(W); NN(dout); POS(N); POS(Cin); POS(Cout);
+    WN_CHECK_ARG(act >= WN_ACT_NONE && act <= WN_ACT_ELU, "wn_pointwise_bwd: bad act %d", act);
+    return generic_pointwise_bwd(x, W, dout, dx, dW, dbias, N, Cin, Cout, act, as_stream(stream));
+}
+
+static int check_skip(const char* fn, int L, int B, int T, int t_off, int Tw, int Cs) {
+    WN_CHECK_ARG(L > 0 && B > 0 && T > 0 && Tw > 0 && Cs > 0, "%s: non-positive size", fn);
+    WN_CHECK_ARG(t_off >= 0 && t_off + Tw <= T, "%s: columns [%d,%d) outside [0,%d)", fn, t_off, t_off + Tw, T);
+    return WN_OK;
+}
+
+int wn_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const float* const* bs, const int* cd,
+                    float* skip, int B, int T, int t_off, int Tw, int Cs, int accumulate, void* stream) {
+    NN(z); NN(Ws); NN(cd); NN(skip);
+    int rc = check_skip("wn_skip_sum_fwd", L, B, T, t_off, Tw, Cs);
+    if (rc) return rc;
+    for (int l = 0; l < L; ++l) WN_CHECK_ARG(z[l] && Ws[l] && cd[l] > 0, "wn_skip_sum_fwd: bad source %d", l);
+    return generic_skip_sum_fwd(L, z, Ws, bs, cd, skip, B, T, t_off, Tw, Cs, accumulate, as_stream(stream));
+}
+
+int wn_skip_sum_bwd_dz(int L, const float* const* Ws, const int* cd, const float* dskip, float* const* dz, int B,
+                       int T, int t_off, int Tw, int Cs, void* stream) {
+    NN(Ws); NN(cd); NN(dskip); NN(dz);
+    int rc = check_skip("wn_skip_sum_bwd_dz", L, B, T, t_off, Tw, Cs);
+    if (rc) return rc;
+    for (int l = 0; l < L; ++l) WN_CHECK_ARG(dz[l] && Ws[l] && cd[l] > 0, "wn_skip_sum_bwd_dz: bad entry %d", l);
+    return generic_skip_bwd_dz(L, Ws, cd, dskip, dz, B, T, t_off, Tw, Cs, as_stream(stream));
+}
+
+int wn_skip_sum_bwd_dw(int L, const float* const* z, const int* cd, const float* dskip, float* const* dWs,
+                       float* const* dbs, int B, int T, int t_off, int Tw, int Cs, void* stream) {
+    NN(z); NN(cd); NN(dskip);
+    int rc = check_skip("wn_skip_sum_bwd_dw", L, B, T, t_off, Tw, Cs);
+    if (rc) return rc;
+    return generic_skip_bwd_dw(L, z, cd, dskip, dWs, dbs, B, T, t_off, Tw, Cs, as_stream(stream));
+}
+
+int wn_softmax_fwd(const float* logits, float* prob, int N, int Q, void* stream) {
+    NN(logits); NN(prob); POS(N); POS(Q);
+    return generic_softmax(logits, prob, N, Q, as_stream(stream));
+}
+
+int wn_softmax_xent(const float* logits, const int32_t* target, float* loss, float* dlogits, int N, int Q,
+                    void* stream) {
+    NN(logits); NN(target); NN(loss); POS(N); POS(Q);
+    return generic_softmax_xent(logits, target, loss, dlogits, N, Q, as_stream(stream));
+}
+
+int wn_nchw_to_btc(const float* src, float* dst, int B, int C, int T, void* stream) {
+    NN(src); NN(dst); POS(B); POS(C); POS(T);
+    return generic_transpose(src, dst, B, C, T, as_stream(stream));
+}
+
+int wn_btc_to_nchw(const float* src, float* dst, int B, int C, int T, void* stream) {
+    NN(src); NN(dst); POS(B); POS(C); POS(T);
+    return generic_transpose(src, dst, B, T, C, as_stream(stream));
+}
+
+int wn_sample_categorical(const float* prob, const double* uniforms, int32_t* out, int n, int Q, void* stream) {
+    NN(prob); NN(uniforms); NN(out); POS(n); POS(Q);
+    return generic_sample(prob, uniforms, out, n, Q, as_stream(stream));
+}
+
+int wn_sqnorm(const float* grad, const float* param, int64_t n, float grad_mult, float weight_decay, float* out,
+              void* stream) {
+    NN(grad); NN(out);
+    WN_CHECK_ARG(n > 0, "wn_sqnorm: n <= 0");
+    WN_CHECK_ARG(weight_decay == 0.f || param, "wn_sqnorm: weight decay needs param");
+    return generic_sqnorm(grad, param, n, grad_mult, weight_decay, out, as_stream(stream));
+}
+
+int wn_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1,
+                 float beta2, float eps, float weight_decay, const float* sqnorm, float clip, float grad_mult,
+                 void* stream) {
+    NN(param); NN(grad); NN(m); NN(v);
+    WN_CHECK_ARG(n > 0, "wn_adam_step: n <= 0");
+    return generic_adam(param, grad, m, v, n, lr_t, beta1, beta2, eps, weight_decay, sqnorm, clip, grad_mult,
+                        as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,781 @@
+// Shape-generic fp32 kernels: correct for every Params the reference accepts (any channel widths,
+// any filter width, biases on or off).  One thread per output element, weights through L1/L2.
+// The shapes BASELINE.json names take the MFMA kernels in mfma_*.hip instead; these are the
+// fallback for everything else and the on-GPU cross-check of the fast kernels.
+#include "wn_common.hpp"
+
+namespace wn {
+
+static constexpr int kThreads = 256;
+
+// ---------------------------------------------------------------------------------------------
+// A10  embedding form of the first causal layer
+// ---------------------------------------------------------------------------------------------
+__global__ void k_embed_fwd(const int32_t* __restrict__ idx, const float* __restrict__ W,
+                            const float* __restrict__ bias, float* __restrict__ out,
+                            int B, int T, int Q, int C, int fw) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)B * T * C;
+    if (i >= total) return;
+    int c = (int)(i % C);
+    long long bt = i / C;
+    int t = (int)(bt % T);
+    int b = (int)(bt / T);
+    float acc = bias ? bias[c] : 0.f;
+    for (int k = 0; k < fw; ++k) {
+        int ts = t - (fw - 1 - k);
+        if (ts < 0) continue;
+        int q = idx[(long long)b * T + ts];
+        acc += W[((long long)c * Q + q) * fw + k];
+    }
+    out[i] = acc;
+}
+
+// dW accumulated through an LDS table [Q*fw][C] per block, then flushed with global atomics.
+__global__ void k_embed_bwd_lds(const int32_t* __restrict__ idx, const float* __restrict__ dout,
+                                float* __restrict__ dW, float* __restrict__ dbias,
+                                int B, int T, int Q, int C, int fw, int cols_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];   // [(q*fw+k)][c], then [C] bias
+    const int ntab = Q * fw * C;
+    float* btab = tab + ntab;
+    for (int i = threadIdx.x; i < ntab + C; i += blockDim.x) tab[i] = 0.f;
+    __syncthreads();
+    long long col0 = (long long)blockIdx.x * cols_per_block;
+    long long ncol = (long long)B * T;
+    long long work = (long long)cols_per_block * C;
+    for (long long w = threadIdx.x; w < work; w += blockDim.x) {
+        long long col = col0 + w / C;
+        if (col >= ncol) break;
+        int c = (int)(w % C);
+        int t = (int)(col % T);
+        int b = (int)(col / T);
+        float g = dout[col * C + c];
+        if (dbias) atomicAdd(&btab[c], g);
+        for (int k = 0; k < fw; ++k) {
+            int ts = t - (fw - 1 - k);
+            if (ts < 0) continue;
+            int q = idx[(long long)b * T + ts];
+            atomicAdd(&tab[(q * fw + k) * C + c], g);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) {
+        float v = tab[i];
+        if (v != 0.f) {
+            int c = i % C;
+            int qk = i / C;     // q*fw + k
+            atomicAdd(&dW[(long long)c * Q * fw + qk], v);
+        }
+    }
+    if (dbias)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&dbias[c], btab[c]);
+}
+
+__global__ void k_embed_bwd_atomic(const int32_t* __restrict__ idx, const float* __restrict__ dout,
+                                   float* __restrict__ dW, float* __restrict__ dbias,
+                                   int B, int T, int Q, int C, int fw) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)B * T * C;
+    if (i >= total) return;
+    int c = (int)(i % C);
+    long long bt = i / C;
+    int t = (int)(bt % T);
+    int b = (int)(bt / T);
+    float g = dout[i];
+    if (dbias) atomicAdd(&dbias[c], g);
+    for (int k = 0; k < fw; ++k) {
+        int ts = t - (fw - 1 - k);
+        if (ts < 0) continue;
+        int q = idx[(long long)b * T + ts];
+        atomicAdd(&dW[((long long)c * Q + q) * fw + k], g);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A5  dense dilated causal convolution
+// ---------------------------------------------------------------------------------------------
+__global__ void k_conv_fwd(const float* __restrict__ x, const float* __restrict__ W,
+                           const float* __restrict__ bias, float* __restrict__ out,
+                           int B, int T, int Cin, int Cout, int fw, int d, int Z) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)B * T * Cout;
+    if (i >= total) return;
+    int o = (int)(i % Cout);
+    long long bt = i / Cout;
+    int t = (int)(bt % T);
+    int b = (int)(bt / T);
+    if (t < Z) { out[i] = 0.f; return; }
+    float acc = bias ? bias[o] : 0.f;
+    const float* wrow = W + (long long)o * Cin * fw;
+    for (int k = 0; k < fw; ++k) {
+        int ts = t - (fw - 1 - k) * d;
+        if (ts < 0) continue;
+        const float* xr = x + ((long long)b * T + ts) * Cin;
+        for (int c = 0; c < Cin; ++c) acc += wrow[c * fw + k] * xr[c];
+    }
+    out[i] = acc;
+}
+
+__global__ void k_conv_bwd_dx(const float* __restrict__ W, const float* __restrict__ dout,
+                              float* __restrict__ dx, int B, int T, int Cin, int Cout, int fw, int d,
+                              int Z) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)B * T * Cin;
+    if (i >= total) return;
+    int c = (int)(i % Cin);
+    long long bt = i / Cin;
+    int t = (int)(bt % T);
+    int b = (int)(bt / T);
+    float acc = 0.f;
+    for (int k = 0; k < fw; ++k) {
+        int to = t + (fw - 1 - k) * d;
+        if (to >= T || to < Z) continue;
+        const float* gr = dout + ((long long)b * T + to) * Cout;
+        for (int o = 0; o < Cout; ++o) acc += W[((long long)o * Cin + c) * fw + k] * gr[o];
+    }
+    dx[i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic weight-gradient reduction:  dW[m*sm + k*sk] += sum_b sum_t A(b,t,m) * Bf(b,t,k)
+//   A(b,t,m)  = A[b*a_bs + (a_t0+t)*lda + m]
+//   Bf(b,t,k) = act(Bm[b*b_bs + (b_t0+t)*ldb + k]) (* B2[same]) ; 0 when b_t0+t < 0
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* A; long long a_bs; int a_t0; int lda;
+    const float* Bm; const float* B2; long long b_bs; int b_t0; int ldb;
+    int act;
+    int nB, tmin, nT, M, K;
+    float* dW; int sm, sk;
+    int t_chunk;
+};
+
+__global__ void k_wgrad(WgradArgs a) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;    // element m*K + k
+    int nchunk = (a.nT - a.tmin + a.t_chunk - 1) / a.t_chunk;
+    int b = blockIdx.y / nchunk;
+    int ch = blockIdx.y % nchunk;
+    if (e >= a.M * a.K) return;
+    int m = e / a.K, k = e % a.K;
+    int t0 = a.tmin + ch * a.t_chunk;
+    int t1 = min(a.nT, t0 + a.t_chunk);
+    float acc = 0.f;
+    for (int t = t0; t < t1; ++t) {
+        int tb = a.b_t0 + t;
+        if (tb < 0) continue;
+        long long bi = (long long)b * a.b_bs + (long long)tb * a.ldb + k;
+        float bv = a.Bm[bi];
+        if (a.B2) bv *= a.B2[bi];
+        bv = act_apply(bv, a.act);
+        acc += a.A[(long long)b * a.a_bs + (long long)(a.a_t0 + t) * a.lda + m] * bv;
+    }
+    atomicAdd(&a.dW[(long long)m * a.sm + (long long)k * a.sk], acc);
+}
+
+static int launch_wgrad(WgradArgs a, hipStream_t s) {
+    if (a.nT <= a.tmin || a.nB <= 0) return WN_OK;
+    a.t_chunk = 512;
+    int nchunk = (a.nT - a.tmin + a.t_chunk - 1) / a.t_chunk;
+    dim3 grid(cdiv((long long)a.M * a.K, kThreads), a.nB * nchunk);
+    hipLaunchKernelGGL(k_wgrad, grid, dim3(kThreads), 0, s, a);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+// column sums:  out[m] += sum_b sum_{t in [tmin,nT)} A(b,t,m)
+__global__ void k_colsum(const float* __restrict__ A, long long a_bs, int a_t0, int lda, int nB,
+                         int tmin, int nT, int M, float* __restrict__ out, int t_chunk) {
+    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    int nchunk = (nT - tmin + t_chunk - 1) / t_chunk;
+    int b = blockIdx.y / nchunk, ch = blockIdx.y % nchunk;
+    if (m >= M) return;
+    int t0 = tmin + ch * t_chunk, t1 = min(nT, t0 + t_chunk);
+    float acc = 0.f;
+    for (int t = t0; t < t1; ++t) acc += A[(long long)b * a_bs + (long long)(a_t0 + t) * lda + m];
+    atomicAdd(&out[m], acc);
+}
+
+static int launch_colsum(const float* A, long long a_bs, int a_t0, int lda, int nB, int tmin, int nT,
+                         int M, float* out, hipStream_t s) {
+    if (nT <= tmin || nB <= 0) return WN_OK;
+    int t_chunk = 1024;
+    int nchunk = (nT - tmin + t_chunk - 1) / t_chunk;
+    dim3 grid(cdiv(M, 64), nB * nchunk);
+    hipLaunchKernelGGL(k_colsum, grid, dim3(64), 0, s, A, a_bs, a_t0, lda, nB, tmin, nT, M, out, t_chunk);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A7  residual layer, generic
+// ---------------------------------------------------------------------------------------------
+__global__ void k_gate_fwd(const float* __restrict__ x, const float* __restrict__ Wf,
+                           const float* __restrict__ bf, const float* __restrict__ Wg,
+                           const float* __restrict__ bg, float* __restrict__ z,
+                           float* __restrict__ fs, float* __restrict__ gs,
+                           int B, int T, int Cr, int Cd, int fw, int d, int Z) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)B * T * Cd;
+    if (i >= total) return;
+    int o = (int)(i % Cd);
+    long long bt = i / Cd;
+    int t = (int)(bt % T);
+    int b = (int)(bt / T);
+    float a = 0.f, g = 0.f;
+    if (t >= Z) {
+        a = bf ? bf[o] : 0.f;
+        g = bg ? bg[o] : 0.f;
+        const float* wf = Wf + (long long)o * Cr * fw;
+        const float* wg = Wg + (long long)o * Cr * fw;
+        for (int k = 0; k < fw; ++k) {
+            int ts = t - (fw - 1 - k) * d;
+            if (ts < 0) continue;
+            const float* xr = x + ((long long)b * T + ts) * Cr;
+            for (int c = 0; c < Cr; ++c) {
+                float xv = xr[c];
+                a += wf[c * fw + k] * xv;
+                g += wg[c * fw + k] * xv;
+            }
+        }
+    }
+    float f = fast_tanh(a), s = fast_sigmoid(g);
+    z[i] = f * s;
+    if (fs) fs[i] = f;
+    if (gs) gs[i] = s;
+}
+
+__global__ void k_proj_res_fwd(const float* __restrict__ x, const float* __restrict__ z,
+                               const float* __restrict__ Wp, const float* __restrict__ bp,
+                               float* __restrict__ out, long long N, int Cr, int Cd) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Cr) return;
+    int o = (int)(i % Cr);
+    long long n = i / Cr;
+    float acc = bp ? bp[o] : 0.f;
+    const float* zr = z + n * Cd;
+    const float* w = Wp + (long long)o * Cd;
+    for (int c = 0; c < Cd; ++c) acc += w[c] * zr[c];
+    out[i] = acc + x[i];
+}
+
+// dab[b,t,0:Cd] = da, dab[b,t,Cd:2Cd] = dg
+__global__ void k_gate_bwd(const float* __restrict__ f, const float* __restrict__ g,
+                           const float* __restrict__ Wp, const float* __restrict__ dout,
+                           const float* __restrict__ dzs, float* __restrict__ dab,
+                           int B, int T, int Cr, int Cd, int Z) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)B * T * Cd;
+    if (i >= total) return;
+    int c = (int)(i % Cd);
+    long long bt = i / Cd;
+    int t = (int)(bt % T);
+    float da = 0.f, dg = 0.f;
+    if (t >= Z) {
+        float dz = dzs ? dzs[i] : 0.f;
+        if (dout) {
+            const float* gr = dout + bt * Cr;
+            for (int o = 0; o < Cr; ++o) dz += Wp[(long long)o * Cd + c] * gr[o];
+        }
+        float fv = f[i], gv = g[i];
+        da = dz * gv * (1.f - fv * fv);
+        dg = dz * fv * gv * (1.f - gv);
+    }
+    dab[bt * 2 * Cd + c] = da;
+    dab[bt * 2 * Cd + Cd + c] = dg;
+}
+
+__global__ void k_layer_bwd_dx(const float* __restrict__ Wf, const float* __restrict__ Wg,
+                               const float* __restrict__ dout, const float* __restrict__ dab,
+                               float* __restrict__ dx, int B, int T, int Cr, int Cd, int fw, int d) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)B * T * Cr;
+    if (i >= total) return;
+    int c = (int)(i % Cr);
+    long long bt = i / Cr;
+    int t = (int)(bt % T);
+    int b = (int)(bt / T);
+    float acc = dout ? dout[i] : 0.f;
+    for (int k = 0; k < fw; ++k) {
+        int to = t + (fw - 1 - k) * d;
+        if (to >= T) continue;
+        const float* r = dab + ((long long)b * T + to) * 2 * Cd;   // zero for to < Z already
+        for (int o = 0; o < Cd; ++o) {
+            acc += Wf[((long long)o * Cr + c) * fw + k] * r[o];
+            acc += Wg[((long long)o * Cr + c) * fw + k] * r[Cd + o];
+        }
+    }
+    dx[i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 convolution with pre-activation
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pointwise_fwd(const float* __restrict__ x, const float* __restrict__ W,
+                                const float* __restrict__ bias, float* __restrict__ out,
+                                long long N, int Cin, int Cout, int act) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Cout) return;
+    int o = (int)(i % Cout);
+    long long n = i / Cout;
+    float acc = bias ? bias[o] : 0.f;
+    const float* xr = x + n * Cin;
+    const float* w = W + (long long)o * Cin;
+    for (int c = 0; c < Cin; ++c) acc += w[c] * act_apply(xr[c], act);
+    out[i] = acc;
+}
+
+__global__ void k_pointwise_bwd_dx(const float* __restrict__ x, const float* __restrict__ W,
+                                   const float* __restrict__ dout, float* __restrict__ dx,
+                                   long long N, int Cin, int Cout, int act) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Cin) return;
+    int c = (int)(i % Cin);
+    long long n = i / Cin;
+    const float* gr = dout + n * Cout;
+    float acc = 0.f;
+    for (int o = 0; o < Cout; ++o) acc += W[(long long)o * Cin + c] * gr[o];
+    dx[i] = acc * act_grad(x[i], act);
+}
+
+// ---------------------------------------------------------------------------------------------
+// A11 deferred skip sum
+// ---------------------------------------------------------------------------------------------
+struct SkipArgs {
+    const float* z[WN_MAX_SRC];
+    const float* Ws[WN_MAX_SRC];
+    const float* bs[WN_MAX_SRC];
+    int cd[WN_MAX_SRC];
+    int L;
+};
+
+__global__ void k_skip_sum_fwd(SkipArgs a, float* __restrict__ skip, int B, int T, int t_off, int Tw,
+                               int Cs, int accumulate) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)B * Tw * Cs;
+    if (i >= total) return;
+    int o = (int)(i % Cs);
+    long long bt = i / Cs;
+    int t = (int)(bt % Tw);
+    int b = (int)(bt / Tw);
+    float acc = accumulate ? skip[i] : 0.f;
+    for (int l = 0; l < a.L; ++l) {
+        int cd = a.cd[l];
+        const float* zr = a.z[l] + ((long long)b * T + t_off + t) * cd;
+        const float* w = a.Ws[l] + (long long)o * cd;
+        float s = a.bs[l] ? a.bs[l][o] : 0.f;
+        for (int c = 0; c < cd; ++c) s += w[c] * zr[c];
+        acc += s;
+    }
+    skip[i] = acc;
+}
+
+__global__ void k_skip_bwd_dz(const float* __restrict__ Ws, const float* __restrict__ dskip,
+                              float* __restrict__ dz, int B, int T, int t_off, int Tw, int Cs, int cd) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)B * T * cd;
+    if (i >= total) return;
+    int c = (int)(i % cd);
+    long long bt = i / cd;
+    int t = (int)(bt % T);
+    int b = (int)(bt / T);
+    float acc = 0.f;
+    if (t >= t_off && t < t_off + Tw) {
+        const float* gr = dskip + ((long long)b * Tw + (t - t_off)) * Cs;
+        for (int o = 0; o < Cs; ++o) acc += Ws[(long long)o * cd + c] * gr[o];
+    }
+    dz[i] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// softmax / cross entropy: one wave per row
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ void k_softmax(const float* __restrict__ logits, float* __restrict__ prob, long long N, int Q) {
+    long long row = (long long)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* r = logits + row * Q;
+    float m = -INFINITY;
+    for (int q = lane; q < Q; q += 64) m = fmaxf(m, r[q]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int q = lane; q < Q; q += 64) s += expf(r[q] - m);
+    s = wave_sum(s);
+    float inv = 1.f / s;
+    for (int q = lane; q < Q; q += 64) prob[row * Q + q] = expf(r[q] - m) * inv;
+}
+
+__global__ void k_softmax_xent(const float* __restrict__ logits, const int32_t* __restrict__ target,
+                               float* __restrict__ loss, float* __restrict__ dlogits, long long N, int Q) {
+    long long row = (long long)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    int lane = threadIdx.x & 63;
+    __shared__ float part[16];
+    float rl = 0.f;
+    if (row < N) {
+        const float* r = logits + row * Q;
+        float m = -INFINITY;
+        for (int q = lane; q < Q; q += 64) m = fmaxf(m, r[q]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int q = lane; q < Q; q += 64) s += expf(r[q] - m);
+        s = wave_sum(s);
+        int tg = target[row];
+        float lse = m + logf(s);
+        rl = lse - r[tg];
+        if (dlogits) {
+            float inv = 1.f / s, invN = 1.f / (float)N;
+            for (int q = lane; q < Q; q += 64) {
+                float p = expf(r[q] - m) * inv;
+                dlogits[row * Q + q] = (p - (q == tg ? 1.f : 0.f)) * invN;
+            }
+        }
+    }
+    if (lane == 0) part[threadIdx.x / 64] = rl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < (int)(blockDim.x / 64); ++w) s += part[w];
+        atomicAdd(loss, s / (float)N);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout conversion (B,C,T) <-> (B,T,C) through a padded 32x32 LDS tile
+// ---------------------------------------------------------------------------------------------
+__global__ void k_transpose(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc) {
+    // src is [batch][R][Cc] -> dst [batch][Cc][R]
+    __shared__ float tile[32][33];
+    long long base = (long long)blockIdx.z * R * Cc;
+    int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        int r = r0 + j, c = c0 + threadIdx.x;
+        if (r < R && c < Cc) tile[j][threadIdx.x] = src[base + (long long)r * Cc + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        int c = c0 + j, r = r0 + threadIdx.x;
+        if (r < R && c < Cc) dst[base + (long long)c * R + r] = tile[threadIdx.x][j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// numpy-compatible categorical draw (generate.py:39)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_sample(const float* __restrict__ prob, const double* __restrict__ u,
+                         int32_t* __restrict__ out, int n, int Q) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = prob + (long long)i * Q;
+    double tot = 0.0;
+    for (int q = 0; q < Q; ++q) tot += (double)p[q];
+    double c = 0.0, uu = u[i];
+    int idx = Q;
+    for (int q = 0; q < Q; ++q) {
+        c += (double)p[q];
+        if (c / tot > uu) { idx = q; break; }
+    }
+    out[i] = idx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimiser step
+// ---------------------------------------------------------------------------------------------
+__global__ void k_sqnorm(const float* __restrict__ g, const float* __restrict__ p, long long n,
+                         float gmult, float wd, float* __restrict__ out) {
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float gi = g[i] * gmult;
+        if (p && wd != 0.f) gi += wd * p[i];
+        acc += gi * gi;
+    }
+    acc = wave_sum(acc);
+    __shared__ float part[16];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x / 64] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int w = 0; w < (int)(blockDim.x / 64); ++w) s += part[w];
+        atomicAdd(out, s);
+    }
+}
+
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                       float* __restrict__ v, long long n, float lr_t, float b1, float b2, float eps,
+                       float wd, const float* __restrict__ sqnorm, float clip, float gmult) {
+    // hook order of wavenet.py:477-480: WeightDecay first, then GradientClipping on the result
+    float rate = 1.f;
+    if (sqnorm && clip > 0.f) {
+        float nrm = sqrtf(*sqnorm);
+        if (nrm > 0.f && clip / nrm < 1.f) rate = clip / nrm;
+    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float gi = g[i] * gmult;
+        float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        gi *= rate;
+        float mi = m[i], vi = v[i];
+        mi += (1.f - b1) * (gi - mi);
+        vi += (1.f - b2) * (gi * gi - vi);
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+}  // namespace wn
+
+using namespace wn;
+
+// =============================================================================================
+// generic host entry points (called by the dispatching C ABI in api.hip)
+// =============================================================================================
+namespace wn {
+
+int generic_embed_fwd(const int32_t* idx, const float* W, const float* bias, float* out, int B, int T,
+                      int Q, int C, int fw, hipStream_t s) {
+    long long total = (long long)B * T * C;
+    hipLaunchKernelGGL(k_embed_fwd, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, s, idx, W, bias, out,
+                       B, T, Q, C, fw);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int generic_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* dbias, int B, int T,
+                      int Q, int C, int fw, hipStream_t s) {
+    size_t lds = ((size_t)Q * fw * C + C) * sizeof(float);
+    long long ncol = (long long)B * T;
+    if (lds <= 64 * 1024) {
+        int nblk = (int)(ncol < 512 ? (ncol + 63) / 64 : 512);
+        int cpb = (int)((ncol + nblk - 1) / nblk);
+        nblk = (int)((ncol + cpb - 1) / cpb);
+        hipLaunchKernelGGL(k_embed_bwd_lds, dim3(nblk), dim3(kThreads), lds, s, idx, dout, dW, dbias, B, T,
+                           Q, C, fw, cpb);
+    } else {
+        long long total = ncol * C;
+        hipLaunchKernelGGL(k_embed_bwd_atomic, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, s, idx, dout,
+                           dW, dbias, B, T, Q, C, fw);
+    }
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int generic_conv_fwd(const float* x, const float* W, const float* bias, float* out, int B, int T, int Cin,
+                     int Cout, int fw, int d, int Z, hipStream_t s) {
+    long long total = (long long)B * T * Cout;
+    hipLaunchKernelGGL(k_conv_fwd, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, s, x, W, bias, out, B, T,
+                       Cin, Cout, fw, d, Z);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+// dW[o][c][k] += sum_{t>=Z} dout[b,t,o] x[b,t-(fw-1-k)d,c]
+static int conv_dw(const float* x, const float* dout, int ld_dout, float* dW, int B, int T, int Cin, int Cout,
+                   int fw, int d, int Z, hipStream_t s) {
+    for (int k = 0; k < fw; ++k) {
+        WgradArgs a{};
+        a.A = dout; a.a_bs = (long long)T * ld_dout; a.a_t0 = 0; a.lda = ld_dout;
+        a.Bm = x; a.B2 = nullptr; a.b_bs = (long long)T * Cin; a.b_t0 = -(fw - 1 - k) * d; a.ldb = Cin;
+        a.act = WN_ACT_NONE;
+        a.nB = B; a.tmin = Z; a.nT = T; a.M = Cout; a.K = Cin;
+        a.dW = dW + k; a.sm = Cin * fw; a.sk = fw;
+        int rc = launch_wgrad(a, s);
+        if (rc) return rc;
+    }
+    return WN_OK;
+}
+
+int generic_conv_bwd(const float* x, const float* W, const float* dout, float* dx, float* dW, float* dbias,
+                     int B, int T, int Cin, int Cout, int fw, int d, int Z, hipStream_t s) {
+    if (dx) {
+        long long total = (long long)B * T * Cin;
+        hipLaunchKernelGGL(k_conv_bwd_dx, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, s, W, dout, dx, B, T,
+                           Cin, Cout, fw, d, Z);
+        WN_LAUNCH_CHECK();
+    }
+    if (dW) {
+        int rc = conv_dw(x, dout, Cout, dW, B, T, Cin, Cout, fw, d, Z, s);
+        if (rc) return rc;
+    }
+    if (dbias) return launch_colsum(dout, (long long)T * Cout, 0, Cout, B, Z, T, Cout, dbias, s);
+    return WN_OK;
+}
+
+int generic_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg,
+                      const float* Wp, const float* bp, float* out, float* z, float* fs, float* gs, int B,
+                      int T, int Cr, int Cd, int fw, int d, int Z, hipStream_t s) {
+    long long tot = (long long)B * T * Cd;
+    hipLaunchKernelGGL(k_gate_fwd, dim3(cdiv(tot, kThreads)), dim3(kThreads), 0, s, x, Wf, bf, Wg, bg, z, fs,
+                       gs, B, T, Cr, Cd, fw, d, Z);
+    WN_LAUNCH_CHECK();
+    long long N = (long long)B * T;
+    hipLaunchKernelGGL(k_proj_res_fwd, dim3(cdiv(N * Cr, kThreads)), dim3(kThreads), 0, s, x, z, Wp, bp, out,
+                       N, Cr, Cd);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int generic_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
+                      const float* Wp, const float* dout, const float* dzs, float* dx, float* dWf, float* dbf,
+                      float* dWg, float* dbg, float* dWp, float* dbp, float* dab, int B, int T, int Cr, int Cd,
+                      int fw, int d, int Z, hipStream_t s) {
+    long long tot = (long long)B * T * Cd;
+    hipLaunchKernelGGL(k_gate_bwd, dim3(cdiv(tot, kThreads)), dim3(kThreads), 0, s, f, g, Wp, dout, dzs, dab, B,
+                       T, Cr, Cd, Z);
+    WN_LAUNCH_CHECK();
+    if (dx) {
+        long long n = (long long)B * T * Cr;
+        hipLaunchKernelGGL(k_layer_bwd_dx, dim3(cdiv(n, kThreads)), dim3(kThreads), 0, s, Wf, Wg, dout, dab, dx,
+                           B, T, Cr, Cd, fw, d);
+        WN_LAUNCH_CHECK();
+    }
+    int rc;
+    if (dWf && (rc = conv_dw(x, dab, 2 * Cd, dWf, B, T, Cr, Cd, fw, d, Z, s))) return rc;
+    if (dWg && (rc = conv_dw(x, dab + Cd, 2 * Cd, dWg, B, T, Cr, Cd, fw, d, Z, s))) return rc;
+    if (dbf && (rc = launch_colsum(dab, (long long)T * 2 * Cd, 0, 2 * Cd, B, Z, T, Cd, dbf, s))) return rc;
+    if (dbg && (rc = launch_colsum(dab + Cd, (long long)T * 2 * Cd, 0, 2 * Cd, B, Z, T, Cd, dbg, s))) return rc;
+    if (dWp) {   // dWp[cr][cd] += dout z^T,  z = f*g
+        WgradArgs a{};
+        a.A = dout; a.a_bs = (long long)T * Cr; a.a_t0 = 0; a.lda = Cr;
+        a.Bm = f; a.B2 = g; a.b_bs = (long long)T * Cd; a.b_t0 = 0; a.ldb = Cd;
+        a.act = WN_ACT_NONE; a.nB = B; a.tmin = 0; a.nT = T; a.M = Cr; a.K = Cd;
+        a.dW = dWp; a.sm = Cd; a.sk = 1;
+        if ((rc = launch_wgrad(a, s))) return rc;
+    }
+    if (dbp && (rc = launch_colsum(dout, (long long)T * Cr, 0, Cr, B, 0, T, Cr, dbp, s))) return rc;
+    return WN_OK;
+}
+
+int generic_pointwise_fwd(const float* x, const float* W, const float* bias, float* out, long long N, int Cin,
+                          int Cout, int act, hipStream_t s) {
+    hipLaunchKernelGGL(k_pointwise_fwd, dim3(cdiv(N * Cout, kThreads)), dim3(kThreads), 0, s, x, W, bias, out, N,
+                       Cin, Cout, act);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int generic_pointwise_bwd(const float* x, const float* W, const float* dout, float* dx, float* dW, float* dbias,
+                          long long N, int Cin, int Cout, int act, hipStream_t s) {
+    if (dx) {
+        hipLaunchKernelGGL(k_pointwise_bwd_dx, dim3(cdiv(N * Cin, kThreads)), dim3(kThreads), 0, s, x, W, dout,
+                           dx, N, Cin, Cout, act);
+        WN_LAUNCH_CHECK();
+    }
+    int rc;
+    if (dW) {
+        WgradArgs a{};
+        a.A = dout; a.a_bs = 0; a.a_t0 = 0; a.lda = Cout;
+        a.Bm = x; a.B2 = nullptr; a.b_bs = 0; a.b_t0 = 0; a.ldb = Cin;
+        a.act = act; a.nB = 1; a.tmin = 0; a.nT = (int)N; a.M = Cout; a.K = Cin;
+        a.dW = dW; a.sm = Cin; a.sk = 1;
+        if ((rc = launch_wgrad(a, s))) return rc;
+    }
+    if (dbias && (rc = launch_colsum(dout, 0, 0, Cout, 1, 0, (int)N, Cout, dbias, s))) return rc;
+    return WN_OK;
+}
+
+int generic_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const float* const* bs,
+                         const int* cd, float* skip, int B, int T, int t_off, int Tw, int Cs, int accumulate,
+                         hipStream_t s) {
+    long long total = (long long)B * Tw * Cs;
+    for (int l0 = 0; l0 < L; l0 += WN_MAX_SRC) {
+        SkipArgs a{};
+        a.L = (L - l0 < WN_MAX_SRC) ? L - l0 : WN_MAX_SRC;
+        for (int l = 0; l < a.L; ++l) {
+            a.z[l] = z[l0 + l]; a.Ws[l] = Ws[l0 + l]; a.bs[l] = bs ? bs[l0 + l] : nullptr; a.cd[l] = cd[l0 + l];
+        }
+        hipLaunchKernelGGL(k_skip_sum_fwd, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, s, a, skip, B, T,
+                           t_off, Tw, Cs, (accumulate || l0 > 0) ? 1 : 0);
+        WN_LAUNCH_CHECK();
+    }
+    return WN_OK;
+}
+
+int generic_skip_bwd_dz(int L, const float* const* Ws, const int* cd, const float* dskip, float* const* dz,
+                        int B, int T, int t_off, int Tw, int Cs, hipStream_t s) {
+    for (int l = 0; l < L; ++l) {
+        long long total = (long long)B * T * cd[l];
+        hipLaunchKernelGGL(k_skip_bwd_dz, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, s, Ws[l], dskip, dz[l],
+                           B, T, t_off, Tw, Cs, cd[l]);
+        WN_LAUNCH_CHECK();
+    }
+    return WN_OK;
+}
+
+int generic_skip_bwd_dw(int L, const float* const* z, const int* cd, const float* dskip, float* const* dWs,
+                        float* const* dbs, int B, int T, int t_off, int Tw, int Cs, hipStream_t s) {
+    int rc;
+    for (int l = 0; l < L; ++l) {
+        if (dWs && dWs[l]) {
+            WgradArgs a{};
+            a.A = dskip; a.a_bs = (long long)Tw * Cs; a.a_t0 = 0; a.lda = Cs;
+            a.Bm = z[l]; a.B2 = nullptr; a.b_bs = (long long)T * cd[l]; a.b_t0 = t_off; a.ldb = cd[l];
+            a.act = WN_ACT_NONE; a.nB = B; a.tmin = 0; a.nT = Tw; a.M = Cs; a.K = cd[l];
+            a.dW = dWs[l]; a.sm = cd[l]; a.sk = 1;
+            if ((rc = launch_wgrad(a, s))) return rc;
+        }
+        if (dbs && dbs[l] &&
+            (rc = launch_colsum(dskip, (long long)Tw * Cs, 0, Cs, B, 0, Tw, Cs, dbs[l], s)))
+            return rc;
+    }
+    return WN_OK;
+}
+
+int generic_softmax(const float* logits, float* prob, long long N, int Q, hipStream_t s) {
+    hipLaunchKernelGGL(k_softmax, dim3(cdiv(N, 4)), dim3(256), 0, s, logits, prob, N, Q);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int generic_softmax_xent(const float* logits, const int32_t* target, float* loss, float* dlogits, long long N,
+                         int Q, hipStream_t s) {
+    WN_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
+    hipLaunchKernelGGL(k_softmax_xent, dim3(cdiv(N, 4)), dim3(256), 0, s, logits, target, loss, dlogits, N, Q);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int generic_transpose(const float* src, float* dst, int batch, int R, int Cc, hipStream_t s) {
+    dim3 grid(cdiv(Cc, 32), cdiv(R, 32), batch);
+    hipLaunchKernelGGL(k_transpose, grid, dim3(32, 8), 0, s, src, dst, R, Cc);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int generic_sample(const float* prob, const double* u, int32_t* out, int n, int Q, hipStream_t s) {
+    hipLaunchKernelGGL(k_sample, dim3(cdiv(n, 64)), dim3(64), 0, s, prob, u, out, n, Q);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int generic_sqnorm(const float* g, const float* p, long long n, float gmult, float wd, float* out,
+                   hipStream_t s) {
+    int blocks = (int)((n + 1023) / 1024);
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_sqnorm, dim3(blocks), dim3(256), 0, s, g, p, n, gmult, wd, out);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int generic_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2,
+                 float eps, float wd, const float* sqnorm, float clip, float gmult, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps, wd, sqnorm, clip,
+                       gmult);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+}  // namespace wn

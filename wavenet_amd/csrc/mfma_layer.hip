@@ -1,0 +1,143 @@
+// Fused residual layer forward on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), for the shape
+// BASELINE.json's configs 2-4 use: Cr = Cd = 32, filter width 2.  Reference op sequence replaced:
+// ResidualConvLayer.__call__ (wavenet.py:358-368) = 2 x DilatedConvolution1D.__call__
+// (wavenet.py:294-342) + tanh * sigmoid + projection_block + residual add.
+//
+// One wave owns a tile of 32 time columns and computes  D[channel][time] = W[channel][k] X[k][time]
+// with time on the MFMA's N (lane) axis.  The contraction order is permuted so that everything
+// stays in registers, no LDS and no cross-lane traffic:
+//
+//   k-step s (0..15), lane half h (lane>>5)  <->  channel ch(s,h) = (s&3) + 8(s>>2) + 4h
+//
+// With that order (a) a lane's 16 B-operand values of x[t] are four float4 loads (channels
+// 8q+4h .. 8q+4h+3), (b) the accumulator register r of lane (j,h) holds output channel ch(r,h) of
+// column j -- the same map -- so the gate output z is directly the B operand of the projection
+// MFMA, x[t] is directly its C input (the residual add is free), and out / z / f / g are stored as
+// float4 with the addresses of the loads.  Weights are read once per wave in their reference
+// layout W[o][c][k] (tap pairs are adjacent, so two float4 give both taps of four channels).
+//
+// Per tile: 64 + 16 MFMAs (5120 SIMD cycles); 2 KB + 2 KB of x read, 4 KB out + 4 KB z written.
+#include "wn_kernels.hpp"
+
+namespace wn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int ch_of(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
+
+template <bool SAVE_FG>
+__global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
+    const float* __restrict__ x, const float* __restrict__ Wf, const float* __restrict__ bf,
+    const float* __restrict__ Wg, const float* __restrict__ bg, const float* __restrict__ Wp,
+    const float* __restrict__ bp, float* __restrict__ out, float* __restrict__ zout,
+    float* __restrict__ fout, float* __restrict__ gout, int B, int T, int d, int Z, int tiles_per_b,
+    int ntiles) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31;      // time column inside the tile (B/D operand), weight row (A operand)
+    const int h = lane >> 5;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+
+    // ---- A operands: lane (i=j, h), step s holds W[i][ch(s,h)] ------------------------------
+    float wf0[16], wf1[16], wg0[16], wg1[16], wp[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        // Wf[i][c][k], c = 8q+4h .. +3, k = 0,1  ->  8 consecutive floats
+        const float4* pf = reinterpret_cast<const float4*>(Wf + ((j * 32) + 8 * q + 4 * h) * 2);
+        const float4* pg = reinterpret_cast<const float4*>(Wg + ((j * 32) + 8 * q + 4 * h) * 2);
+        float4 a0 = pf[0], a1 = pf[1], b0 = pg[0], b1 = pg[1];
+        wf0[4 * q + 0] = a0.x; wf1[4 * q + 0] = a0.y; wf0[4 * q + 1] = a0.z; wf1[4 * q + 1] = a0.w;
+        wf0[4 * q + 2] = a1.x; wf1[4 * q + 2] = a1.y; wf0[4 * q + 3] = a1.z; wf1[4 * q + 3] = a1.w;
+        wg0[4 * q + 0] = b0.x; wg1[4 * q + 0] = b0.y; wg0[4 * q + 1] = b0.z; wg1[4 * q + 1] = b0.w;
+        wg0[4 * q + 2] = b1.x; wg1[4 * q + 2] = b1.y; wg0[4 * q + 3] = b1.z; wg1[4 * q + 3] = b1.w;
+        float4 p4 = *reinterpret_cast<const float4*>(Wp + j * 32 + 8 * q + 4 * h);
+        wp[4 * q + 0] = p4.x; wp[4 * q + 1] = p4.y; wp[4 * q + 2] = p4.z; wp[4 * q + 3] = p4.w;
+    }
+    // biases in accumulator layout: register r of lane (.,h) is channel ch(r,h)
+    f32x16 bias_f, bias_g, bias_p;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        int c = ch_of(r, h);
+        bias_f[r] = bf ? bf[c] : 0.f;
+        bias_g[r] = bg ? bg[c] : 0.f;
+        bias_p[r] = bp ? bp[c] : 0.f;
+    }
+
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int b = tile / tiles_per_b;
+        const int t = (tile - b * tiles_per_b) * 32 + j;
+        const bool valid = t < T;
+        const bool has_old = valid && (t - d) >= 0;
+        const long long row = ((long long)b * T + t) * 32 + 4 * h;
+        float xc[16], xo[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = valid ? *reinterpret_cast<const float4*>(x + row + 8 * q) : make_float4(0, 0, 0, 0);
+            float4 o = has_old ? *reinterpret_cast<const float4*>(x + row - (long long)d * 32 + 8 * q)
+                               : make_float4(0, 0, 0, 0);
+            xc[4 * q + 0] = v.x; xc[4 * q + 1] = v.y; xc[4 * q + 2] = v.z; xc[4 * q + 3] = v.w;
+            xo[4 * q + 0] = o.x; xo[4 * q + 1] = o.y; xo[4 * q + 2] = o.z; xo[4 * q + 3] = o.w;
+        }
+        f32x16 aa = bias_f, ag = bias_g;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            aa = __builtin_amdgcn_mfma_f32_32x32x2f32(wf0[s], xo[s], aa, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_32x32x2f32(wg0[s], xo[s], ag, 0, 0, 0);
+            aa = __builtin_amdgcn_mfma_f32_32x32x2f32(wf1[s], xc[s], aa, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_32x32x2f32(wg1[s], xc[s], ag, 0, 0, 0);
+        }
+        const bool live = t >= Z;       // reference zero prefix: conv outputs (and bias) are 0 there
+        float zz[16], ff[16], gg[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float a = live ? aa[r] : 0.f;
+            float g = live ? ag[r] : 0.f;
+            ff[r] = fast_tanh(a);
+            gg[r] = fast_sigmoid(g);
+            zz[r] = ff[r] * gg[r];
+        }
+        f32x16 ao;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ao[r] = xc[r] + bias_p[r];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) ao = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[s], zz[s], ao, 0, 0, 0);
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                *reinterpret_cast<float4*>(out + row + 8 * q) =
+                    make_float4(ao[4 * q], ao[4 * q + 1], ao[4 * q + 2], ao[4 * q + 3]);
+                *reinterpret_cast<float4*>(zout + row + 8 * q) =
+                    make_float4(zz[4 * q], zz[4 * q + 1], zz[4 * q + 2], zz[4 * q + 3]);
+                if (SAVE_FG) {
+                    *reinterpret_cast<float4*>(fout + row + 8 * q) =
+                        make_float4(ff[4 * q], ff[4 * q + 1], ff[4 * q + 2], ff[4 * q + 3]);
+                    *reinterpret_cast<float4*>(gout + row + 8 * q) =
+                        make_float4(gg[4 * q], gg[4 * q + 1], gg[4 * q + 2], gg[4 * q + 3]);
+                }
+            }
+        }
+    }
+}
+
+bool mfma_layer_supported(int Cr, int Cd, int fw) { return Cr == 32 && Cd == 32 && fw == 2; }
+
+int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg,
+                   const float* Wp, const float* bp, float* out, float* z, float* fs, float* gs, int B, int T,
+                   int d, int Z, hipStream_t s) {
+    const int tiles_per_b = (T + 31) / 32;
+    const long long nt = (long long)B * tiles_per_b;
+    WN_CHECK_SHAPE(nt < (1ll << 31), "mfma_layer_fwd: too many tiles");
+    const int ntiles = (int)nt;
+    int blocks = (ntiles + 3) / 4;
+    if (blocks > 512) blocks = 512;          // 256 CUs x 2 resident workgroups; waves stride over tiles
+    if (fs)
+        hipLaunchKernelGGL(k_layer_fwd_mfma32<true>, dim3(blocks), dim3(256), 0, s, x, Wf, bf, Wg, bg, Wp, bp, out,
+                           z, fs, gs, B, T, d, Z, tiles_per_b, ntiles);
+    else
+        hipLaunchKernelGGL(k_layer_fwd_mfma32<false>, dim3(blocks), dim3(256), 0, s, x, Wf, bf, Wg, bg, Wp, bp,
+                           out, z, fs, gs, B, T, d, Z, tiles_per_b, ntiles);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+}  // namespace wn

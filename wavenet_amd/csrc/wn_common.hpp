@@ -1,0 +1,78 @@
+// Shared host/device helpers for libwavenet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/wavenet_hip.h"
+
+namespace wn {
+
+void set_error(const char* fmt, ...);
+
+#define WN_CHECK_ARG(cond, ...)                       \
+    do {                                              \
+        if (!(cond)) {                                \
+            wn::set_error(__VA_ARGS__);               \
+            return WN_EARG;                           \
+        }                                             \
+    } while (0)
+
+#define WN_CHECK_SHAPE(cond, ...)                     \
+    do {                                              \
+        if (!(cond)) {                                \
+            wn::set_error(__VA_ARGS__);               \
+            return WN_ESHAPE;                         \
+        }                                             \
+    } while (0)
+
+#define WN_HIP(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e__ = (expr);                                                            \
+        if (e__ != hipSuccess) {                                                            \
+            wn::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, \
+                          __LINE__);                                                        \
+            return WN_EHIP;                                                                 \
+        }                                                                                   \
+    } while (0)
+
+#define WN_LAUNCH_CHECK()                                                                 \
+    do {                                                                                  \
+        hipError_t e__ = hipGetLastError();                                               \
+        if (e__ != hipSuccess) {                                                          \
+            wn::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__),     \
+                          __FILE__, __LINE__);                                            \
+            return WN_EHIP;                                                               \
+        }                                                                                 \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- device math shared by the generic and the MFMA kernels ---------------------------------
+// tanh / sigmoid through one v_exp_f32 and one v_rcp_f32 each; absolute error ~1e-7, which is
+// what the 1e-4 logit tolerance of the north star needs (the reference computes them in float32
+// too: F.tanh, and F.sigmoid as tanh(x/2)/2+1/2).
+__device__ __forceinline__ float fast_tanh(float a) {
+    // 1 - 2/(1+e^{2a});  e^{2a} -> inf gives 1, -> 0 gives -1
+    float e = __expf(2.0f * a);
+    return 1.0f - 2.0f * __frcp_rn(1.0f + e);
+}
+__device__ __forceinline__ float fast_sigmoid(float a) {
+    float e = __expf(-a);
+    return __frcp_rn(1.0f + e);
+}
+__device__ __forceinline__ float act_apply(float x, int act) {
+    if (act == WN_ACT_RELU) return x > 0.f ? x : 0.f;
+    if (act == WN_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    return x;
+}
+// d act(x) / dx
+__device__ __forceinline__ float act_grad(float x, int act) {
+    if (act == WN_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    if (act == WN_ACT_ELU) return x > 0.f ? 1.f : expf(x);
+    return 1.f;
+}
+
+}  // namespace wn

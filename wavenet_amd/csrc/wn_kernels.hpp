@@ -1,0 +1,51 @@
+// Internal host-side launchers shared between translation units of libwavenet_hip.so.
+#pragma once
+#include "wn_common.hpp"
+
+namespace wn {
+
+// ---- generic_kernels.hip (any shape) --------------------------------------------------------
+int generic_embed_fwd(const int32_t*, const float*, const float*, float*, int, int, int, int, int, hipStream_t);
+int generic_embed_bwd(const int32_t*, const float*, float*, float*, int, int, int, int, int, hipStream_t);
+int generic_conv_fwd(const float*, const float*, const float*, float*, int, int, int, int, int, int, int,
+                     hipStream_t);
+int generic_conv_bwd(const float*, const float*, const float*, float*, float*, float*, int, int, int, int, int,
+                     int, int, hipStream_t);
+int generic_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg,
+                      const float* Wp, const float* bp, float* out, float* z, float* fs, float* gs, int B,
+                      int T, int Cr, int Cd, int fw, int d, int Z, hipStream_t s);
+int generic_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
+                      const float* Wp, const float* dout, const float* dzs, float* dx, float* dWf, float* dbf,
+                      float* dWg, float* dbg, float* dWp, float* dbp, float* dab, int B, int T, int Cr, int Cd,
+                      int fw, int d, int Z, hipStream_t s);
+int generic_pointwise_fwd(const float*, const float*, const float*, float*, long long, int, int, int,
+                          hipStream_t);
+int generic_pointwise_bwd(const float*, const float*, const float*, float*, float*, float*, long long, int, int,
+                          int, hipStream_t);
+int generic_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const float* const* bs,
+                         const int* cd, float* skip, int B, int T, int t_off, int Tw, int Cs, int accumulate,
+                         hipStream_t s);
+int generic_skip_bwd_dz(int L, const float* const* Ws, const int* cd, const float* dskip, float* const* dz,
+                        int B, int T, int t_off, int Tw, int Cs, hipStream_t s);
+int generic_skip_bwd_dw(int L, const float* const* z, const int* cd, const float* dskip, float* const* dWs,
+                        float* const* dbs, int B, int T, int t_off, int Tw, int Cs, hipStream_t s);
+int generic_softmax(const float*, float*, long long, int, hipStream_t);
+int generic_softmax_xent(const float*, const int32_t*, float*, float*, long long, int, hipStream_t);
+int generic_transpose(const float* src, float* dst, int batch, int R, int Cc, hipStream_t s);
+int generic_sample(const float*, const double*, int32_t*, int, int, hipStream_t);
+int generic_sqnorm(const float* g, const float* p, long long n, float gmult, float wd, float* out, hipStream_t s);
+int generic_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2,
+                 float eps, float wd, const float* sqnorm, float clip, float gmult, hipStream_t s);
+
+// ---- mfma_layer.hip: fp32-MFMA fused residual layer, Cr = Cd = 32, fw = 2 -------------------
+bool mfma_layer_supported(int Cr, int Cd, int fw);
+int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg,
+                   const float* Wp, const float* bp, float* out, float* z, float* fs, float* gs, int B, int T,
+                   int d, int Z, hipStream_t s);
+
+// ---- mfma_gemm.hip: fp32-MFMA channel GEMM over time columns --------------------------------
+// out[n, 0:M] (+)= sum_src W_src[M x K_src] act(X_src[n]) + bias ; see the file header.
+struct ColGemmSrc { const float* X; long long ldx; const float* W; int K; };
+bool mfma_colgemm_supported(int M, const int* Ks, int nsrc);
+
+}  // namespace wn

@@ -1,0 +1,166 @@
+"""`FasterWaveNet` with the reference's face (faster_wavenet.py:11-113), backed by the HIP decoder.
+
+The reference caches every layer's full-window output and rolls all caches by one column per
+generated sample.  Here the state is a handle owned by libwavenet_hip.so: per-layer rings of the
+last (fw-1)*d input columns in HBM, advanced by one persistent kernel (csrc/decoder.hip).
+
+Differences a caller can observe, both deliberate:
+* ``_forward_one_step`` returns ``(1, Q, 1, 1)`` -- the newest column -- not the full ``(1, Q, 1, W)``
+  window; the reference's caller reads ``[0, :, 0, -1]`` only (train_audio/generate.py:38), which
+  indexes the same values.
+* only the newest token of ``x_batch_data`` is read (the reference also reads nothing else of it:
+  wavenet.py:286), and an integer token may be passed instead of the one-hot window.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, ptr_array, int_array, stream_ptr, ACT
+from .wavenet import WaveNet, _as_view, _need_gpu
+
+
+class _RingState(object):
+    """Marker stored in prev_causal_outputs / prev_residual_outputs (the state itself is on the GPU)."""
+
+    def __init__(self, what):
+        self.what = what
+
+    def __repr__(self):
+        return "<device ring state: %s>" % self.what
+
+
+class FasterWaveNet(WaveNet):
+    fast_head_activation = "elu"       # faster_wavenet.py:108 (the normal head is ReLU, wavenet.py:588)
+
+    def __init__(self, params, compat_zero_prefix: bool = True, seed: Optional[int] = None):
+        self._dec = None
+        self._dec_keep = None
+        self._dec_stale = True
+        self.prev_causal_outputs = None
+        self.prev_residual_outputs = None
+        super().__init__(params, compat_zero_prefix=compat_zero_prefix, seed=seed)
+
+    def __del__(self):
+        try:
+            if self._dec is not None:
+                _lib.lib().wn_decoder_destroy(self._dec)
+        except Exception:
+            pass
+
+    def _weights_changed(self):
+        self._dec_stale = True
+
+    # -- decoder handle -------------------------------------------------------------------------
+    def _desc(self):
+        p = self.params
+        L = self._flat_layers
+        keep = dict(
+            causal_ch=int_array(p.causal_conv_channels), cd=int_array(p.residual_conv_channels),
+            head_ch=int_array(p.softmax_conv_channels),
+            causal_W=ptr_array([l.W for l in self.causal_conv_layers]),
+            causal_b=ptr_array([l.b for l in self.causal_conv_layers]),
+            Wf=ptr_array([l.wf.W for l in L]), bf=ptr_array([l.wf.b for l in L]),
+            Wg=ptr_array([l.wg.W for l in L]), bg=ptr_array([l.wg.b for l in L]),
+            Wp=ptr_array([l.projection_block.W for l in L]), bp=ptr_array([l.projection_block.b for l in L]),
+            Ws=ptr_array([l.projection_softmax.W for l in L]), bs=ptr_array([l.projection_softmax.b for l in L]),
+            head_W=ptr_array([l.W for l in self.softmax_conv_layers]),
+            head_b=ptr_array([l.b for l in self.softmax_conv_layers]))
+        d = _lib.WnDecoderDesc()
+        d.Q, d.fw_causal, d.n_causal = p.quantization_steps, p.causal_conv_filter_width, len(p.causal_conv_channels)
+        d.fw, d.n_blocks, d.n_layers = p.residual_conv_filter_width, p.residual_num_blocks, len(p.residual_conv_channels)
+        d.Cr, d.Cs, d.n_head = self._Cr, self._Cs, len(self.softmax_conv_layers)
+        d.causal_channels, d.cd, d.head_channels = keep["causal_ch"], keep["cd"], keep["head_ch"]
+        for k in ("causal_W", "causal_b", "Wf", "bf", "Wg", "bg", "Wp", "bp", "Ws", "bs", "head_W", "head_b"):
+            setattr(d, k, C.cast(keep[k], C.POINTER(C.c_void_p)))
+        d.head_act = ACT[self.fast_head_activation]
+        return d, keep
+
+    def _decoder(self):
+        lib = _lib.lib()
+        if self._dec is None:
+            d, keep = self._desc()
+            h = C.c_void_p()
+            check(lib.wn_decoder_create(C.byref(h), C.byref(d), stream_ptr()), "wn_decoder_create")
+            self._dec, self._dec_stale = h, False
+        elif self._dec_stale:
+            d, keep = self._desc()
+            check(lib.wn_decoder_update_weights(self._dec, C.byref(d), stream_ptr()), "wn_decoder_update_weights")
+            self._dec_stale = False
+        return self._dec
+
+    # -- the reference's face -------------------------------------------------------------------
+    def forward_one_step(self, x_batch, apply_softmax=True, as_numpy=False):
+        """Full forward over the window that also seeds the decoder state (faster_wavenet.py:13-47)."""
+        x = self.to_variable(x_batch)
+        _need_gpu(x)
+        if x.shape[0] != 1:
+            raise Exception("FasterWaveNet generates one utterance at a time (batch 1), like the reference")
+        with torch.no_grad():
+            causal_output = self.forward_causal_block(x)
+            _, sum_skip = self.forward_residual_block(causal_output)
+            out = self.forward_softmax_block(sum_skip, apply_softmax=apply_softmax)
+            tokens = (x if not x.is_floating_point() else x[:, :, 0, :].argmax(dim=1)).to(torch.int32).contiguous()
+            W = tokens.shape[1]
+            dec = self._decoder()
+            check(_lib.lib().wn_decoder_load_state(
+                dec, ptr(tokens), W, ptr_array([t.contiguous() for t in self._last_causal_outputs]),
+                ptr_array(self._last_layer_inputs), stream_ptr()), "wn_decoder_load_state")
+        self.prev_causal_outputs = _RingState("causal")
+        self.prev_residual_outputs = _RingState("residual")
+        return self.to_numpy(out) if as_numpy else out
+
+    def _forward_one_step(self, x_batch_data, apply_softmax=True, as_numpy=False):
+        """One incremental step (faster_wavenet.py:50-63); falls back to the full forward when the
+        state was reset by ``prev_causal_outputs = None``."""
+        if getattr(self, "prev_causal_outputs", None) is None:
+            return self.forward_one_step(x_batch_data, apply_softmax=apply_softmax, as_numpy=as_numpy)
+        if isinstance(x_batch_data, (int, np.integer)):
+            token = int(x_batch_data)
+        else:
+            x = x_batch_data
+            if isinstance(x, np.ndarray):
+                token = int(x[0, -1]) if x.ndim == 2 else int(np.argmax(x[0, :, 0, -1]))
+            else:
+                token = int(x[0, -1]) if x.dim() == 2 else int(x[0, :, 0, -1].argmax())
+        Q = self.params.quantization_steps
+        prob = torch.empty((1, 1, Q), device=self.device, dtype=torch.float32)
+        check(_lib.lib().wn_decoder_step(self._decoder(), token, ptr(prob), 1 if apply_softmax else 0, stream_ptr()),
+              "wn_decoder_step")
+        out = _as_view(prob)
+        return self.to_numpy(out) if as_numpy else out
+
+    # -- the whole generate loop on the device (train_audio/generate.py:9-60 with --fast) --------
+    def generate(self, n_samples: int, uniforms, initial_tokens=None, return_probs: bool = False):
+        """Emit ``n_samples`` tokens.  Step 1 is the full forward over the initial window (ReLU head,
+        like the reference's first ``_forward_one_step`` call); steps 2.. run inside one persistent
+        kernel with the ELU head.  ``uniforms[i]`` is the float64 draw numpy's ``choice`` would make
+        at step i (``RandomState.random_sample``)."""
+        p = self.params
+        Q = p.quantization_steps
+        iw = self.input_width
+        if initial_tokens is None:
+            initial_tokens = np.full((iw,), 127 if Q > 127 else Q // 2, dtype=np.int32)   # generate.py:21
+        tok = torch.as_tensor(np.asarray(initial_tokens, dtype=np.int32).reshape(1, -1)).to(self.device)
+        u = torch.as_tensor(np.asarray(uniforms, dtype=np.float64)).to(self.device)
+        if u.numel() < n_samples:
+            raise Exception("need one uniform per emitted sample")
+        lib = _lib.lib()
+        self.prev_causal_outputs = None
+        p0 = self.forward_one_step(tok, apply_softmax=True)          # (1,Q,1,W)
+        first_prob = p0[0, :, 0, -1].contiguous().view(1, Q)
+        out = torch.empty((n_samples,), device=self.device, dtype=torch.int32)
+        check(lib.wn_sample_categorical(ptr(first_prob), ptr(u), ptr(out), 1, Q, stream_ptr()),
+              "wn_sample_categorical")
+        probs = torch.empty((n_samples, Q), device=self.device, dtype=torch.float32) if return_probs else None
+        if return_probs:
+            probs[0] = first_prob[0]
+        if n_samples > 1:
+            first = int(out[0].item())
+            check(lib.wn_decoder_run(self._decoder(), first, ptr(u[1:]), n_samples - 1, ptr(out[1:]),
+                                     ptr(probs[1:]) if return_probs else None, stream_ptr()), "wn_decoder_run")
+        return (out, probs) if return_probs else out

@@ -1,0 +1,788 @@
+"""`WaveNet` / `Params` with the reference's Python face, backed by libwavenet_hip.so.
+
+Drop-in for wavenet.py of musyoku/wavenet: same class, method and hyper-parameter names (including
+``update_laerning_rate``), same logical tensor shapes ``(B, C, 1, T)`` and the same numerical
+conventions (zero prefix of the reshape-trick convolution, activation before every head conv,
+cross-entropy row order).  Nothing here computes on the CPU: every forward / backward FLOP is a HIP
+kernel reached through the C ABI in include/wavenet_hip.h, and calling a forward method without a
+GPU raises.  PyTorch supplies device memory, streams and the autograd tape only.
+
+Memory layout: activations live time-major / channel-minor, ``x[b][t][c]``; the tensors handed back
+to the caller are ``(B, C, 1, T)`` *views* of that storage (``torch.channels_last`` strides), so the
+reference's indexing (``out[0, :, 0, -1]``) works unchanged and no transpose is ever materialised on
+the hot path.  T-contiguous inputs (numpy one-hot images) are converted once at the boundary.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, ptr_array, int_array, stream_ptr, ACT
+
+
+# ----------------------------------------------------------------------------------------------
+# hyper-parameters (wavenet.py:100-173): same fields, same defaults, same checks
+# ----------------------------------------------------------------------------------------------
+class Params(object):
+    def __init__(self, dict=None):
+        self.quantization_steps = 256
+        self.sampling_rate = 8000
+        self.causal_conv_no_bias = True
+        self.causal_conv_filter_width = 2
+        self.causal_conv_channels = [128]
+        self.residual_conv_dilation_no_bias = True
+        self.residual_conv_projection_no_bias = True
+        self.residual_conv_filter_width = 2
+        self.residual_conv_channels = [32, 32, 32, 32, 32, 32, 32, 32, 32]
+        self.residual_num_blocks = 2
+        self.softmax_conv_no_bias = False
+        self.softmax_conv_channels = [128, 256]
+        self.optimizer = "adam"
+        self.weight_decay = 0
+        self.momentum = 0.9
+        self.gradient_clipping = 1.0
+        if dict:
+            self.from_dict(dict)
+
+    def from_dict(self, dict):
+        for attr, value in dict.items():
+            if hasattr(self, attr):           # unknown keys are ignored, wavenet.py:151-154
+                setattr(self, attr, value)
+
+    def to_dict(self):
+        return {attr: value for attr, value in self.__dict__.items()}
+
+    def dump(self):
+        print("params:")
+        for attr, value in self.__dict__.items():
+            print("	{}: {}".format(attr, value))
+
+    def check(self):
+        base = Params()
+        for attr in self.__dict__:
+            if not hasattr(base, attr):
+                raise Exception("invalid parameter '{}'".format(attr))
+        if self.quantization_steps != self.softmax_conv_channels[-1]:
+            raise Exception("quantization_steps != softmax_conv_channels[-1]")
+
+
+def zero_prefix(T: int, d: int, fw: int) -> int:
+    """Columns the reference's reshape trick leaves at exactly 0 (wavenet.py:303-340)."""
+    if d == 1:
+        return 0
+    pad = (-T) % d
+    if (T + pad) // d < fw:
+        pad += (fw - (T + pad) // d) * d
+    return max(0, (fw - 1) * d - pad)
+
+
+# ----------------------------------------------------------------------------------------------
+# tensor plumbing
+# ----------------------------------------------------------------------------------------------
+def _need_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise _lib.WaveNetHipError(
+            "this operation runs on the MI355X only: call to_gpu() first (there is no CPU path)")
+
+
+def _as_view(btc: torch.Tensor) -> torch.Tensor:
+    """(B,T,C) storage -> the reference's logical (B,C,1,T) shape, zero copy."""
+    B, T, Cc = btc.shape
+    return btc.view(B, T, 1, Cc).permute(0, 3, 2, 1)
+
+
+def _to_btc(x: torch.Tensor) -> torch.Tensor:
+    """Logical (B,C,1,T) tensor -> dense (B,T,C) storage; zero copy when x is one of our views."""
+    if x.dim() != 4 or x.shape[2] != 1:
+        raise Exception("expected a (B, C, 1, T) tensor, got %s" % (tuple(x.shape),))
+    B, Cc, _, T = x.shape
+    st = x.stride()
+    if (st[1] == 1 or Cc == 1) and (st[3] == Cc or T == 1) and (st[0] == T * Cc or B == 1):
+        return x.permute(0, 3, 2, 1).reshape(B, T, Cc)          # a view: memory already (B,T,C)
+    if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and not x.requires_grad:
+        out = torch.empty((B, T, Cc), device=x.device, dtype=torch.float32)
+        check(_lib.lib().wn_nchw_to_btc(ptr(x), ptr(out), B, Cc, T, stream_ptr()), "wn_nchw_to_btc")
+        return out
+    return x.permute(0, 3, 2, 1).reshape(B, T, Cc).contiguous()
+
+
+class _Fn(torch.autograd.Function):
+    """Base for the autograd nodes below.  Weight gradients are accumulated by the kernels straight
+    into the model's flat gradient arena (``p.grad`` are views of it), so backward returns None for
+    weights and tensors only for activations."""
+
+
+class _EmbedFn(_Fn):
+    @staticmethod
+    def forward(ctx, idx, W, b, fw, hook):
+        B, T = idx.shape
+        Cc, Q = W.shape[0], W.shape[1]
+        out = torch.empty((B, T, Cc), device=idx.device, dtype=torch.float32)
+        check(_lib.lib().wn_embed_fwd(ptr(idx), ptr(W), ptr(b), ptr(out), B, T, Q, Cc, fw, stream_ptr()),
+              "wn_embed_fwd")
+        ctx.save_for_backward(idx)
+        ctx.W, ctx.b, ctx.fw = W, b, fw
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        W, b = ctx.W, ctx.b
+        B, T = idx.shape
+        dout = dout.contiguous()
+        check(_lib.lib().wn_embed_bwd(ptr(idx), ptr(dout), ptr(W.grad), ptr(None if b is None else b.grad), B, T,
+                                      W.shape[1], W.shape[0], ctx.fw, stream_ptr()), "wn_embed_bwd")
+        return None, None, None, None, None
+
+
+class _ConvFn(_Fn):
+    """Dense dilated causal convolution (DilatedConvolution1D.__call__)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, fw, d, Z, hook):
+        B, T, Cin = x.shape
+        Cout = W.shape[0]
+        x = x.contiguous()
+        out = torch.empty((B, T, Cout), device=x.device, dtype=torch.float32)
+        check(_lib.lib().wn_conv_fwd(ptr(x), ptr(W), ptr(b), ptr(out), B, T, Cin, Cout, fw, d, Z, stream_ptr()),
+              "wn_conv_fwd")
+        ctx.save_for_backward(x)
+        ctx.W, ctx.b, ctx.geom = W, b, (fw, d, Z)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        W, b = ctx.W, ctx.b
+        fw, d, Z = ctx.geom
+        B, T, Cin = x.shape
+        dout = dout.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        check(_lib.lib().wn_conv_bwd(ptr(x), ptr(W), ptr(dout), ptr(dx), ptr(W.grad),
+                                     ptr(None if b is None else b.grad), B, T, Cin, W.shape[0], fw, d, Z,
+                                     stream_ptr()), "wn_conv_bwd")
+        return dx, None, None, None, None, None, None
+
+
+class _PointwiseFn(_Fn):
+    """out = W act(x) + b  (head convs, projection convs)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, hook):
+        lead = x.shape[:-1]
+        Cin, Cout = x.shape[-1], W.shape[0]
+        x2 = x.reshape(-1, Cin).contiguous()
+        out = torch.empty((x2.shape[0], Cout), device=x.device, dtype=torch.float32)
+        check(_lib.lib().wn_pointwise_fwd(ptr(x2), ptr(W), ptr(b), ptr(out), x2.shape[0], Cin, Cout, act,
+                                          stream_ptr()), "wn_pointwise_fwd")
+        ctx.save_for_backward(x2)
+        ctx.W, ctx.b, ctx.act, ctx.lead = W, b, act, lead
+        return out.view(*lead, Cout)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x2,) = ctx.saved_tensors
+        W, b = ctx.W, ctx.b
+        Cout, Cin = W.shape[0], x2.shape[1]
+        dout2 = dout.reshape(-1, Cout).contiguous()
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        check(_lib.lib().wn_pointwise_bwd(ptr(x2), ptr(W), ptr(dout2), ptr(dx), ptr(W.grad),
+                                          ptr(None if b is None else b.grad), x2.shape[0], Cin, Cout, ctx.act,
+                                          stream_ptr()), "wn_pointwise_bwd")
+        return (None if dx is None else dx.view(*ctx.lead, Cin)), None, None, None, None
+
+
+class _SoftmaxFn(_Fn):
+    @staticmethod
+    def forward(ctx, x):
+        Q = x.shape[-1]
+        x2 = x.reshape(-1, Q).contiguous()
+        out = torch.empty_like(x2)
+        check(_lib.lib().wn_softmax_fwd(ptr(x2), ptr(out), x2.shape[0], Q, stream_ptr()), "wn_softmax_fwd")
+        ctx.save_for_backward(out)
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):   # not on the reference's training path (train.py:76 passes apply_softmax=False)
+        (p,) = ctx.saved_tensors
+        g = dout.reshape(p.shape)
+        return (p * (g - (g * p).sum(-1, keepdim=True))).view(dout.shape)
+
+
+class _XentFn(_Fn):
+    @staticmethod
+    def forward(ctx, logits, target):
+        N, Q = logits.shape
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        dlog = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
+        check(_lib.lib().wn_softmax_xent(ptr(logits), ptr(target), ptr(loss), ptr(dlog), N, Q, stream_ptr()),
+              "wn_softmax_xent")
+        ctx.dlog = dlog
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        return ctx.dlog * dloss, None
+
+
+class _StackFn(_Fn):
+    """All residual layers + the deferred skip sum as ONE autograd node
+    (WaveNet.forward_residual_block, wavenet.py:572-582)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, net, t_off, train):
+        # `anchor` is a dummy leaf that requires grad: it keeps this node on the tape even when x
+        # does not require grad, because the weights are not tensor inputs of the node.
+        ctx.set_materialize_grads(False)
+        B, T, Cr = x.shape
+        x = x.contiguous()
+        lib, st = _lib.lib(), stream_ptr()
+        L = net._flat_layers
+        nL = len(L)
+        xs = [x]
+        zs, fs, gs = [], [], []
+        for lay in L:
+            Z = net._Z(T, lay.dilation)
+            out = torch.empty((B, T, Cr), device=x.device, dtype=torch.float32)
+            z = torch.empty((B, T, lay.cd), device=x.device, dtype=torch.float32)
+            f = torch.empty_like(z) if train else None
+            g = torch.empty_like(z) if train else None
+            check(lib.wn_layer_fwd(ptr(xs[-1]), ptr(lay.wf.W), ptr(lay.wf.b), ptr(lay.wg.W), ptr(lay.wg.b),
+                                   ptr(lay.projection_block.W), ptr(lay.projection_block.b), ptr(out), ptr(z),
+                                   ptr(f), ptr(g), B, T, Cr, lay.cd, lay.fw, lay.dilation, Z, st), "wn_layer_fwd")
+            xs.append(out)
+            zs.append(z); fs.append(f); gs.append(g)
+        Tw = T - t_off
+        Cs = net._Cs
+        skip = torch.empty((B, Tw, Cs), device=x.device, dtype=torch.float32)
+        net._skip_sum(zs, skip, B, T, t_off, Tw)
+        ctx.net, ctx.t_off, ctx.shape = net, t_off, (B, T, Cr)
+        ctx.xs = xs[:-1] if train else None      # inputs of every layer
+        ctx.zs, ctx.fs, ctx.gs = (zs, fs, gs) if train else (None, None, None)
+        net._last_layer_inputs = xs[:-1]         # FasterWaveNet seeds its rings from these
+        return xs[-1], skip
+
+    @staticmethod
+    def backward(ctx, dout, dskip):
+        net, t_off = ctx.net, ctx.t_off
+        B, T, Cr = ctx.shape
+        if ctx.xs is None:
+            raise _lib.WaveNetHipError("backward through a forward that ran without grad enabled")
+        lib, st = _lib.lib(), stream_ptr()
+        L = net._flat_layers
+        nL = len(L)
+        Tw = T - t_off
+        dev = ctx.xs[0].device
+        dzs = [None] * nL
+        if dskip is not None:
+            dskip = dskip.contiguous()
+            dzs = [torch.empty((B, T, lay.cd), device=dev, dtype=torch.float32) for lay in L]
+            cds = int_array([lay.cd for lay in L])
+            check(lib.wn_skip_sum_bwd_dz(nL, ptr_array([lay.projection_softmax.W for lay in L]), cds, ptr(dskip),
+                                         ptr_array(dzs), B, T, t_off, Tw, net._Cs, st), "wn_skip_sum_bwd_dz")
+            check(lib.wn_skip_sum_bwd_dw(nL, ptr_array(ctx.zs), cds, ptr(dskip),
+                                         ptr_array([lay.projection_softmax.W.grad for lay in L]),
+                                         ptr_array([None if lay.projection_softmax.b is None
+                                                    else lay.projection_softmax.b.grad for lay in L]),
+                                         B, T, t_off, Tw, net._Cs, st), "wn_skip_sum_bwd_dw")
+        g_out = None if dout is None else dout.contiguous()
+        maxcd = max(lay.cd for lay in L)
+        dab = torch.empty((B, T, 2 * maxcd), device=dev, dtype=torch.float32)
+        for j in range(nL - 1, -1, -1):
+            lay = L[j]
+            if g_out is None and dzs[j] is None:
+                continue
+            Z = net._Z(T, lay.dilation)
+            need_dx = j > 0 or ctx.needs_input_grad[0]
+            dx = torch.empty((B, T, Cr), device=dev, dtype=torch.float32) if need_dx else None
+            pb = lay.projection_block
+            has_do = g_out is not None
+            check(lib.wn_layer_bwd(ptr(ctx.xs[j]), ptr(ctx.fs[j]), ptr(ctx.gs[j]), ptr(lay.wf.W), ptr(lay.wg.W),
+                                   ptr(pb.W), ptr(g_out), ptr(dzs[j]), ptr(dx),
+                                   ptr(lay.wf.W.grad), ptr(None if lay.wf.b is None else lay.wf.b.grad),
+                                   ptr(lay.wg.W.grad), ptr(None if lay.wg.b is None else lay.wg.b.grad),
+                                   ptr(pb.W.grad if has_do else None),
+                                   ptr(pb.b.grad if (has_do and pb.b is not None) else None),
+                                   ptr(dab), B, T, Cr, lay.cd, lay.fw, lay.dilation, Z, st), "wn_layer_bwd")
+            g_out = dx
+            dzs[j] = None
+        ctx.xs = ctx.zs = ctx.fs = ctx.gs = None
+        return g_out, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------
+# links: objects with the attribute names the reference's scripts touch
+# ----------------------------------------------------------------------------------------------
+class _Link(object):
+    """A parameter holder: ``W`` (reference shape) and ``b`` (or None), views of the flat arena."""
+
+    def __init__(self, name: str, wshape: Tuple[int, ...], bshape: Optional[Tuple[int]]):
+        self.name, self.wshape, self.bshape = name, wshape, bshape
+        self.W: Optional[torch.Tensor] = None
+        self.b: Optional[torch.Tensor] = None
+
+
+class DilatedConvolution1D(_Link):
+    """Drop-in for wavenet.py:263-342 (``__call__`` = whole window, ``_forward`` = newest column)."""
+
+    def __init__(self, net, name, in_channels, out_channels, ksize, filter_width=2, dilation=1, nobias=False):
+        shape = (out_channels, in_channels) + tuple(ksize)
+        super().__init__(name, shape, None if nobias else (out_channels,))
+        self.net = net
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.filter_width, self.dilation = filter_width, dilation
+
+    def __call__(self, x):
+        x = self.net.to_variable(x)
+        _need_gpu(x)
+        xb = _to_btc(x)
+        Z = self.net._Z(xb.shape[1], self.dilation)
+        return _as_view(_ConvFn.apply(xb, self.W, self.b, self.filter_width, self.dilation, Z, self.net._hook))
+
+    def _forward(self, x_batch_data):
+        """Newest column only, batch 0 (wavenet.py:281-292); returns (1, Cout, 1, 1)."""
+        x = self.net.to_variable(x_batch_data)
+        _need_gpu(x)
+        need = (self.filter_width - 1) * self.dilation + 1
+        if x.shape[3] < need:
+            raise IndexError("window of %d columns is shorter than the layer's reach %d" % (x.shape[3], need))
+        cols = [x.shape[3] - 1 - (self.filter_width - 1 - k) * self.dilation for k in range(self.filter_width)]
+        taps = x[0:1, :, :, cols]                                   # (1, Cin, 1, fw), oldest first
+        with torch.no_grad():
+            out = _ConvFn.apply(_to_btc(taps), self.W, self.b, self.filter_width, 1, 0, None)
+        return _as_view(out[:, -1:, :])
+
+
+class Convolution1x1(_Link):
+    def __init__(self, net, name, in_channels, out_channels, nobias=False):
+        super().__init__(name, (out_channels, in_channels, 1, 1), None if nobias else (out_channels,))
+        self.net = net
+        self.in_channels, self.out_channels = in_channels, out_channels
+
+    def __call__(self, x, act="none"):
+        x = self.net.to_variable(x)
+        _need_gpu(x)
+        return _as_view(_PointwiseFn.apply(_to_btc(x), self.W, self.b, ACT[act], self.net._hook))
+
+
+class ResidualConvLayer(object):
+    """wavenet.py:344-368.  ``__call__`` returns (output, projection_softmax) like the reference."""
+
+    def __init__(self, net):
+        self.net = net
+        self.wf = self.wg = self.projection_block = self.projection_softmax = None
+
+    @property
+    def cd(self):
+        return self.wf.out_channels
+
+    @property
+    def fw(self):
+        return self.wf.filter_width
+
+    @property
+    def dilation(self):
+        return self.wf.dilation
+
+    def _run(self, xb, save):
+        B, T, Cr = xb.shape
+        out = torch.empty_like(xb)
+        z = torch.empty((B, T, self.cd), device=xb.device, dtype=torch.float32)
+        check(_lib.lib().wn_layer_fwd(ptr(xb), ptr(self.wf.W), ptr(self.wf.b), ptr(self.wg.W), ptr(self.wg.b),
+                                      ptr(self.projection_block.W), ptr(self.projection_block.b), ptr(out), ptr(z),
+                                      None, None, B, T, Cr, self.cd, self.fw, self.dilation,
+                                      self.net._Z(T, self.dilation), stream_ptr()), "wn_layer_fwd")
+        return out, z
+
+    def __call__(self, x):
+        """Inference-only single-layer call (training goes through forward_residual_block)."""
+        x = self.net.to_variable(x)
+        _need_gpu(x)
+        with torch.no_grad():
+            out, z = self._run(_to_btc(x).contiguous(), False)
+            skip = _PointwiseFn.apply(z, self.projection_softmax.W, self.projection_softmax.b, ACT["none"], None)
+        return _as_view(out), _as_view(skip)
+
+    def _forward(self, x):
+        """Newest column only (wavenet.py:350-356): (1,Cr,1,1), (1,Cs,1,1)."""
+        x = self.net.to_variable(x)
+        _need_gpu(x)
+        fw, d = self.fw, self.dilation
+        cols = [x.shape[3] - 1 - (fw - 1 - k) * d for k in range(fw)]
+        taps = _to_btc(x[0:1, :, :, cols]).contiguous()             # (1, fw, Cr)
+        with torch.no_grad():
+            B, T, Cr = taps.shape
+            out = torch.empty_like(taps)
+            z = torch.empty((B, T, self.cd), device=taps.device, dtype=torch.float32)
+            check(_lib.lib().wn_layer_fwd(ptr(taps), ptr(self.wf.W), ptr(self.wf.b), ptr(self.wg.W), ptr(self.wg.b),
+                                          ptr(self.projection_block.W), ptr(self.projection_block.b), ptr(out),
+                                          ptr(z), None, None, B, T, Cr, self.cd, fw, 1, 0, stream_ptr()),
+                  "wn_layer_fwd")
+            skip = _PointwiseFn.apply(z[:, -1:, :], self.projection_softmax.W, self.projection_softmax.b,
+                                      ACT["none"], None)
+        return _as_view(out[:, -1:, :]), _as_view(skip)
+
+
+# ----------------------------------------------------------------------------------------------
+# the model
+# ----------------------------------------------------------------------------------------------
+class WaveNet(object):
+    """Drop-in for wavenet.py:370-639."""
+
+    head_activation = "relu"          # wavenet.py:588
+
+    def __init__(self, params, compat_zero_prefix: bool = True, seed: Optional[int] = None):
+        params.check()
+        self.params = params
+        self.compat_zero_prefix = compat_zero_prefix
+        self._gpu = False
+        self._hook = None
+        self._anchor = torch.zeros((1,), requires_grad=True)
+        self._dp_group = None
+        self._last_layer_inputs = None
+        self.create_network()
+        self._allocate(seed)
+        self.setup_optimizer()
+
+    # -- topology (wavenet.py:379-455) --------------------------------------------------------
+    def create_network(self):
+        p = self.params
+        self.causal_conv_layers: List[DilatedConvolution1D] = []
+        fw = p.causal_conv_filter_width
+        chans = [p.quantization_steps] + list(p.causal_conv_channels)
+        for i in range(len(chans) - 1):
+            self.causal_conv_layers.append(DilatedConvolution1D(
+                self, "causal_%d" % i, chans[i], chans[i + 1], (1, fw), filter_width=fw, dilation=1,
+                nobias=p.causal_conv_no_bias))
+        self.residual_blocks: List[List[ResidualConvLayer]] = []
+        fw = p.residual_conv_filter_width
+        n_in = p.causal_conv_channels[-1]
+        n_skip = p.softmax_conv_channels[0]
+        for blk in range(p.residual_num_blocks):
+            layers = []
+            for li, n_out in enumerate(p.residual_conv_channels):
+                ksize = (1, fw) if li == 0 else (fw, 1)              # wavenet.py:418-424
+                lay = ResidualConvLayer(self)
+                pre = "residual_%d_block_%d_" % (blk, li)
+                lay.wf = DilatedConvolution1D(self, pre + "wf", n_in, n_out, ksize, filter_width=fw,
+                                              dilation=fw ** li, nobias=p.residual_conv_dilation_no_bias)
+                lay.wg = DilatedConvolution1D(self, pre + "wg", n_in, n_out, ksize, filter_width=fw,
+                                              dilation=fw ** li, nobias=p.residual_conv_dilation_no_bias)
+                lay.projection_block = Convolution1x1(self, pre + "projection_block", n_out, n_in,
+                                                      nobias=p.residual_conv_projection_no_bias)
+                lay.projection_softmax = Convolution1x1(self, pre + "projection_softmax", n_out, n_skip,
+                                                        nobias=p.residual_conv_projection_no_bias)
+                layers.append(lay)
+            self.residual_blocks.append(layers)
+        self.softmax_conv_layers: List[Convolution1x1] = []
+        sc = p.softmax_conv_channels
+        for i in range(len(sc) - 1):
+            self.softmax_conv_layers.append(Convolution1x1(self, "softmax_%d" % i, sc[i], sc[i + 1],
+                                                           nobias=p.softmax_conv_no_bias))
+        self._flat_layers = [lay for blk in self.residual_blocks for lay in blk]
+        self._Cr, self._Cs = n_in, n_skip
+
+    def links(self) -> List[_Link]:
+        """All parameter holders in the reference's registration order (wavenet.py:461-472)."""
+        out: List[_Link] = list(self.causal_conv_layers)
+        for lay in self._flat_layers:
+            out += [lay.wf, lay.wg, lay.projection_block, lay.projection_softmax]
+        return out + list(self.softmax_conv_layers)
+
+    # -- parameters: one flat arena (what the DP all-reduce and the optimiser kernel see) -----
+    def _allocate(self, seed):
+        rs = np.random.RandomState(seed) if seed is not None else np.random
+        spans = []
+        off = 0
+        for ln in self.links():
+            n = int(np.prod(ln.wshape))
+            spans.append((ln, "W", off, n, ln.wshape))
+            off += (n + 63) // 64 * 64                               # keep every tensor 256-byte aligned
+            if ln.bshape is not None:
+                spans.append((ln, "b", off, ln.bshape[0], ln.bshape))
+                off += (ln.bshape[0] + 63) // 64 * 64
+        self._spans = spans
+        host = np.zeros((off,), dtype=np.float32)
+        for ln, kind, o, n, shape in spans:
+            if kind == "W":                                         # LeCunNormal like Chainer's default
+                fan_in = shape[1] * shape[2] * shape[3]
+                host[o:o + n] = (rs.standard_normal(n) / math.sqrt(fan_in)).astype(np.float32)
+        self._arena = torch.from_numpy(host)
+        self._grad_arena = torch.zeros_like(self._arena)
+        self._bind()
+
+    def _bind(self):
+        self._any_requires_grad = True
+        for ln, kind, o, n, shape in self._spans:
+            t = self._arena[o:o + n].view(shape)
+            t.requires_grad_(True)
+            t.grad = self._grad_arena[o:o + n].view(shape)
+            setattr(ln, kind, t)
+
+    @property
+    def receptive_field(self) -> int:
+        """train_audio/train.py:36-38."""
+        p = self.params
+        return (p.residual_conv_filter_width ** len(p.residual_conv_channels) - 1) * p.residual_num_blocks + 1
+
+    @property
+    def input_width(self) -> int:
+        """Receptive field plus one column per causal layer (train_audio/train.py:42-44)."""
+        return self.receptive_field + len(self.params.causal_conv_channels)
+
+    @property
+    def num_parameters(self) -> int:
+        return sum(n for _, _, _, n, _ in self._spans)
+
+    def state_dict(self) -> Dict[str, np.ndarray]:
+        """Reference checkpoint keys (``<link>/W``, ``<link>/b``) and shapes."""
+        return {"%s/%s" % (ln.name, kind): self._arena[o:o + n].view(shape).detach().cpu().numpy().copy()
+                for ln, kind, o, n, shape in self._spans}
+
+    def load_state_dict(self, sd: Dict[str, np.ndarray]):
+        with torch.no_grad():
+            for ln, kind, o, n, shape in self._spans:
+                key = "%s/%s" % (ln.name, kind)
+                if key not in sd:
+                    raise KeyError(key)
+                a = np.asarray(sd[key], dtype=np.float32)
+                if a.shape != tuple(shape):
+                    raise Exception("shape of %s is %s, expected %s" % (key, a.shape, tuple(shape)))
+                self._arena[o:o + n].copy_(torch.from_numpy(a.reshape(-1)))
+        self._weights_changed()
+
+    def _weights_changed(self):
+        pass
+
+    # -- optimiser (wavenet.py:457-519) ---------------------------------------------------------
+    def setup_optimizer(self):
+        p = self.params
+        if p.optimizer != "adam":
+            raise NotImplementedError("only the reference's default optimizer 'adam' is built (got %r)" % p.optimizer)
+        self.optimizer = AdamState(self, alpha=0.0001, beta1=p.momentum)     # wavenet.py:475
+
+    def update_laerning_rate(self, lr):
+        self.optimizer.alpha = lr
+
+    def update_momentum(self, momentum):
+        self.optimizer.beta1 = momentum
+
+    def zero_grads(self):
+        self._grad_arena.zero_()
+
+    def backprop(self, loss):
+        """cleargrads -> backward -> [DP all-reduce] -> WeightDecay, GradientClipping -> Adam."""
+        self.zero_grads()
+        if callable(loss):
+            loss = loss()
+        loss.backward()
+        gmult = 1.0
+        if self._dp_group is not None:
+            gmult = self._dp_group.all_reduce_grads(self._grad_arena)
+        self.optimizer.update(gmult)
+        self._weights_changed()
+
+    # -- device --------------------------------------------------------------------------------
+    def to_gpu(self, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.WaveNetHipError("to_gpu(): no HIP device is visible")
+        _lib.lib()
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self._arena = self._arena.detach().to(dev)
+        self._grad_arena = self._grad_arena.to(dev)
+        self._bind()
+        self._anchor = torch.zeros((1,), device=dev, requires_grad=True)
+        self.optimizer.to(dev)
+        self._gpu = True
+        self._weights_changed()
+
+    @property
+    def gpu_enabled(self):
+        return self._gpu and torch.cuda.is_available()
+
+    @property
+    def device(self):
+        return self._arena.device
+
+    # -- small tensor helpers (wavenet.py:531-554) ---------------------------------------------
+    def slice_1d(self, x, cut=0):
+        if cut < 1:
+            raise Exception("CausalSlice1d: cut cannot be less than one.")      # wavenet.py:235-236
+        return self.to_variable(x)[:, :, :, cut:]
+
+    def padding_1d(self, x, pad=0):
+        return torch.nn.functional.pad(self.to_variable(x), (pad, 0))
+
+    def to_variable(self, x):
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x))
+        if not isinstance(x, torch.Tensor):
+            raise Exception("expected a numpy array or a torch tensor")
+        if self._gpu and not x.is_cuda:
+            x = x.to(self.device, non_blocking=True)
+        return x
+
+    def to_numpy(self, x):
+        if isinstance(x, torch.Tensor):
+            return x.detach().cpu().numpy()
+        return x
+
+    def get_batchsize(self, x):
+        return x.shape[0]
+
+    def _Z(self, T, d):
+        fw = self.params.residual_conv_filter_width
+        return zero_prefix(T, d, fw) if self.compat_zero_prefix else 0
+
+    # -- forward (wavenet.py:556-593) -----------------------------------------------------------
+    def forward_one_step(self, x_batch, apply_softmax=True, as_numpy=False):
+        causal_output = self.forward_causal_block(x_batch)
+        _, sum_skip_connections = self.forward_residual_block(causal_output)
+        softmax_output = self.forward_softmax_block(sum_skip_connections, apply_softmax=apply_softmax)
+        if as_numpy:
+            return self.to_numpy(softmax_output)
+        return softmax_output
+
+    def forward_causal_block(self, x_batch):
+        """Accepts the reference's one-hot image (B,Q,1,T) float32 *or* integer tokens (B,T): for
+        tokens the first layer is a row gather (out = W[:,idx[t-1],0] + W[:,idx[t],1]) instead of a
+        dense conv over 256 mostly-zero channels."""
+        x = self.to_variable(x_batch)
+        _need_gpu(x)
+        layers = self.causal_conv_layers
+        if not x.is_floating_point():
+            if x.dim() != 2:
+                raise Exception("integer input must be (B, T) tokens")
+            l0 = layers[0]
+            out = _EmbedFn.apply(x.to(torch.int32).contiguous(), l0.W, l0.b, l0.filter_width, self._hook)
+            start = 1
+        else:
+            out = _to_btc(x.to(torch.float32))
+            start = 0
+        outs = [out] if start == 1 else []
+        for lay in layers[start:]:
+            out = _ConvFn.apply(out, lay.W, lay.b, lay.filter_width, 1, 0, self._hook)
+            outs.append(out)
+        self._last_causal_outputs = outs                          # FasterWaveNet seeds its rings from these
+        return _as_view(out)
+
+    def forward_residual_block(self, x_batch, t_off: int = 0):
+        """(output, sum_skip_connections).  ``t_off`` > 0 (an extension) computes the skip sum for
+        columns t_off.. only -- what train.py:73 keeps -- instead of slicing it afterwards."""
+        x = self.to_variable(x_batch)
+        _need_gpu(x)
+        out, skip = _StackFn.apply(_to_btc(x), self._anchor, self, int(t_off), torch.is_grad_enabled())
+        return _as_view(out), _as_view(skip)
+
+    def forward_softmax_block(self, x_batch, apply_softmax=True, activation: Optional[str] = None):
+        x = self.to_variable(x_batch)
+        _need_gpu(x)
+        act = ACT[activation or self.head_activation]
+        out = _to_btc(x)
+        for lay in self.softmax_conv_layers:
+            out = _PointwiseFn.apply(out, lay.W, lay.b, act, self._hook)
+        if apply_softmax:
+            out = _SoftmaxFn.apply(out)
+        return _as_view(out)
+
+    # -- loss (wavenet.py:597-617) ----------------------------------------------------------------
+    def cross_entropy(self, raw_network_output, target_signal_data):
+        if isinstance(target_signal_data, torch.Tensor) and target_signal_data.requires_grad:
+            raise Exception("target_signal_data cannot be Variable")
+        raw = self.to_variable(raw_network_output)
+        _need_gpu(raw)
+        tgt = self.to_variable(np.asarray(target_signal_data) if not isinstance(target_signal_data, torch.Tensor)
+                               else target_signal_data)
+        if raw.shape[3] != tgt.shape[1]:
+            raise Exception("raw_network_output.width != target.width")
+        rows = _to_btc(raw)                                        # row b*T'+t, as after the reference's transpose
+        B, Tw, Q = rows.shape
+        return _XentFn.apply(rows.reshape(B * Tw, Q).contiguous(), tgt.to(torch.int32).reshape(-1).contiguous())
+
+    # -- the deferred skip projection -----------------------------------------------------------
+    def _skip_sum(self, zs: Sequence[torch.Tensor], skip: torch.Tensor, B, T, t_off, Tw):
+        L = self._flat_layers
+        check(_lib.lib().wn_skip_sum_fwd(
+            len(L), ptr_array(zs), ptr_array([lay.projection_softmax.W for lay in L]),
+            ptr_array([lay.projection_softmax.b for lay in L]), int_array([lay.cd for lay in L]), ptr(skip), B, T,
+            t_off, Tw, self._Cs, 0, stream_ptr()), "wn_skip_sum_fwd")
+
+    # -- checkpoints (wavenet.py:619-639): reference key names, .npz container (h5py is absent) --
+    def save(self, model_dir="./"):
+        os.makedirs(model_dir, exist_ok=True)
+        np.savez(os.path.join(model_dir, "wavenet.model.npz"), **self.state_dict())
+        np.savez(os.path.join(model_dir, "wavenet.opt.npz"), **self.optimizer.state_dict())
+
+    def load(self, model_dir="./"):
+        fn = os.path.join(model_dir, "wavenet.model.npz")
+        if os.path.isfile(fn):                                     # silently skipped when absent, like the reference
+            print("loading", fn, "...")
+            with np.load(fn) as z:
+                self.load_state_dict({k: z[k] for k in z.files})
+        fn = os.path.join(model_dir, "wavenet.opt.npz")
+        if os.path.isfile(fn):
+            print("loading", fn, "...")
+            with np.load(fn) as z:
+                self.optimizer.load_state_dict({k: z[k] for k in z.files})
+
+    # -- data parallel (new capability) -----------------------------------
+    def enable_data_parallel(self, group=None):
+        from .dp import DataParallel
+        self._dp_group = DataParallel(self, group)
+        return self._dp_group
+
+
+class AdamState(object):
+    """Chainer's Adam on the flat arena, with the reference's hook order (WeightDecay, then
+    GradientClipping; wavenet.py:477-480), as two kernel launches per step."""
+
+    def __init__(self, net: WaveNet, alpha=0.001, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.net = net
+        self.alpha, self.beta1, self.beta2, self.eps = alpha, beta1, beta2, eps
+        self.t = 0
+        self.m = torch.zeros_like(net._arena)
+        self.v = torch.zeros_like(net._arena)
+        self._norm = torch.zeros((1,), dtype=torch.float32)
+
+    def to(self, dev):
+        self.m, self.v, self._norm = self.m.to(dev), self.v.to(dev), self._norm.to(dev)
+
+    @property
+    def lr(self):
+        fix1 = 1.0 - self.beta1 ** self.t
+        fix2 = 1.0 - self.beta2 ** self.t
+        return self.alpha * math.sqrt(fix2) / fix1
+
+    def update(self, grad_mult: float = 1.0):
+        net = self.net
+        _need_gpu(net._arena)
+        self.t += 1
+        p = net.params
+        lib, st = _lib.lib(), stream_ptr()
+        n = net._arena.numel()
+        clip = float(p.gradient_clipping) if p.gradient_clipping and p.gradient_clipping > 0 else 0.0
+        wd = float(p.weight_decay) if p.weight_decay and p.weight_decay > 0 else 0.0
+        norm_ptr = None
+        if clip > 0:
+            self._norm.zero_()
+            check(lib.wn_sqnorm(ptr(net._grad_arena), ptr(net._arena), n, grad_mult, wd, ptr(self._norm), st),
+                  "wn_sqnorm")
+            norm_ptr = ptr(self._norm)
+        check(lib.wn_adam_step(ptr(net._arena), ptr(net._grad_arena), ptr(self.m), ptr(self.v), n, self.lr,
+                               self.beta1, self.beta2, self.eps, wd, norm_ptr, clip, grad_mult, st), "wn_adam_step")
+
+    def state_dict(self):
+        return {"t": np.array(self.t), "alpha": np.array(self.alpha), "m": self.m.cpu().numpy(),
+                "v": self.v.cpu().numpy()}
+
+    def load_state_dict(self, sd):
+        self.t = int(sd["t"])
+        self.alpha = float(sd["alpha"])
+        self.m.copy_(torch.from_numpy(np.asarray(sd["m"])))
+        self.v.copy_(torch.from_numpy(np.asarray(sd["v"])))
