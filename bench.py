@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Benchmark of the WaveNet hot path on MI355X (BASELINE.json metric: audio samples/sec, train
+fwd+bwd and AR-generate, 4x10-layer dilated stack).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one training step of config 2 (4 blocks x 10 dilations, 32 residual / 256 skip channels,
+fp32, 8 clips x 16,384 samples per GPU, loss over the last 12,290 columns as train_audio/train.py
+does): forward, cross-entropy, backward, [RCCL all-reduce], clip + Adam.  Inputs (tokens, targets)
+are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.  Besides `value` (train
+samples/s over all GPUs) the line carries the stack-forward rate, the AR-decode rate (config 4,
+N=1 only), `roofline` for the dominant kernel and `cpu_baseline` (the oracle's literal
+"Chainer-equivalent" restatement timed on this box's host cores, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from wavenet_amd import FasterWaveNet, Params, _lib, data     # noqa: E402
+
+CFG2 = dict(quantization_steps=256, sampling_rate=16000, causal_conv_channels=[32],
+            residual_conv_channels=[32] * 10, residual_num_blocks=4, softmax_conv_channels=[256, 256])
+B_PER_GPU, T = 8, 16384
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
+
+
+def make_batch(rank, world, iw):
+    """Synthetic 16 kHz clips -> mu-law tokens; targets are the next sample (train.py:14-22)."""
+    wav = data.synthetic_waveform(B_PER_GPU, T + 1, 16000, b0=rank * B_PER_GPU, Btot=world * B_PER_GPU)
+    tok = data.mulaw_encode(wav)
+    x = tok[:, :T]
+    tgt = tok[:, iw + 1:T + 1]
+    return torch.as_tensor(x).cuda(), torch.as_tensor(tgt).cuda()
+
+
+def train_step(net, x, tgt, iw):
+    c = net.forward_causal_block(x)
+    _, s = net.forward_residual_block(c, t_off=iw)            # skip sum for the columns train.py:73 keeps
+    logits = net.forward_softmax_block(s, apply_softmax=False)
+    loss = net.cross_entropy(logits, tgt)
+    net.backprop(loss)
+    return loss
+
+
+def stack_forward(net, c):
+    with torch.no_grad():
+        return net.forward_residual_block(c)
+
+
+def timed(fn, steps, warmup, barrier=None):
+    for _ in range(warmup):
+        fn()
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def cpu_baseline(budget_s=25.0):
+    """The oracle's literal restatement (oracle/wavenet_ref.py) on the host cores: train fwd+bwd at
+    config 2's topology, B=1 x T=16384 (CPU samples/s is batch-independent), and the full-window
+    fast decode (faster_wavenet.py:50-113 restated: caches rolled every step)."""
+    from oracle import wavenet_ref as R
+    from oracle import data_ref as D
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p = R.make_params(**{k: v for k, v in CFG2.items() if k != "sampling_rate"})
+    w = R.init_weights(p, 1234)
+    iw = R.input_width(p)
+    tok = D.mulaw_quantize(D.synthetic_waveform(1, T + 1, 16000))
+    x, tgt = tok[:, :T], tok[:, iw + 1:T + 1]
+    t0 = time.perf_counter()
+    R.train_step_grads(p, w, x, tgt)                                        # warm-up
+    one = time.perf_counter() - t0
+    reps = max(1, min(3, int(budget_s * 0.6 / max(one, 1e-3))))
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        R.train_step_grads(p, w, x, tgt)
+        ts.append(time.perf_counter() - t0)
+    train_sps = T / float(np.median(ts))
+    fast = R.RefFasterWaveNet(p, w)
+    buf = np.full((iw,), 127, np.int32)
+    fast._forward_one_step(D.onehot_pixel_image(buf.reshape(1, -1), 256))   # prefill
+    t0 = time.perf_counter()
+    n = 0
+    while n < 200 and time.perf_counter() - t0 < budget_s * 0.4:
+        buf = np.append(buf[1:], [n % 256]).astype(np.int32)
+        fast._forward_one_step(D.onehot_pixel_image(buf.reshape(1, -1), 256))
+        n += 1
+    dec_sps = n / (time.perf_counter() - t0)
+    return {"value": train_sps, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "oracle literal restatement (Chainer-equivalent op sequence, not Chainer), torch-CPU fp32, "
+                      "%d threads: train fwd+bwd cfg2 topology B=1 x T=16384, median of %d steps; "
+                      "fast decode %d steps at W=4094" % (cores, reps, n),
+            "decode_value": dec_sps, "decode_unit": "samples/s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--decode-samples", type=int, default=16000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local)
+    barrier = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        barrier = dist.barrier
+
+    p = Params(CFG2)
+    net = FasterWaveNet(p, seed=1234)
+    net.to_gpu()
+    net.update_laerning_rate(0.001)                                     # train_audio/args.py --lr default
+    if world > 1:
+        net.enable_data_parallel()
+    iw = net.input_width
+    x, tgt = make_batch(rank, world, iw)
+    assert _lib.lib().wn_layer_fast_path(32, 32, 2) == 1
+
+    # ---- the timed region: K training steps ------------------------------------------------
+    dom = ["wn_layer_fwd", "wn_layer_bwd", "wn_skip_sum_fwd", "wn_skip_sum_bwd_dz", "wn_skip_sum_bwd_dw",
+           "wn_pointwise_fwd", "wn_pointwise_bwd", "wn_embed_fwd", "wn_embed_bwd", "wn_softmax_xent",
+           "wn_adam_step", "wn_sqnorm"]
+    for _ in range(args.warmup):
+        train_step(net, x, tgt, iw)
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    with _lib.profile(dom) as prof:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = train_step(net, x, tgt, iw)
+        if barrier:
+            barrier()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    kms = {k: v for k, v in prof.ms().items() if v}
+    per_step = {k: sum(v) / args.steps for k, v in kms.items()}          # ms of each entry point per step
+    samples = world * B_PER_GPU * T
+    value = samples / dt
+
+    out = {
+        "metric": "audio samples/sec: train fwd+bwd, 4x10-layer dilated stack (cfg2)", "value": value,
+        "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg2 train step: 4 blocks x 10 dilations (1..512), 32 residual / 256 skip ch, "
+                               "16 kHz, %d clips x 16384 samples per GPU, loss over last 12290 columns, "
+                               "fwd + bwd + clip + Adam%s" % (B_PER_GPU, " + RCCL all-reduce" if world > 1 else ""),
+                   "global_batch": world * B_PER_GPU, "seq_len": T, "parallelism": "dp%d" % world},
+        "loss": float(loss),
+        "entry_point_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+    }
+
+    if rank == 0 and world == 1:
+        # ---- fused residual-stack forward (the north star's roofline target) -------------------
+        with torch.no_grad():
+            c = net.forward_causal_block(x)
+        names = ["wn_layer_fwd", "wn_skip_sum_fwd"]
+        timed(lambda: stack_forward(net, c), 2, 2)
+        with _lib.profile(names) as prof2:
+            sdt = timed(lambda: stack_forward(net, c), 10, 0)
+        ms2 = prof2.ms()
+        nl = len(net._flat_layers)
+        Cr, Cd, Cs = 32, 32, 256
+        alg_bytes_layer = 4 * (2 * Cr + 2 * Cs) * B_PER_GPU * T            # 2,304 B per sample-layer
+        alg_flops_layer = 2 * (2 * 2 * Cr * Cd + Cd * Cr + Cd * Cs) * B_PER_GPU * T
+        layer_ms = float(np.mean(ms2["wn_layer_fwd"]))
+        skip_ms = float(np.mean(ms2["wn_skip_sum_fwd"]))
+        stack_ms = layer_ms * nl + skip_ms
+        out["stack_forward"] = {
+            "samples_per_s": B_PER_GPU * T / sdt, "ms_wall": sdt * 1e3, "ms_kernels": stack_ms,
+            "wn_layer_fwd_ms": layer_ms, "wn_skip_sum_fwd_ms": skip_ms,
+            "algorithmic_GBps": nl * alg_bytes_layer / (stack_ms * 1e-3) / 1e9,
+            "frac_of_hbm_8TBps": nl * alg_bytes_layer / (stack_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "TFLOPs": nl * alg_flops_layer / (stack_ms * 1e-3) / 1e12,
+        }
+        # dominant kernel of the stack forward: the deferred skip contraction or the layer kernel
+        skip_flops = 2.0 * Cs * Cd * nl * B_PER_GPU * T
+        layer_flops = 2.0 * (2 * 2 * Cr * Cd + Cd * Cr) * B_PER_GPU * T
+        if skip_ms >= layer_ms * nl:
+            kname, kflops, kms_ = "wn_skip_sum_fwd", skip_flops, skip_ms
+        else:
+            kname, kflops, kms_ = "wn_layer_fwd", layer_flops, layer_ms
+        ach = kflops / (kms_ * 1e-3) / 1e12
+        out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TF,
+                           "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TF, "traffic": None,
+                           "launch_ms": kms_, "flops_per_launch": kflops}
+        # ---- AR decode, config 4: 16k samples on one GPU, persistent per-layer state -----------
+        if not args.no_decode:
+            n = args.decode_samples
+            u = np.random.RandomState(7).random_sample(n)
+            net.generate(64, u)                                           # warm-up (creates the handle)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            toks = net.generate(n, u)
+            torch.cuda.synchronize()
+            ddt = time.perf_counter() - t0
+            out["ar_generate"] = {"samples_per_s": n / ddt, "seconds": ddt, "samples": n,
+                                  "workload": "cfg4: faster_wavenet queue-cached decode, window 4094, 1 GPU",
+                                  "token_checksum": int(toks.sum().item())}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            if "ar_generate" in out:
+                out["ar_generate"]["vs_cpu_baseline"] = out["ar_generate"]["samples_per_s"] / \
+                    out["cpu_baseline"]["decode_value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

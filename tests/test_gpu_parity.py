@@ -234,12 +234,14 @@ def test_sampler_is_numpys_choice():
     u = np.array([np.random.RandomState(i).random_sample() for i in range(n)])
     want = np.array([np.random.RandomState(i).choice(np.arange(Q), p=prob[i]) for i in range(n)])
     out = torch.empty((n,), dtype=torch.int32, device="cuda")
-    check(_lib.lib().wn_sample_categorical(ptr(dev(prob)), ptr(dev(u)), ptr(out), n, Q, None))
+    dp, du = dev(prob), dev(u)                                # keep alive until the kernel has run
+    check(_lib.lib().wn_sample_categorical(ptr(dp), ptr(du), ptr(out), n, Q, None))
     np.testing.assert_array_equal(to_np(out), want)          # bit-exact indices
     # edge cases: u just below / at a cdf boundary, one-hot rows
     p1 = np.zeros((3, Q), np.float32); p1[0, 17] = 1; p1[1, 0] = 1; p1[2, Q - 1] = 1
     u1 = np.array([0.999999999, 0.0, 0.5])
-    check(_lib.lib().wn_sample_categorical(ptr(dev(p1)), ptr(dev(u1)), ptr(out), 3, Q, None))
+    dp1, du1 = dev(p1), dev(u1)
+    check(_lib.lib().wn_sample_categorical(ptr(dp1), ptr(du1), ptr(out), 3, Q, None))
     np.testing.assert_array_equal(to_np(out)[:3], [R.choice_from_uniform(p1[i], u1[i]) for i in range(3)])
 
 
@@ -407,3 +409,101 @@ def test_causality_and_batch_independence_at_full_size():
     with torch.no_grad():
         r = ref.forward_one_step(R.onehot_t(crop, 256), apply_softmax=False).numpy()
     np.testing.assert_allclose(to_np(a)[2, :, 0, t0], r[0, :, 0, -1], atol=ATOL)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,act,bias", [(1000, 64, 96, "elu", True), (37, 32, 32, "none", False),
+                                                 (4099, 256, 256, "relu", True), (130, 96, 160, "relu", True)])
+def test_pointwise_mfma_fwd_bwd(N, Cin, Cout, act, bias):
+    """colgemm (fp32 MFMA): ragged N, several M-tile groupings, activations, transposed-W dx."""
+    rs = np.random.RandomState(N)
+    x = rs.standard_normal((N, Cin)).astype(np.float32)
+    W = (rs.standard_normal((Cout, Cin)) / np.sqrt(Cin)).astype(np.float32)
+    b = rs.standard_normal(Cout).astype(np.float32) if bias else None
+    g = rs.standard_normal((N, Cout)).astype(np.float32)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    Wt = torch.tensor(W, dtype=torch.float64, requires_grad=True)
+    a = {"elu": torch.nn.functional.elu, "relu": torch.relu, "none": lambda v: v}[act](xt)
+    ref = a @ Wt.T + (0 if b is None else torch.tensor(b, dtype=torch.float64))
+    ref.backward(torch.tensor(g, dtype=torch.float64))
+    lib = _lib.lib()
+    dx_, dW_, db_ = dev(x), dev(W), (None if b is None else dev(b))
+    out = torch.empty((N, Cout), device="cuda")
+    check(lib.wn_pointwise_fwd(ptr(dx_), ptr(dW_), ptr(db_), ptr(out), N, Cin, Cout, _lib.ACT[act], None))
+    np.testing.assert_allclose(to_np(out), ref.detach().numpy(), atol=ATOL)
+    gd = dev(g)
+    dx = torch.empty((N, Cin), device="cuda")
+    dW = torch.zeros((Cout, Cin), device="cuda")
+    dbias = torch.zeros((Cout,), device="cuda") if bias else None
+    check(lib.wn_pointwise_bwd(ptr(dx_), ptr(dW_), ptr(gd), ptr(dx), ptr(dW), ptr(dbias), N, Cin, Cout, _lib.ACT[act], None))
+    np.testing.assert_allclose(to_np(dx), xt.grad.numpy(), atol=ATOL)
+    np.testing.assert_allclose(to_np(dW), Wt.grad.numpy(), atol=1e-4 * max(1.0, float(Wt.grad.abs().max())))
+    if bias:
+        np.testing.assert_allclose(to_np(dbias), g.astype(np.float64).sum(0), atol=1e-3)
+
+
+def _layer_bwd_ref(x, Wf, Wg, Wp, b, Z, d, fw, dout, dzs):
+    """float64 autograd through the closed form of one residual layer (+ an explicit dz_skip term)."""
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    ws = [torch.tensor(w, dtype=torch.float64, requires_grad=True) for w in (Wf, Wg, Wp)]
+    bs = [None if v is None else torch.tensor(v, dtype=torch.float64, requires_grad=True) for v in b]
+    B, Cr, _, T = x.shape
+    Cd = Wf.shape[0]
+
+    def conv(W, bias):
+        Wk = W.reshape(Cd, Cr, fw)
+        out = torch.zeros((B, Cd, 1, T), dtype=torch.float64)
+        for k in range(fw):
+            s = (fw - 1 - k) * d
+            if s < T:
+                out[:, :, 0, s:] = out[:, :, 0, s:] + torch.einsum("oc,bct->bot", Wk[:, :, k], xt[:, :, 0, :T - s])
+        if bias is not None:
+            out = out + bias.reshape(1, -1, 1, 1)
+        mask = torch.ones(T, dtype=torch.float64)
+        mask[:Z] = 0
+        return out * mask
+    f_ = torch.tanh(conv(ws[0], bs[0]))
+    g_ = torch.sigmoid(conv(ws[1], bs[1]))
+    z = f_ * g_
+    out = torch.einsum("oc,bcht->boht", ws[2], z) + xt
+    if bs[2] is not None:
+        out = out + bs[2].reshape(1, -1, 1, 1)
+    loss = (z * torch.tensor(dzs, dtype=torch.float64)).sum()
+    if dout is not None:
+        loss = loss + (out * torch.tensor(dout, dtype=torch.float64)).sum()
+    loss.backward()
+    return xt.grad.numpy(), [w.grad.numpy() for w in ws], [None if v is None else v.grad for v in bs], \
+        f_.detach().numpy(), g_.detach().numpy()
+
+
+@pytest.mark.parametrize("Cr,Cd,fw,d,B,T,bias,with_dout", [
+    (32, 32, 2, 1, 2, 100, False, True), (32, 32, 2, 512, 2, 1100, True, True), (32, 32, 2, 16, 3, 257, False, False),
+    (32, 32, 2, 64, 1, 31, True, True), (32, 32, 2, 256, 1, 2048, False, True),
+    (16, 12, 3, 9, 2, 77, True, True), (8, 8, 2, 4, 1, 40, False, False)])
+def test_layer_bwd(Cr, Cd, fw, d, B, T, bias, with_dout):
+    """wn_layer_bwd: MFMA path (32/32/2) and generic path against float64 autograd."""
+    rs = np.random.RandomState(T + d)
+    x, Wf, Wg, Wp, b, Z, _, _, _, _ = _layer_case(Cr, Cd, fw, d, B, T, bias, seed=T)
+    dout = rs.standard_normal((B, Cr, 1, T)).astype(np.float32) if with_dout else None
+    dzs = rs.standard_normal((B, Cd, 1, T)).astype(np.float32)
+    dx_ref, dW_ref, db_ref, f_, g_ = _layer_bwd_ref(x, Wf, Wg, Wp, b, Z, d, fw, dout, dzs)
+    lib = _lib.lib()
+    xb, fb, gb = dev(btc(x)), dev(btc(f_.astype(np.float32))), dev(btc(g_.astype(np.float32)))
+    wt = [dev(Wf), dev(Wg), dev(Wp)]
+    do = None if dout is None else dev(btc(dout))
+    dz = dev(btc(dzs))
+    dx = torch.empty_like(xb)
+    gW = [torch.zeros_like(w) for w in wt]
+    gb_ = [torch.zeros(n, device="cuda") if bias else None for n in (Cd, Cd, Cr)]
+    dab = torch.empty((B, T, 2 * Cd), device="cuda")
+    check(lib.wn_layer_bwd(ptr(xb), ptr(fb), ptr(gb), ptr(wt[0]), ptr(wt[1]), ptr(wt[2]), ptr(do), ptr(dz), ptr(dx),
+                           ptr(gW[0]), ptr(gb_[0]), ptr(gW[1]), ptr(gb_[1]),
+                           ptr(gW[2] if with_dout else None), ptr(gb_[2] if with_dout else None), ptr(dab),
+                           B, T, Cr, Cd, fw, d, Z, None), "wn_layer_bwd")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(to_np(dx), btc(dx_ref), atol=2e-4)
+    for k in range(3 if with_dout else 2):
+        sc = max(1.0, np.abs(dW_ref[k]).max())
+        np.testing.assert_allclose(to_np(gW[k]).reshape(dW_ref[k].shape), dW_ref[k], atol=2e-4 * sc)
+    if bias:
+        for k in range(3 if with_dout else 2):
+            np.testing.assert_allclose(to_np(gb_[k]), db_ref[k].numpy(), atol=2e-4 * max(1.0, float(db_ref[k].abs().max())))

@@ -67,6 +67,7 @@ _SIGS = {
 
 EXPORTS = tuple(_SIGS)
 _lib: Optional[C.CDLL] = None
+_profile = None          # {entry point name: [(start_event, end_event), ...]} while profiling is on
 
 
 class WaveNetHipError(RuntimeError):
@@ -88,7 +89,54 @@ def lib() -> C.CDLL:
         if l.wn_abi_version() != ABI_VERSION:
             raise WaveNetHipError("ABI mismatch: library %d, binding %d" % (l.wn_abi_version(), ABI_VERSION))
         _lib = l
-    return _lib
+    return _lib if _profile is None else _Profiled(_lib)
+
+
+class _Profiled(object):
+    """Proxy used only inside :func:`profile`: brackets the selected entry points with HIP events
+    recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self, raw):
+        self._raw = raw
+
+    def __getattr__(self, name):
+        fn = getattr(self._raw, name)
+        rec = _profile.get(name) if _profile is not None else None
+        if rec is None:
+            return fn
+        import torch
+
+        def wrapped(*a):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            rec.append((e0, e1))
+            return rc
+        return wrapped
+
+
+class profile(object):
+    """``with profile(["wn_layer_fwd"]) as prof: ...`` then ``prof.ms()`` -> {name: [ms per launch]}."""
+
+    def __init__(self, names):
+        self.rec = {n: [] for n in names}
+
+    def __enter__(self):
+        global _profile
+        lib()
+        _profile = self.rec
+        return self
+
+    def __exit__(self, *exc):
+        global _profile
+        _profile = None
+
+    def ms(self):
+        import torch
+        torch.cuda.synchronize()
+        return {n: [a.elapsed_time(b) for a, b in ev] for n, ev in self.rec.items()}
 
 
 def check(rc: int, what: str = "") -> None:

@@ -85,6 +85,12 @@ int wn_layer_bwd(const float* x, const float* f, const float* g, const float* Wf
     POS(B); POS(T); POS(Cr); POS(Cd); POS(fw); POS(d);
     WN_CHECK_ARG(Z >= 0, "wn_layer_bwd: Z < 0");
     WN_CHECK_ARG(dout || dz_skip, "wn_layer_bwd: both dout and dz_skip are NULL");
+    if (wn_layer_fast_path(Cr, Cd, fw)) {
+        int rc = mfma_layer_bwd(x, f, g, Wf, Wg, Wp, dout, dz_skip, dx, dWf, dWg, dWp, dab_ws, B, T, d, Z,
+                                as_stream(stream));
+        if (rc) return rc;
+        return generic_layer_bwd_biases(dab_ws, dout, dbf, dbg, dbp, B, T, Cr, Cd, Z, as_stream(stream));
+    }
     return generic_layer_bwd(x, f, g, Wf, Wg, Wp, dout, dz_skip, dx, dWf, dbf, dWg, dbg, dWp, dbp, dab_ws, B, T,
                              Cr, Cd, fw, d, Z, as_stream(stream));
 }
@@ -93,6 +99,8 @@ int wn_pointwise_fwd(const float* x, const float* W, const float* bias, float* o
                      int act, void* stream) {
     NN(x); NN(W); NN(out); POS(N); POS(Cin); POS(Cout);
     WN_CHECK_ARG(act >= WN_ACT_NONE && act <= WN_ACT_ELU, "wn_pointwise_fwd: bad act %d", act);
+    if (!force_generic() && mfma_pointwise_supported(Cin, Cout))
+        return mfma_pointwise_fwd(x, W, bias, out, N, Cin, Cout, act, as_stream(stream));
     return generic_pointwise_fwd(x, W, bias, out, N, Cin, Cout, act, as_stream(stream));
 }
 
@@ -100,6 +108,11 @@ int wn_pointwise_bwd(const float* x, const float* W, const float* dout, float* d
                      int N, int Cin, int Cout, int act, void* stream) {
     NN(x); NN(W); NN(dout); POS(N); POS(Cin); POS(Cout);
     WN_CHECK_ARG(act >= WN_ACT_NONE && act <= WN_ACT_ELU, "wn_pointwise_bwd: bad act %d", act);
+    if (dx && !force_generic() && mfma_pointwise_supported(Cin, Cout)) {
+        int rc = mfma_pointwise_bwd_dx(x, W, dout, dx, N, Cin, Cout, act, as_stream(stream));
+        if (rc) return rc;
+        dx = nullptr;
+    }
     return generic_pointwise_bwd(x, W, dout, dx, dW, dbias, N, Cin, Cout, act, as_stream(stream));
 }
 
@@ -115,6 +128,8 @@ int wn_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const 
     int rc = check_skip("wn_skip_sum_fwd", L, B, T, t_off, Tw, Cs);
     if (rc) return rc;
     for (int l = 0; l < L; ++l) WN_CHECK_ARG(z[l] && Ws[l] && cd[l] > 0, "wn_skip_sum_fwd: bad source %d", l);
+    if (!force_generic() && mfma_skip_supported(L, cd, Cs))
+        return mfma_skip_sum_fwd(L, z, Ws, bs, cd, skip, B, T, t_off, Tw, Cs, accumulate, as_stream(stream));
     return generic_skip_sum_fwd(L, z, Ws, bs, cd, skip, B, T, t_off, Tw, Cs, accumulate, as_stream(stream));
 }
 
@@ -124,6 +139,9 @@ int wn_skip_sum_bwd_dz(int L, const float* const* Ws, const int* cd, const float
     int rc = check_skip("wn_skip_sum_bwd_dz", L, B, T, t_off, Tw, Cs);
     if (rc) return rc;
     for (int l = 0; l < L; ++l) WN_CHECK_ARG(dz[l] && Ws[l] && cd[l] > 0, "wn_skip_sum_bwd_dz: bad entry %d", l);
+    bool fast = !force_generic() && Cs % 32 == 0;
+    for (int l = 0; l < L && fast; ++l) fast = cd[l] == 32 || cd[l] == 64 || cd[l] == 128 || cd[l] == 256;
+    if (fast) return mfma_skip_bwd_dz(L, Ws, cd, dskip, dz, B, T, t_off, Tw, Cs, as_stream(stream));
     return generic_skip_bwd_dz(L, Ws, cd, dskip, dz, B, T, t_off, Tw, Cs, as_stream(stream));
 }
 

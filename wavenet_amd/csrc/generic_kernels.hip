@@ -655,6 +655,16 @@ int generic_layer_bwd(const float* x, const float* f, const float* g, const floa
     return WN_OK;
 }
 
+// bias gradients of a residual layer from the (da,dg) scratch: dbf += sum da, dbg += sum dg, dbp += sum dout
+int generic_layer_bwd_biases(const float* dab, const float* dout, float* dbf, float* dbg, float* dbp, int B,
+                             int T, int Cr, int Cd, int Z, hipStream_t s) {
+    int rc;
+    if (dbf && (rc = launch_colsum(dab, (long long)T * 2 * Cd, 0, 2 * Cd, B, Z, T, Cd, dbf, s))) return rc;
+    if (dbg && (rc = launch_colsum(dab + Cd, (long long)T * 2 * Cd, 0, 2 * Cd, B, Z, T, Cd, dbg, s))) return rc;
+    if (dbp && dout && (rc = launch_colsum(dout, (long long)T * Cr, 0, Cr, B, 0, T, Cr, dbp, s))) return rc;
+    return WN_OK;
+}
+
 int generic_pointwise_fwd(const float* x, const float* W, const float* bias, float* out, long long N, int Cin,
                           int Cout, int act, hipStream_t s) {
     hipLaunchKernelGGL(k_pointwise_fwd, dim3(cdiv(N * Cout, kThreads)), dim3(kThreads), 0, s, x, W, bias, out, N,

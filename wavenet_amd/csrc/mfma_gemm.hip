@@ -1,0 +1,227 @@
+// Channel GEMMs over time columns on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+//   colgemm:  out[n][m] (+)= sum_src sum_k W_src[m][k] * act(X_src[row(n)][k])  (+ sum_src bias_src[m])
+//
+// used for  (1) the deferred skip sum  sum_l Ws_l z_l  (A11, wavenet.py:574-582: 40 sources of K=32,
+// M=256), (2) the head's 1x1 convs (A12, wavenet.py:587-590: relu/elu -> conv), (3) their input
+// gradients dx = act'(x) * W^T dout (W read transposed), (4) dz_l = Ws_l^T dskip for all layers in
+// one launch ("multi-problem": one source, one 32-wide output per layer).
+//
+// Tiling: a workgroup = 4 waves = 128 columns x (MT*32) outputs; every wave owns 32 columns and all
+// MT output tiles (MT*16 accumulator registers).  The contraction runs in chunks of 32 channels:
+// the W chunk [MT*32][32] is staged in LDS already in MFMA A-operand order (one ds_read_b128 feeds
+// four MFMAs), the X chunk goes straight from HBM to registers as four float4 per lane using the
+// same channel permutation as mfma_layer.hip:  k-step s, lane half h  <->  channel (s&3)+8(s>>2)+4h.
+// With that permutation a float4 of four consecutive channels lands in one 16-byte LDS slot, and
+// the accumulator layout equals the store layout (float4 stores along the channel axis).
+#include "wn_kernels.hpp"
+
+namespace wn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct CGArgs {
+    const float* X[WN_MAX_SRC];      // per source
+    const float* W[WN_MAX_SRC];      // per source (multi-source) or per problem (multi-problem)
+    const float* bias[WN_MAX_SRC];   // per source, may be NULL
+    float* out[WN_MAX_SRC];          // per problem
+    int K[WN_MAX_SRC];               // per source; row stride of X_src is K
+    int wsm[WN_MAX_SRC];             // W row (m) stride per source / problem
+    int wsk;                         // W column (k) stride: 1 = row-major W[m][k], else transposed view
+    int nsrc, M, ldo;
+    long long N;                     // output rows
+    int rows_out_per_b, rows_src_per_b, off;   // src row = b*rows_src_per_b + (n % rows_out_per_b) + off
+    int act;                         // applied to X on load
+    const float* gate_x; int gate_act;         // out *= act'(gate_x[n][m])   (dx of a pre-activated conv)
+    int accumulate;
+};
+
+__device__ __forceinline__ int cg_ch(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
+
+template <int MT, bool MP>
+__global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
+    __shared__ __attribute__((aligned(16))) float Alds[MT * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int prob = MP ? blockIdx.y : 0;
+    const int m0 = MP ? 0 : blockIdx.y * (MT * 32);
+    const long long n = ((long long)blockIdx.x * 4 + wave) * 32 + j;
+    const bool nvalid = n < a.N;
+    long long srow = -1;
+    if (nvalid) {
+        long long b = n / a.rows_out_per_b;
+        int r = (int)(n - b * a.rows_out_per_b) + a.off;
+        if (r >= 0 && r < a.rows_src_per_b) srow = b * a.rows_src_per_b + r;
+    }
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    // fill mapping: thread -> (row i of the tile, 4-channel group c4)
+    const int fi = tid & 31, fc4 = tid >> 5;
+    const int fq = fc4 >> 1, fh = fc4 & 1;
+
+    for (int src = 0; src < a.nsrc; ++src) {
+        const float* __restrict__ Wb = a.W[MP ? prob : src];
+        const int wsm = a.wsm[MP ? prob : src];
+        const float* __restrict__ Xb = a.X[src];
+        const int K = a.K[src];
+        if (a.bias[src] && !MP) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][r] += a.bias[src][m0 + mt * 32 + cg_ch(r, h)];
+        }
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < MT; ++it) {
+                const float* wp = Wb + (long long)(m0 + it * 32 + fi) * wsm + (long long)(k0 + 4 * fc4) * a.wsk;
+                float4 v;
+                if (a.wsk == 1) {
+                    v = *reinterpret_cast<const float4*>(wp);
+                } else {
+                    v.x = wp[0]; v.y = wp[a.wsk]; v.z = wp[2 * (long long)a.wsk]; v.w = wp[3 * (long long)a.wsk];
+                }
+                *reinterpret_cast<float4*>(&Alds[(((it * 4 + fq) * 64) + fi + 32 * fh) * 4]) = v;
+            }
+            float xb[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (srow >= 0) v = *reinterpret_cast<const float4*>(Xb + srow * K + k0 + 8 * q + 4 * h);
+                xb[4 * q + 0] = act_apply(v.x, a.act); xb[4 * q + 1] = act_apply(v.y, a.act);
+                xb[4 * q + 2] = act_apply(v.z, a.act); xb[4 * q + 3] = act_apply(v.w, a.act);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    float4 a4 = *reinterpret_cast<const float4*>(&Alds[((mt * 4 + q) * 64 + lane) * 4]);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, xb[4 * q + 0], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, xb[4 * q + 1], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, xb[4 * q + 2], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, xb[4 * q + 3], acc[mt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!nvalid) return;
+    float* __restrict__ orow = a.out[prob] + n * a.ldo + m0 + 4 * h;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
+            float* p = orow + mt * 32 + 8 * q;
+            if (a.gate_x) {
+                float4 gx = *reinterpret_cast<const float4*>(a.gate_x + n * a.ldo + m0 + 4 * h + mt * 32 + 8 * q);
+                v.x *= act_grad(gx.x, a.gate_act); v.y *= act_grad(gx.y, a.gate_act);
+                v.z *= act_grad(gx.z, a.gate_act); v.w *= act_grad(gx.w, a.gate_act);
+            }
+            if (a.accumulate) {
+                float4 o = *reinterpret_cast<const float4*>(p);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4*>(p) = v;
+        }
+    }
+}
+
+template <bool MP>
+static int launch_colgemm(const CGArgs& a, int nprob, hipStream_t s) {
+    const int M = a.M;
+    int mt = (M % 256 == 0) ? 8 : (M % 128 == 0) ? 4 : (M % 64 == 0) ? 2 : 1;
+    if (MP) mt = M / 32;      // multi-problem: the whole (small) M in one workgroup
+    dim3 grid(cdiv(a.N, 128), MP ? nprob : M / (mt * 32));
+    switch (mt) {
+        case 8: hipLaunchKernelGGL((k_colgemm<8, MP>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_colgemm<4, MP>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_colgemm<2, MP>), grid, dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_colgemm<1, MP>), grid, dim3(256), 0, s, a); break;
+        default: wn::set_error("colgemm: unsupported M=%d", M); return WN_ESHAPE;
+    }
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- entry points used by api.hip -------------------------------------------------------------
+bool mfma_skip_supported(int L, const int* cd, int Cs) {
+    if (Cs % 32) return false;
+    for (int l = 0; l < L; ++l)
+        if (cd[l] % 32) return false;
+    return true;
+}
+
+int mfma_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const float* const* bs, const int* cd,
+                      float* skip, int B, int T, int t_off, int Tw, int Cs, int accumulate, hipStream_t s) {
+    for (int l0 = 0; l0 < L; l0 += WN_MAX_SRC) {
+        CGArgs a{};
+        a.nsrc = (L - l0 < WN_MAX_SRC) ? L - l0 : WN_MAX_SRC;
+        for (int l = 0; l < a.nsrc; ++l) {
+            a.X[l] = z[l0 + l]; a.W[l] = Ws[l0 + l]; a.bias[l] = bs ? bs[l0 + l] : nullptr;
+            a.K[l] = cd[l0 + l]; a.wsm[l] = cd[l0 + l];
+            if (!aligned16(a.X[l]) || !aligned16(a.W[l])) { wn::set_error("skip_sum: pointers must be 16-byte aligned"); return WN_EARG; }
+        }
+        a.out[0] = skip; a.wsk = 1; a.M = Cs; a.ldo = Cs; a.N = (long long)B * Tw;
+        a.rows_out_per_b = Tw; a.rows_src_per_b = T; a.off = t_off;
+        a.act = WN_ACT_NONE; a.gate_x = nullptr; a.gate_act = 0;
+        a.accumulate = (accumulate || l0 > 0) ? 1 : 0;
+        int rc = launch_colgemm<false>(a, 1, s);
+        if (rc) return rc;
+    }
+    return WN_OK;
+}
+
+int mfma_skip_bwd_dz(int L, const float* const* Ws, const int* cd, const float* dskip, float* const* dz, int B,
+                     int T, int t_off, int Tw, int Cs, hipStream_t s) {
+    // all layers must share cd for the one-launch form; otherwise launch per distinct width
+    for (int l0 = 0; l0 < L;) {
+        int l1 = l0;
+        while (l1 < L && l1 - l0 < WN_MAX_SRC && cd[l1] == cd[l0]) ++l1;
+        CGArgs a{};
+        a.nsrc = 1; a.X[0] = dskip; a.K[0] = Cs; a.bias[0] = nullptr;
+        for (int l = l0; l < l1; ++l) { a.W[l - l0] = Ws[l]; a.wsm[l - l0] = 1; a.out[l - l0] = dz[l]; }
+        a.wsk = cd[l0];                                   // W[m][k] = Ws[k][m]
+        a.M = cd[l0]; a.ldo = cd[l0]; a.N = (long long)B * T;
+        a.rows_out_per_b = T; a.rows_src_per_b = Tw; a.off = -t_off;
+        a.act = WN_ACT_NONE; a.gate_x = nullptr; a.accumulate = 0;
+        if (cd[l0] / 32 > 8) { wn::set_error("skip_bwd_dz: cd > 256 not covered"); return WN_ESHAPE; }
+        int rc = launch_colgemm<true>(a, l1 - l0, s);
+        if (rc) return rc;
+        l0 = l1;
+    }
+    return WN_OK;
+}
+
+bool mfma_pointwise_supported(int Cin, int Cout) { return Cin % 32 == 0 && Cout % 32 == 0; }
+
+int mfma_pointwise_fwd(const float* x, const float* W, const float* bias, float* out, long long N, int Cin,
+                       int Cout, int act, hipStream_t s) {
+    CGArgs a{};
+    a.nsrc = 1; a.X[0] = x; a.W[0] = W; a.bias[0] = bias; a.K[0] = Cin; a.wsm[0] = Cin; a.wsk = 1;
+    a.out[0] = out; a.M = Cout; a.ldo = Cout; a.N = N;
+    a.rows_out_per_b = (int)(N < (1ll << 30) ? N : (1ll << 30)); a.rows_src_per_b = a.rows_out_per_b; a.off = 0;
+    if (N >= (1ll << 30)) { wn::set_error("pointwise: N too large"); return WN_ESHAPE; }
+    a.act = act; a.gate_x = nullptr; a.accumulate = 0;
+    return launch_colgemm<false>(a, 1, s);
+}
+
+// dx[n][c] = act'(x[n][c]) * sum_o W[o][c] dout[n][o]
+int mfma_pointwise_bwd_dx(const float* x, const float* W, const float* dout, float* dx, long long N, int Cin,
+                          int Cout, int act, hipStream_t s) {
+    CGArgs a{};
+    a.nsrc = 1; a.X[0] = dout; a.W[0] = W; a.bias[0] = nullptr; a.K[0] = Cout; a.wsm[0] = 1; a.wsk = Cin;
+    a.out[0] = dx; a.M = Cin; a.ldo = Cin; a.N = N;
+    if (N >= (1ll << 30)) { wn::set_error("pointwise: N too large"); return WN_ESHAPE; }
+    a.rows_out_per_b = (int)N; a.rows_src_per_b = (int)N; a.off = 0;
+    a.act = WN_ACT_NONE; a.gate_x = (act == WN_ACT_NONE) ? nullptr : x; a.gate_act = act; a.accumulate = 0;
+    return launch_colgemm<false>(a, 1, s);
+}
+
+}  // namespace wn

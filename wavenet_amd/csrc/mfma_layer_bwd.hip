@@ -1,0 +1,239 @@
+// Backward of the fused residual layer on the fp32 matrix cores, Cr = Cd = 32, filter width 2
+// (Chainer autograd through ResidualConvLayer.__call__, wavenet.py:358-368).
+//
+// Pass 1 (k_layer_bwd_p1), one wave per tile of 32 time columns:
+//     dz = Wp^T dout + dz_skip          D[cd][t], time on lanes, same channel permutation as forward
+//     da = dz g (1 - f^2),  dg = dz f g (1 - g)   (0 in the reference's zero prefix t < Z)
+//     da, dg -> scratch (B,T,64) for pass 2
+//   and the weight gradients, where the MFMA contraction runs over TIME: the tile's da / dg are
+//   transposed through a per-wave LDS patch (channel on lanes), x[t], x[t-d], dout, f*g are read
+//   straight from HBM/L2 in channel-on-lane order (one coalesced 128-byte row per half wave):
+//     dWf_k += da x[t-(1-k)d]^T,  dWg_k += dg x[t-(1-k)d]^T,  dWp += dout z^T
+//   Five 32x32 accumulators stay in registers over all tiles of a wave, are summed over the
+//   workgroup's waves in LDS and leave as one set of float atomics per workgroup.
+// Pass 2 (k_layer_bwd_p2):  dx[t] = dout[t] + [Wf1;Wg1]^T dab[t] + [Wf0;Wg0]^T dab[t+d]
+//   -- the forward kernel's structure with transposed weights (64 MFMAs per tile).
+#include "wn_kernels.hpp"
+
+namespace wn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int bch(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
+
+static constexpr int kPad = 36;                 // LDS row stride (floats) of a transposed 32x32 patch
+static constexpr int kWaves = 4;
+
+__global__ __launch_bounds__(256, 2) void k_layer_bwd_p1(
+    const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
+    const float* __restrict__ Wp, const float* __restrict__ dout, const float* __restrict__ dzs,
+    float* __restrict__ dab, float* __restrict__ dWf, float* __restrict__ dWg, float* __restrict__ dWp,
+    int B, int T, int d, int Z, int tiles_per_b, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float lds[kWaves * 2 * 32 * kPad + 5 * 16 * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    float* lda = lds + wv * (2 * 32 * kPad);
+    float* ldg = lda + 32 * kPad;
+    float* red = lds + kWaves * 2 * 32 * kPad;
+    const int wave = blockIdx.x * kWaves + wv;
+    const int nwaves = gridDim.x * kWaves;
+    const bool has_do = dout != nullptr;
+
+    float wpT[16];                                   // A operand of dz: lane (i=cd,h), step s: Wp[ch(s,h)][i]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) wpT[s] = Wp[bch(s, h) * 32 + j];
+
+    f32x16 aWf0, aWf1, aWg0, aWg1, aWp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aWf0[r] = 0.f; aWf1[r] = 0.f; aWg0[r] = 0.f; aWg1[r] = 0.f; aWp[r] = 0.f; }
+
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int b = tile / tiles_per_b;
+        const int t0 = (tile - b * tiles_per_b) * 32;
+        const int t = t0 + j;
+        const bool valid = t < T;
+        const long long row = ((long long)b * T + t) * 32 + 4 * h;
+        f32x16 acc;
+        float ff[16], gg[16], dob[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 z4 = make_float4(0, 0, 0, 0), f4 = z4, g4 = z4, o4 = z4;
+            if (valid) {
+                f4 = *reinterpret_cast<const float4*>(f + row + 8 * q);
+                g4 = *reinterpret_cast<const float4*>(g + row + 8 * q);
+                if (dzs) z4 = *reinterpret_cast<const float4*>(dzs + row + 8 * q);
+                if (has_do) o4 = *reinterpret_cast<const float4*>(dout + row + 8 * q);
+            }
+            acc[4 * q] = z4.x; acc[4 * q + 1] = z4.y; acc[4 * q + 2] = z4.z; acc[4 * q + 3] = z4.w;
+            ff[4 * q] = f4.x; ff[4 * q + 1] = f4.y; ff[4 * q + 2] = f4.z; ff[4 * q + 3] = f4.w;
+            gg[4 * q] = g4.x; gg[4 * q + 1] = g4.y; gg[4 * q + 2] = g4.z; gg[4 * q + 3] = g4.w;
+            dob[4 * q] = o4.x; dob[4 * q + 1] = o4.y; dob[4 * q + 2] = o4.z; dob[4 * q + 3] = o4.w;
+        }
+        if (has_do) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wpT[s], dob[s], acc, 0, 0, 0);
+        }
+        const bool live = valid && t >= Z;
+        float da[16], dg[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float dz = live ? acc[r] : 0.f;
+            da[r] = dz * gg[r] * (1.f - ff[r] * ff[r]);
+            dg[r] = dz * ff[r] * gg[r] * (1.f - gg[r]);
+        }
+        // scratch for pass 2 and the transposed LDS patches for the weight gradients
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 a4 = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
+            float4 g4 = make_float4(dg[4 * q], dg[4 * q + 1], dg[4 * q + 2], dg[4 * q + 3]);
+            if (valid) {
+                float* p = dab + ((long long)b * T + t) * 64 + 8 * q + 4 * h;
+                *reinterpret_cast<float4*>(p) = a4;
+                *reinterpret_cast<float4*>(p + 32) = g4;
+            }
+            *reinterpret_cast<float4*>(lda + j * kPad + 8 * q + 4 * h) = a4;
+            *reinterpret_cast<float4*>(ldg + j * kPad + 8 * q + 4 * h) = g4;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // contraction over the tile's 32 time columns: step s covers columns 2s and 2s+1
+#pragma unroll 4
+        for (int s = 0; s < 16; ++s) {
+            const int tt = t0 + 2 * s + h;
+            const bool tv = tt < T;
+            const long long r0 = ((long long)b * T + tt) * 32 + j;
+            float a_da = lda[(2 * s + h) * kPad + j];
+            float a_dg = ldg[(2 * s + h) * kPad + j];
+            float b_xc = tv ? x[r0] : 0.f;
+            float b_xo = (tv && tt - d >= 0) ? x[r0 - (long long)d * 32] : 0.f;
+            aWf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xc, aWf1, 0, 0, 0);
+            aWf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xo, aWf0, 0, 0, 0);
+            aWg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xc, aWg1, 0, 0, 0);
+            aWg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xo, aWg0, 0, 0, 0);
+            if (dWp) {
+                float a_do = tv ? dout[r0] : 0.f;
+                float b_z = tv ? f[r0] * g[r0] : 0.f;
+                aWp = __builtin_amdgcn_mfma_f32_32x32x2f32(a_do, b_z, aWp, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- sum the five accumulators over the workgroup's waves, then one set of atomics ---------
+    for (int w = 1; w < kWaves; ++w) {
+        __syncthreads();
+        if (wv == w) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                red[(0 * 16 + r) * 64 + lane] = aWf0[r]; red[(1 * 16 + r) * 64 + lane] = aWf1[r];
+                red[(2 * 16 + r) * 64 + lane] = aWg0[r]; red[(3 * 16 + r) * 64 + lane] = aWg1[r];
+                red[(4 * 16 + r) * 64 + lane] = aWp[r];
+            }
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                aWf0[r] += red[(0 * 16 + r) * 64 + lane]; aWf1[r] += red[(1 * 16 + r) * 64 + lane];
+                aWg0[r] += red[(2 * 16 + r) * 64 + lane]; aWg1[r] += red[(3 * 16 + r) * 64 + lane];
+                aWp[r] += red[(4 * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    if (wv == 0) {
+        // D layout: lane (j,h), register r  <->  element [row bch(r,h)][column j]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = bch(r, h);
+            if (dWf) {                                   // dWf[cd=i][cr=j][k]
+                atomicAdd(dWf + (i * 32 + j) * 2 + 0, aWf0[r]);
+                atomicAdd(dWf + (i * 32 + j) * 2 + 1, aWf1[r]);
+            }
+            if (dWg) {
+                atomicAdd(dWg + (i * 32 + j) * 2 + 0, aWg0[r]);
+                atomicAdd(dWg + (i * 32 + j) * 2 + 1, aWg1[r]);
+            }
+            if (dWp) atomicAdd(dWp + i * 32 + j, aWp[r]);  // dWp[cr=i][cd=j]
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_layer_bwd_p2(
+    const float* __restrict__ Wf, const float* __restrict__ Wg, const float* __restrict__ dout,
+    const float* __restrict__ dab, float* __restrict__ dx, int B, int T, int d, int tiles_per_b, int ntiles) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    // A operands: lane (i=cr,h), step s: W[cd=ch(s,h)][cr=i][k]
+    float wf0[16], wf1[16], wg0[16], wg1[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const float2 a = *reinterpret_cast<const float2*>(Wf + (bch(s, h) * 32 + j) * 2);
+        const float2 c = *reinterpret_cast<const float2*>(Wg + (bch(s, h) * 32 + j) * 2);
+        wf0[s] = a.x; wf1[s] = a.y; wg0[s] = c.x; wg1[s] = c.y;
+    }
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int b = tile / tiles_per_b;
+        const int t = (tile - b * tiles_per_b) * 32 + j;
+        const bool valid = t < T;
+        const bool has_new = valid && (t + d) < T;
+        const long long row = ((long long)b * T + t) * 32 + 4 * h;
+        const long long drow = ((long long)b * T + t) * 64 + 4 * h;
+        f32x16 acc;
+        float a0[16], g0[16], a1[16], g1[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 z = make_float4(0, 0, 0, 0), o = z, va = z, vg = z, na = z, ng = z;
+            if (valid) {
+                if (dout) o = *reinterpret_cast<const float4*>(dout + row + 8 * q);
+                va = *reinterpret_cast<const float4*>(dab + drow + 8 * q);
+                vg = *reinterpret_cast<const float4*>(dab + drow + 32 + 8 * q);
+            }
+            if (has_new) {
+                na = *reinterpret_cast<const float4*>(dab + drow + (long long)d * 64 + 8 * q);
+                ng = *reinterpret_cast<const float4*>(dab + drow + (long long)d * 64 + 32 + 8 * q);
+            }
+            acc[4 * q] = o.x; acc[4 * q + 1] = o.y; acc[4 * q + 2] = o.z; acc[4 * q + 3] = o.w;
+            a0[4 * q] = va.x; a0[4 * q + 1] = va.y; a0[4 * q + 2] = va.z; a0[4 * q + 3] = va.w;
+            g0[4 * q] = vg.x; g0[4 * q + 1] = vg.y; g0[4 * q + 2] = vg.z; g0[4 * q + 3] = vg.w;
+            a1[4 * q] = na.x; a1[4 * q + 1] = na.y; a1[4 * q + 2] = na.z; a1[4 * q + 3] = na.w;
+            g1[4 * q] = ng.x; g1[4 * q + 1] = ng.y; g1[4 * q + 2] = ng.z; g1[4 * q + 3] = ng.w;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf1[s], a0[s], acc, 0, 0, 0);   // tap 1 reads x[t]
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wg1[s], g0[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf0[s], a1[s], acc, 0, 0, 0);   // tap 0 of column t+d reads x[t]
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wg0[s], g1[s], acc, 0, 0, 0);
+        }
+        if (valid) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(dx + row + 8 * q) =
+                    make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+        }
+    }
+}
+
+int mfma_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
+                   const float* Wp, const float* dout, const float* dzs, float* dx, float* dWf, float* dWg,
+                   float* dWp, float* dab, int B, int T, int d, int Z, hipStream_t s) {
+    const int tiles_per_b = (T + 31) / 32;
+    const long long nt = (long long)B * tiles_per_b;
+    WN_CHECK_SHAPE(nt < (1ll << 31), "mfma_layer_bwd: too many tiles");
+    const int ntiles = (int)nt;
+    int blocks = (ntiles + 3) / 4;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(k_layer_bwd_p1, dim3(blocks), dim3(256), 0, s, x, f, g, Wp, dout, dzs, dab, dWf, dWg,
+                       dout ? dWp : (float*)nullptr, B, T, d, Z, tiles_per_b, ntiles);
+    WN_LAUNCH_CHECK();
+    if (dx) {
+        hipLaunchKernelGGL(k_layer_bwd_p2, dim3(blocks), dim3(256), 0, s, Wf, Wg, dout, dab, dx, B, T, d,
+                           tiles_per_b, ntiles);
+        WN_LAUNCH_CHECK();
+    }
+    return WN_OK;
+}
+
+}  // namespace wn

@@ -43,9 +43,23 @@ int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float
                    const float* Wp, const float* bp, float* out, float* z, float* fs, float* gs, int B, int T,
                    int d, int Z, hipStream_t s);
 
-// ---- mfma_gemm.hip: fp32-MFMA channel GEMM over time columns --------------------------------
-// out[n, 0:M] (+)= sum_src W_src[M x K_src] act(X_src[n]) + bias ; see the file header.
-struct ColGemmSrc { const float* X; long long ldx; const float* W; int K; };
-bool mfma_colgemm_supported(int M, const int* Ks, int nsrc);
+// ---- mfma_layer_bwd.hip: backward of the same shape; bias gradients come from the scratch -----
+int mfma_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
+                   const float* Wp, const float* dout, const float* dzs, float* dx, float* dWf, float* dWg,
+                   float* dWp, float* dab, int B, int T, int d, int Z, hipStream_t s);
+int generic_layer_bwd_biases(const float* dab, const float* dout, float* dbf, float* dbg, float* dbp, int B,
+                             int T, int Cr, int Cd, int Z, hipStream_t s);
+
+// ---- mfma_gemm.hip: fp32-MFMA channel GEMMs over time columns (all widths multiples of 32) ---
+bool mfma_skip_supported(int L, const int* cd, int Cs);
+int mfma_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const float* const* bs, const int* cd,
+                      float* skip, int B, int T, int t_off, int Tw, int Cs, int accumulate, hipStream_t s);
+int mfma_skip_bwd_dz(int L, const float* const* Ws, const int* cd, const float* dskip, float* const* dz, int B,
+                     int T, int t_off, int Tw, int Cs, hipStream_t s);
+bool mfma_pointwise_supported(int Cin, int Cout);
+int mfma_pointwise_fwd(const float* x, const float* W, const float* bias, float* out, long long N, int Cin,
+                       int Cout, int act, hipStream_t s);
+int mfma_pointwise_bwd_dx(const float* x, const float* W, const float* dout, float* dx, long long N, int Cin,
+                          int Cout, int act, hipStream_t s);
 
 }  // namespace wn

@@ -47,3 +47,16 @@ def create_batch(signal, batch_size, input_width, target_width, rng=np.random):
         x[n] = signal[s:s + input_width + target_width]
         t[n] = signal[s + input_width + 1:s + input_width + target_width + 1]
     return x, t
+
+
+def synthetic_waveform(B: int, n: int, sr: int, b0: int = 0, Btot=None) -> np.ndarray:
+    """Synthetic clips for benchmarks: two sines + noise in [-1, 1], float64.
+    Clip ``b`` uses phase ``2 pi (b0+b)/Btot`` and its own noise row, so data-parallel shards differ."""
+    Btot = B if Btot is None else Btot
+    t = np.arange(n, dtype=np.float64) / sr
+    noise = np.random.RandomState(0).standard_normal((Btot, n))
+    out = np.empty((B, n), dtype=np.float64)
+    for b in range(B):
+        ph = 2 * np.pi * (b0 + b) / Btot
+        out[b] = 0.6 * np.sin(2 * np.pi * 220.0 * t + ph) + 0.3 * np.sin(2 * np.pi * 554.37 * t) + 0.05 * noise[b0 + b]
+    return np.clip(out, -1.0, 1.0)
