@@ -274,7 +274,9 @@ def test_train_step_loss_and_grads_vs_oracle_and_golden():
           softmax_conv_channels=[14, 11, 20], causal_conv_no_bias=False, residual_conv_dilation_no_bias=False,
           residual_conv_projection_no_bias=False), 2, 90, 30, 0.3),
     (dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 5, residual_num_blocks=2,
-          softmax_conv_channels=[64, 256]), 2, 300, 237, 0.0)])
+          softmax_conv_channels=[64, 256]), 2, 300, 237, 0.0),
+    (dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 3, residual_num_blocks=2,
+          softmax_conv_channels=[256, 256], residual_conv_projection_no_bias=False), 3, 700, 650, 0.2)])
 def test_train_step_grads_general(over, B, T, tw, bias):
     """fused path (t_off) and sliced path give the oracle's loss and gradients, biases included."""
     p, w, net = build(over, bias_scale=bias)
@@ -471,7 +473,8 @@ def _layer_bwd_ref(x, Wf, Wg, Wp, b, Z, d, fw, dout, dzs):
     if dout is not None:
         loss = loss + (out * torch.tensor(dout, dtype=torch.float64)).sum()
     loss.backward()
-    return xt.grad.numpy(), [w.grad.numpy() for w in ws], [None if v is None else v.grad for v in bs], \
+    return xt.grad.numpy(), [None if w.grad is None else w.grad.numpy() for w in ws], \
+        [None if (v is None or v.grad is None) else v.grad for v in bs], \
         f_.detach().numpy(), g_.detach().numpy()
 
 

@@ -113,6 +113,11 @@ int wn_pointwise_bwd(const float* x, const float* W, const float* dout, float* d
         if (rc) return rc;
         dx = nullptr;
     }
+    if (dW && !force_generic() && mfma_pointwise_supported(Cin, Cout)) {
+        int rc = mfma_pointwise_bwd_dw(x, dout, dW, N, Cin, Cout, act, as_stream(stream));
+        if (rc) return rc;
+        dW = nullptr;
+    }
     return generic_pointwise_bwd(x, W, dout, dx, dW, dbias, N, Cin, Cout, act, as_stream(stream));
 }
 
@@ -150,6 +155,13 @@ int wn_skip_sum_bwd_dw(int L, const float* const* z, const int* cd, const float*
     NN(z); NN(cd); NN(dskip);
     int rc = check_skip("wn_skip_sum_bwd_dw", L, B, T, t_off, Tw, Cs);
     if (rc) return rc;
+    bool fast = !force_generic() && Cs % 32 == 0 && dWs;
+    for (int l = 0; l < L && fast; ++l) fast = cd[l] == 32;
+    if (fast) {
+        rc = mfma_skip_bwd_dw(L, z, dskip, dWs, B, T, t_off, Tw, Cs, as_stream(stream));
+        if (rc) return rc;
+        dWs = nullptr;
+    }
     return generic_skip_bwd_dw(L, z, cd, dskip, dWs, dbs, B, T, t_off, Tw, Cs, as_stream(stream));
 }
 

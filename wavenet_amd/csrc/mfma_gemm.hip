@@ -225,3 +225,145 @@ int mfma_pointwise_bwd_dx(const float* x, const float* W, const float* dout, flo
 }
 
 }  // namespace wn
+
+// =============================================================================================
+// wgrad:  dW_p[m][k] += sum_n A[n][m] * act(B_p[row(n)][k])      (contraction over time columns)
+//
+// used for dWs_l = dskip^T z_l of all layers in one launch (A15; 40 "problems" sharing A) and for the
+// head convs' dW = dout^T act(x) (problems = 32-wide column tiles of x).  The MFMA K dimension is
+// TIME: a workgroup stages 32 rows of A (all M channels) in LDS, every wave owns one problem (one
+// 32-wide tile of B, read straight from HBM in channel-on-lane order) and all MT row tiles of dW.
+// Each workgroup covers a slab of rows of one clip and leaves with one set of float atomics.
+// =============================================================================================
+namespace wn {
+
+struct WGArgs {
+    const float* A; int lda;
+    const float* Bp[WN_MAX_SRC];
+    float* out[WN_MAX_SRC];
+    int nprob, ldb, ldo;
+    int nB, rows_A_per_b, rows_B_per_b, off;   // B row = b*rows_B_per_b + r + off for A row b*rows_A_per_b + r
+    int act;
+    int rows_per_wg, wgs_per_b;
+};
+
+template <int MT>
+__global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WGArgs a) {
+    __shared__ __attribute__((aligned(16))) float Alds[32 * MT * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int p = blockIdx.y * 4 + wv;
+    const bool active = p < a.nprob;
+    const int m0 = blockIdx.z * (MT * 32);
+    const int b = blockIdx.x / a.wgs_per_b;
+    const int r_begin = (blockIdx.x - b * a.wgs_per_b) * a.rows_per_wg;
+    const int r_end = min(a.rows_A_per_b, r_begin + a.rows_per_wg);
+    const float* __restrict__ Ab = a.A + ((long long)b * a.rows_A_per_b) * a.lda + m0;
+    const float* __restrict__ Bb = active ? a.Bp[p] + ((long long)b * a.rows_B_per_b + a.off) * a.ldb + j : nullptr;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < MT; ++it) {
+            const int idx = it * 256 + tid;                 // float4 index inside the [32][MT*32] chunk
+            const int row = idx / (MT * 8), c4 = idx - row * (MT * 8);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r0 + row < r_end) v = *reinterpret_cast<const float4*>(Ab + (long long)(r0 + row) * a.lda + 4 * c4);
+            *reinterpret_cast<float4*>(&Alds[row * (MT * 32) + 4 * c4]) = v;
+        }
+        float bv[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int r = r0 + 2 * s + h;
+            const int rb = r + a.off;
+            float v = 0.f;
+            if (active && r < r_end && rb >= 0 && rb < a.rows_B_per_b) v = act_apply(Bb[(long long)r * a.ldb], a.act);
+            bv[s] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float av = Alds[(2 * s + h) * (MT * 32) + mt * 32 + j];
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[s], acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    if (!active) return;
+    float* __restrict__ o = a.out[p];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            atomicAdd(o + (long long)(m0 + mt * 32 + cg_ch(r, h)) * a.ldo + j, acc[mt][r]);
+}
+
+static int launch_wgrad_mfma(WGArgs& a, int M, hipStream_t s) {
+    int mt = (M % 256 == 0) ? 8 : (M % 128 == 0) ? 4 : (M % 64 == 0) ? 2 : 1;
+    // row slabs: enough workgroups to fill the chip, few enough that the atomics stay small
+    int groups = cdiv(a.nprob, 4) * (M / (mt * 32));
+    int want = 1024 / (groups > 0 ? groups : 1);
+    if (want < 1) want = 1;
+    int per_b = cdiv(want, a.nB);
+    int rows = cdiv(a.rows_A_per_b, per_b);
+    rows = ((rows + 31) / 32) * 32;
+    if (rows < 256) rows = 256;
+    a.rows_per_wg = rows;
+    a.wgs_per_b = cdiv(a.rows_A_per_b, rows);
+    dim3 grid(a.nB * a.wgs_per_b, cdiv(a.nprob, 4), M / (mt * 32));
+    switch (mt) {
+        case 8: hipLaunchKernelGGL(k_wgrad_mfma<8>, grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(k_wgrad_mfma<4>, grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(k_wgrad_mfma<2>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(k_wgrad_mfma<1>, grid, dim3(256), 0, s, a); break;
+    }
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+// dWs[l][cs][cd] += sum dskip[b,t',cs] z_l[b,t_off+t',cd]   for every layer with cd == 32
+int mfma_skip_bwd_dw(int L, const float* const* z, const float* dskip, float* const* dWs, int B, int T,
+                     int t_off, int Tw, int Cs, hipStream_t s) {
+    for (int l0 = 0; l0 < L; l0 += WN_MAX_SRC) {
+        WGArgs a{};
+        a.A = dskip; a.lda = Cs;
+        a.nprob = 0;
+        for (int l = l0; l < L && l - l0 < WN_MAX_SRC; ++l) {
+            if (!dWs[l]) continue;
+            a.Bp[a.nprob] = z[l]; a.out[a.nprob] = dWs[l]; ++a.nprob;
+        }
+        if (a.nprob == 0) continue;
+        a.ldb = 32; a.ldo = 32;
+        a.nB = B; a.rows_A_per_b = Tw; a.rows_B_per_b = T; a.off = t_off; a.act = WN_ACT_NONE;
+        int rc = launch_wgrad_mfma(a, Cs, s);
+        if (rc) return rc;
+    }
+    return WN_OK;
+}
+
+// dW[o][c] += sum_n dout[n][o] act(x[n][c])
+int mfma_pointwise_bwd_dw(const float* x, const float* dout, float* dW, long long N, int Cin, int Cout, int act,
+                          hipStream_t s) {
+    if (N >= (1ll << 30)) { wn::set_error("pointwise dW: N too large"); return WN_ESHAPE; }
+    for (int c0 = 0; c0 < Cin; c0 += 32 * WN_MAX_SRC) {
+        WGArgs a{};
+        a.A = dout; a.lda = Cout;
+        a.nprob = 0;
+        for (int c = c0; c < Cin && a.nprob < WN_MAX_SRC; c += 32) {
+            a.Bp[a.nprob] = x + c; a.out[a.nprob] = dW + c; ++a.nprob;
+        }
+        a.ldb = Cin; a.ldo = Cin;
+        a.nB = 1; a.rows_A_per_b = (int)N; a.rows_B_per_b = (int)N; a.off = 0; a.act = act;
+        int rc = launch_wgrad_mfma(a, Cout, s);
+        if (rc) return rc;
+    }
+    return WN_OK;
+}
+
+}  // namespace wn
