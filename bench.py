@@ -77,37 +77,39 @@ def cpu_baseline(budget_s=25.0):
     fast decode (faster_wavenet.py:50-113 restated: caches rolled every step)."""
     from oracle import wavenet_ref as R
     from oracle import data_ref as D
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)          # small convs stop scaling past ~16 threads
     torch.set_num_threads(cores)
     p = R.make_params(**{k: v for k, v in CFG2.items() if k != "sampling_rate"})
     w = R.init_weights(p, 1234)
     iw = R.input_width(p)
     tok = D.mulaw_quantize(D.synthetic_waveform(1, T + 1, 16000))
-    x, tgt = tok[:, :T], tok[:, iw + 1:T + 1]
+    # bounded sample: a pilot crop sizes the timed crop so that the leg stays within its budget
+    Tp = iw + 512
     t0 = time.perf_counter()
-    R.train_step_grads(p, w, x, tgt)                                        # warm-up
-    one = time.perf_counter() - t0
-    reps = max(1, min(3, int(budget_s * 0.6 / max(one, 1e-3))))
-    ts = []
+    R.train_step_grads(p, w, tok[:, :Tp], tok[:, iw + 1:Tp + 1])            # warm-up + pilot
+    pilot = (time.perf_counter() - t0) / Tp
+    Tc = int(min(T, max(iw + 1024, budget_s * 0.3 / max(pilot, 1e-9))))
+    x, tgt = tok[:, :Tc], tok[:, iw + 1:Tc + 1]
+    reps, ts = 2, []
     for _ in range(reps):
         t0 = time.perf_counter()
         R.train_step_grads(p, w, x, tgt)
         ts.append(time.perf_counter() - t0)
-    train_sps = T / float(np.median(ts))
+    train_sps = Tc / float(np.median(ts))
     fast = R.RefFasterWaveNet(p, w)
     buf = np.full((iw,), 127, np.int32)
     fast._forward_one_step(D.onehot_pixel_image(buf.reshape(1, -1), 256))   # prefill
     t0 = time.perf_counter()
     n = 0
-    while n < 200 and time.perf_counter() - t0 < budget_s * 0.4:
+    while n < 200 and time.perf_counter() - t0 < budget_s * 0.35:
         buf = np.append(buf[1:], [n % 256]).astype(np.int32)
         fast._forward_one_step(D.onehot_pixel_image(buf.reshape(1, -1), 256))
         n += 1
     dec_sps = n / (time.perf_counter() - t0)
     return {"value": train_sps, "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": "oracle literal restatement (Chainer-equivalent op sequence, not Chainer), torch-CPU fp32, "
-                      "%d threads: train fwd+bwd cfg2 topology B=1 x T=16384, median of %d steps; "
-                      "fast decode %d steps at W=4094" % (cores, reps, n),
+                      "%d threads: train fwd+bwd cfg2 topology B=1 x T=%d, median of %d steps; "
+                      "fast decode %d steps at W=4094" % (cores, Tc, reps, n),
             "decode_value": dec_sps, "decode_unit": "samples/s"}
 
 
@@ -146,15 +148,12 @@ def main():
     assert _lib.lib().wn_layer_fast_path(32, 32, 2) == 1
 
     # ---- the timed region: K training steps ------------------------------------------------
-    dom = ["wn_layer_fwd", "wn_layer_bwd", "wn_skip_sum_fwd", "wn_skip_sum_bwd_dz", "wn_skip_sum_bwd_dw",
-           "wn_pointwise_fwd", "wn_pointwise_bwd", "wn_embed_fwd", "wn_embed_bwd", "wn_softmax_xent",
-           "wn_adam_step", "wn_sqnorm"]
     for _ in range(args.warmup):
         train_step(net, x, tgt, iw)
     if barrier:
         barrier()
     torch.cuda.synchronize()
-    with _lib.profile(dom) as prof:
+    with _lib.profile() as prof:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             loss = train_step(net, x, tgt, iw)
@@ -166,8 +165,7 @@ def main():
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    kms = {k: v for k, v in prof.ms().items() if v}
-    per_step = {k: sum(v) / args.steps for k, v in kms.items()}          # ms of each entry point per step
+    per_step = {k: v[1] / args.steps for k, v in prof.result().items()}  # ms of each entry point per step
     samples = world * B_PER_GPU * T
     value = samples / dt
 
@@ -188,17 +186,16 @@ def main():
         # ---- fused residual-stack forward (the north star's roofline target) -------------------
         with torch.no_grad():
             c = net.forward_causal_block(x)
-        names = ["wn_layer_fwd", "wn_skip_sum_fwd"]
         timed(lambda: stack_forward(net, c), 2, 2)
-        with _lib.profile(names) as prof2:
+        with _lib.profile() as prof2:
             sdt = timed(lambda: stack_forward(net, c), 10, 0)
-        ms2 = prof2.ms()
+        ms2 = prof2.result()
         nl = len(net._flat_layers)
         Cr, Cd, Cs = 32, 32, 256
         alg_bytes_layer = 4 * (2 * Cr + 2 * Cs) * B_PER_GPU * T            # 2,304 B per sample-layer
         alg_flops_layer = 2 * (2 * 2 * Cr * Cd + Cd * Cr + Cd * Cs) * B_PER_GPU * T
-        layer_ms = float(np.mean(ms2["wn_layer_fwd"]))
-        skip_ms = float(np.mean(ms2["wn_skip_sum_fwd"]))
+        layer_ms = ms2["wn_layer_fwd"][1] / ms2["wn_layer_fwd"][0]
+        skip_ms = ms2["wn_skip_sum_fwd"][1] / ms2["wn_skip_sum_fwd"][0]
         stack_ms = layer_ms * nl + skip_ms
         out["stack_forward"] = {
             "samples_per_s": B_PER_GPU * T / sdt, "ms_wall": sdt * 1e3, "ms_kernels": stack_ms,

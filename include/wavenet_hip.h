@@ -26,6 +26,7 @@
 #ifndef WAVENET_HIP_H
 #define WAVENET_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -118,6 +119,31 @@ int wn_skip_sum_bwd_dw(int L, const float* const* z, const int* cd, const float*
                        float* const* dWs, float* const* dbs, int B, int T, int t_off, int Tw, int Cs,
                        void* stream);
 
+/* ---- A11 + A15 as one call each: the reference's per-layer Python loop (wavenet.py:572-582 and
+ * Chainer's backward over it) executed inside the library on one stream.                        */
+typedef struct WnStackDesc {
+    int n_layers, Cr, Cs, fw;              /* n_layers = blocks * layers per block                */
+    const int* cd;                         /* host, per layer: gate width                          */
+    const int* dilation;                   /* host, per layer: fw ** layer_index (wavenet.py:429)  */
+    /* host arrays (n_layers) of device pointers; bias tables or entries may be NULL             */
+    const float* const* Wf; const float* const* bf; const float* const* Wg; const float* const* bg;
+    const float* const* Wp; const float* const* bp; const float* const* Ws; const float* const* bs;
+} WnStackDesc;
+/* xs (n_layers,B,T,Cr) receives every layer's output (xs[n_layers-1] is the stack output); z, f, g
+ * are layer-major (layer l at offset sum_{i<l} B*T*cd[i]); f/g NULL for inference; skip (B,T-t_off,Cs)
+ * may be NULL.  The zero prefix is derived from T per layer when compat_zero_prefix != 0.         */
+int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, float* f, float* g,
+                 float* skip, int B, int T, int t_off, int compat_zero_prefix, void* stream);
+size_t wn_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T);
+/* dout: gradient of the last layer's output (NULL = unused, train_audio/train.py:72); dskip
+ * (B,T-t_off,Cs): gradient of the skip sum (NULL = unused); dx (B,T,Cr) may be NULL.  Gradient
+ * tables are host arrays of device pointers, accumulated into (the flat gradient arena).          */
+int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const float* z, const float* f,
+                 const float* g, const float* dout, const float* dskip, float* dx,
+                 float* const* dWf, float* const* dbf, float* const* dWg, float* const* dbg,
+                 float* const* dWp, float* const* dbp, float* const* dWs, float* const* dbs,
+                 float* ws, size_t ws_bytes, int B, int T, int t_off, int compat_zero_prefix, void* stream);
+
 /* ---- softmax over the channel axis (wavenet.py:592) and A14 (wavenet.py:597-617) ------------ */
 int wn_softmax_fwd(const float* logits, float* prob, int N, int Q, void* stream);
 /* row_loss[n] = -log softmax(logits[n])[target[n]]; *loss = mean(row_loss) (device scalar);
@@ -186,6 +212,11 @@ int wn_sqnorm(const float* grad, const float* param, int64_t n, float grad_mult,
 int wn_adam_step(float* param, const float* grad, float* m, float* v, int64_t n,
                  float lr_t, float beta1, float beta2, float eps, float weight_decay,
                  const float* sqnorm, float clip, float grad_mult, void* stream);
+
+/* ---- measurement aid (bench.py): per-entry-point HIP-event timing on the caller's stream ------- */
+int wn_prof_enable(int on);                    /* 1: clear + start recording, 0: stop               */
+/* "name calls total_ms min_ms max_ms" per line into buf; returns the bytes needed (synchronises). */
+int wn_prof_report(char* buf, int buflen);
 
 #ifdef __cplusplus
 }

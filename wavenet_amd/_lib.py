@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Optional, Sequence
+from typing import Dict, Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwavenet_hip.so")
@@ -35,6 +35,13 @@ class WnDecoderDesc(C.Structure):
     ]
 
 
+class WnStackDesc(C.Structure):
+    _fields_ = [
+        ("n_layers", _i), ("Cr", _i), ("Cs", _i), ("fw", _i), ("cd", _ip), ("dilation", _ip),
+        ("Wf", _pp), ("bf", _pp), ("Wg", _pp), ("bg", _pp), ("Wp", _pp), ("bp", _pp), ("Ws", _pp), ("bs", _pp),
+    ]
+
+
 _SIGS = {
     "wn_abi_version": (_i, []),
     "wn_last_error": (C.c_char_p, []),
@@ -50,6 +57,9 @@ _SIGS = {
     "wn_skip_sum_fwd": (_i, [_i, _pp, _pp, _pp, _ip, _p, _i, _i, _i, _i, _i, _i, _p]),
     "wn_skip_sum_bwd_dz": (_i, [_i, _pp, _ip, _p, _pp, _i, _i, _i, _i, _i, _p]),
     "wn_skip_sum_bwd_dw": (_i, [_i, _pp, _ip, _p, _pp, _pp, _i, _i, _i, _i, _i, _p]),
+    "wn_stack_fwd": (_i, [C.POINTER(WnStackDesc), _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "wn_stack_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(WnStackDesc), _i, _i]),
+    "wn_stack_bwd": (_i, [C.POINTER(WnStackDesc)] + [_p] * 8 + [_pp] * 8 + [_p, C.c_size_t, _i, _i, _i, _i, _p]),
     "wn_softmax_fwd": (_i, [_p, _p, _i, _i, _p]),
     "wn_softmax_xent": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "wn_nchw_to_btc": (_i, [_p, _p, _i, _i, _i, _p]),
@@ -63,11 +73,12 @@ _SIGS = {
     "wn_sample_categorical": (_i, [_p, _p, _p, _i, _i, _p]),
     "wn_sqnorm": (_i, [_p, _p, _i64, _f, _f, _p, _p]),
     "wn_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _f, _f, _p]),
+    "wn_prof_enable": (_i, [_i]),
+    "wn_prof_report": (_i, [C.c_char_p, _i]),
 }
 
 EXPORTS = tuple(_SIGS)
 _lib: Optional[C.CDLL] = None
-_profile = None          # {entry point name: [(start_event, end_event), ...]} while profiling is on
 
 
 class WaveNetHipError(RuntimeError):
@@ -89,54 +100,34 @@ def lib() -> C.CDLL:
         if l.wn_abi_version() != ABI_VERSION:
             raise WaveNetHipError("ABI mismatch: library %d, binding %d" % (l.wn_abi_version(), ABI_VERSION))
         _lib = l
-    return _lib if _profile is None else _Profiled(_lib)
-
-
-class _Profiled(object):
-    """Proxy used only inside :func:`profile`: brackets the selected entry points with HIP events
-    recorded on the stream the kernels are launched on (torch's current stream)."""
-
-    def __init__(self, raw):
-        self._raw = raw
-
-    def __getattr__(self, name):
-        fn = getattr(self._raw, name)
-        rec = _profile.get(name) if _profile is not None else None
-        if rec is None:
-            return fn
-        import torch
-
-        def wrapped(*a):
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            rc = fn(*a)
-            e1.record()
-            rec.append((e0, e1))
-            return rc
-        return wrapped
+    return _lib
 
 
 class profile(object):
-    """``with profile(["wn_layer_fwd"]) as prof: ...`` then ``prof.ms()`` -> {name: [ms per launch]}."""
-
-    def __init__(self, names):
-        self.rec = {n: [] for n in names}
+    """``with profile() as prof: ...`` then ``prof.result()`` -> {entry point: (calls, total_ms, min_ms,
+    max_ms)}: HIP events recorded by the library around each per-op entry point's kernels, on the
+    stream they are launched on (include/wavenet_hip.h: wn_prof_enable / wn_prof_report)."""
 
     def __enter__(self):
-        global _profile
-        lib()
-        _profile = self.rec
+        lib().wn_prof_enable(1)
+        self._res = None
         return self
 
     def __exit__(self, *exc):
-        global _profile
-        _profile = None
+        self.result()
+        lib().wn_prof_enable(0)
 
-    def ms(self):
-        import torch
-        torch.cuda.synchronize()
-        return {n: [a.elapsed_time(b) for a, b in ev] for n, ev in self.rec.items()}
+    def result(self) -> Dict[str, Tuple[int, float, float, float]]:
+        if self._res is None:
+            n = lib().wn_prof_report(None, 0)
+            buf = C.create_string_buffer(n + 16)
+            lib().wn_prof_report(buf, n + 16)
+            res = {}
+            for line in buf.value.decode().splitlines():
+                name, calls, tot, mn, mx = line.split()
+                res[name] = (int(calls), float(tot), float(mn), float(mx))
+            self._res = res
+        return self._res
 
 
 def check(rc: int, what: str = "") -> None:

@@ -39,18 +39,21 @@ int wn_layer_fast_path(int Cr, int Cd, int fw) {
 
 int wn_embed_fwd(const int32_t* idx, const float* W, const float* bias, float* out, int B, int T, int Q, int C,
                  int fw, void* stream) {
+    wn::ProfScope prof__("wn_embed_fwd", stream);
     NN(idx); NN(W); NN(out); POS(B); POS(T); POS(Q); POS(C); POS(fw);
     return generic_embed_fwd(idx, W, bias, out, B, T, Q, C, fw, as_stream(stream));
 }
 
 int wn_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* dbias, int B, int T, int Q, int C,
                  int fw, void* stream) {
+    wn::ProfScope prof__("wn_embed_bwd", stream);
     NN(idx); NN(dout); NN(dW); POS(B); POS(T); POS(Q); POS(C); POS(fw);
     return generic_embed_bwd(idx, dout, dW, dbias, B, T, Q, C, fw, as_stream(stream));
 }
 
 int wn_conv_fwd(const float* x, const float* W, const float* bias, float* out, int B, int T, int Cin, int Cout,
                 int fw, int d, int Z, void* stream) {
+    wn::ProfScope prof__("wn_conv_fwd", stream);
     NN(x); NN(W); NN(out); POS(B); POS(T); POS(Cin); POS(Cout); POS(fw); POS(d);
     WN_CHECK_ARG(Z >= 0, "wn_conv_fwd: Z < 0");
     return generic_conv_fwd(x, W, bias, out, B, T, Cin, Cout, fw, d, Z, as_stream(stream));
@@ -58,6 +61,7 @@ int wn_conv_fwd(const float* x, const float* W, const float* bias, float* out, i
 
 int wn_conv_bwd(const float* x, const float* W, const float* dout, float* dx, float* dW, float* dbias, int B,
                 int T, int Cin, int Cout, int fw, int d, int Z, void* stream) {
+    wn::ProfScope prof__("wn_conv_bwd", stream);
     NN(x); NN(W); NN(dout); POS(B); POS(T); POS(Cin); POS(Cout); POS(fw); POS(d);
     WN_CHECK_ARG(Z >= 0, "wn_conv_bwd: Z < 0");
     return generic_conv_bwd(x, W, dout, dx, dW, dbias, B, T, Cin, Cout, fw, d, Z, as_stream(stream));
@@ -66,6 +70,7 @@ int wn_conv_bwd(const float* x, const float* W, const float* dout, float* dx, fl
 int wn_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg,
                  const float* Wp, const float* bp, float* out, float* z, float* f_save, float* g_save, int B,
                  int T, int Cr, int Cd, int fw, int d, int Z, void* stream) {
+    wn::ProfScope prof__("wn_layer_fwd", stream);
     NN(x); NN(Wf); NN(Wg); NN(Wp); NN(out); NN(z);
     POS(B); POS(T); POS(Cr); POS(Cd); POS(fw); POS(d);
     WN_CHECK_ARG(Z >= 0, "wn_layer_fwd: Z < 0");
@@ -81,6 +86,7 @@ int wn_layer_bwd(const float* x, const float* f, const float* g, const float* Wf
                  const float* Wp, const float* dout, const float* dz_skip, float* dx, float* dWf, float* dbf,
                  float* dWg, float* dbg, float* dWp, float* dbp, float* dab_ws, int B, int T, int Cr, int Cd,
                  int fw, int d, int Z, void* stream) {
+    wn::ProfScope prof__("wn_layer_bwd", stream);
     NN(x); NN(f); NN(g); NN(Wf); NN(Wg); NN(Wp); NN(dab_ws);
     POS(B); POS(T); POS(Cr); POS(Cd); POS(fw); POS(d);
     WN_CHECK_ARG(Z >= 0, "wn_layer_bwd: Z < 0");
@@ -97,6 +103,7 @@ int wn_layer_bwd(const float* x, const float* f, const float* g, const float* Wf
 
 int wn_pointwise_fwd(const float* x, const float* W, const float* bias, float* out, int N, int Cin, int Cout,
                      int act, void* stream) {
+    wn::ProfScope prof__("wn_pointwise_fwd", stream);
     NN(x); NN(W); NN(out); POS(N); POS(Cin); POS(Cout);
     WN_CHECK_ARG(act >= WN_ACT_NONE && act <= WN_ACT_ELU, "wn_pointwise_fwd: bad act %d", act);
     if (!force_generic() && mfma_pointwise_supported(Cin, Cout))
@@ -106,6 +113,7 @@ int wn_pointwise_fwd(const float* x, const float* W, const float* bias, float* o
 
 int wn_pointwise_bwd(const float* x, const float* W, const float* dout, float* dx, float* dW, float* dbias,
                      int N, int Cin, int Cout, int act, void* stream) {
+    wn::ProfScope prof__("wn_pointwise_bwd", stream);
     NN(x); NN(W); NN(dout); POS(N); POS(Cin); POS(Cout);
     WN_CHECK_ARG(act >= WN_ACT_NONE && act <= WN_ACT_ELU, "wn_pointwise_bwd: bad act %d", act);
     if (dx && !force_generic() && mfma_pointwise_supported(Cin, Cout)) {
@@ -129,6 +137,7 @@ static int check_skip(const char* fn, int L, int B, int T, int t_off, int Tw, in
 
 int wn_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const float* const* bs, const int* cd,
                     float* skip, int B, int T, int t_off, int Tw, int Cs, int accumulate, void* stream) {
+    wn::ProfScope prof__("wn_skip_sum_fwd", stream);
     NN(z); NN(Ws); NN(cd); NN(skip);
     int rc = check_skip("wn_skip_sum_fwd", L, B, T, t_off, Tw, Cs);
     if (rc) return rc;
@@ -140,6 +149,7 @@ int wn_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const 
 
 int wn_skip_sum_bwd_dz(int L, const float* const* Ws, const int* cd, const float* dskip, float* const* dz, int B,
                        int T, int t_off, int Tw, int Cs, void* stream) {
+    wn::ProfScope prof__("wn_skip_sum_bwd_dz", stream);
     NN(Ws); NN(cd); NN(dskip); NN(dz);
     int rc = check_skip("wn_skip_sum_bwd_dz", L, B, T, t_off, Tw, Cs);
     if (rc) return rc;
@@ -152,6 +162,7 @@ int wn_skip_sum_bwd_dz(int L, const float* const* Ws, const int* cd, const float
 
 int wn_skip_sum_bwd_dw(int L, const float* const* z, const int* cd, const float* dskip, float* const* dWs,
                        float* const* dbs, int B, int T, int t_off, int Tw, int Cs, void* stream) {
+    wn::ProfScope prof__("wn_skip_sum_bwd_dw", stream);
     NN(z); NN(cd); NN(dskip);
     int rc = check_skip("wn_skip_sum_bwd_dw", L, B, T, t_off, Tw, Cs);
     if (rc) return rc;
@@ -166,33 +177,39 @@ int wn_skip_sum_bwd_dw(int L, const float* const* z, const int* cd, const float*
 }
 
 int wn_softmax_fwd(const float* logits, float* prob, int N, int Q, void* stream) {
+    wn::ProfScope prof__("wn_softmax_fwd", stream);
     NN(logits); NN(prob); POS(N); POS(Q);
     return generic_softmax(logits, prob, N, Q, as_stream(stream));
 }
 
 int wn_softmax_xent(const float* logits, const int32_t* target, float* loss, float* dlogits, int N, int Q,
                     void* stream) {
+    wn::ProfScope prof__("wn_softmax_xent", stream);
     NN(logits); NN(target); NN(loss); POS(N); POS(Q);
     return generic_softmax_xent(logits, target, loss, dlogits, N, Q, as_stream(stream));
 }
 
 int wn_nchw_to_btc(const float* src, float* dst, int B, int C, int T, void* stream) {
+    wn::ProfScope prof__("wn_nchw_to_btc", stream);
     NN(src); NN(dst); POS(B); POS(C); POS(T);
     return generic_transpose(src, dst, B, C, T, as_stream(stream));
 }
 
 int wn_btc_to_nchw(const float* src, float* dst, int B, int C, int T, void* stream) {
+    wn::ProfScope prof__("wn_btc_to_nchw", stream);
     NN(src); NN(dst); POS(B); POS(C); POS(T);
     return generic_transpose(src, dst, B, T, C, as_stream(stream));
 }
 
 int wn_sample_categorical(const float* prob, const double* uniforms, int32_t* out, int n, int Q, void* stream) {
+    wn::ProfScope prof__("wn_sample_categorical", stream);
     NN(prob); NN(uniforms); NN(out); POS(n); POS(Q);
     return generic_sample(prob, uniforms, out, n, Q, as_stream(stream));
 }
 
 int wn_sqnorm(const float* grad, const float* param, int64_t n, float grad_mult, float weight_decay, float* out,
               void* stream) {
+    wn::ProfScope prof__("wn_sqnorm", stream);
     NN(grad); NN(out);
     WN_CHECK_ARG(n > 0, "wn_sqnorm: n <= 0");
     WN_CHECK_ARG(weight_decay == 0.f || param, "wn_sqnorm: weight decay needs param");
@@ -202,6 +219,7 @@ int wn_sqnorm(const float* grad, const float* param, int64_t n, float grad_mult,
 int wn_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1,
                  float beta2, float eps, float weight_decay, const float* sqnorm, float clip, float grad_mult,
                  void* stream) {
+    wn::ProfScope prof__("wn_adam_step", stream);
     NN(param); NN(grad); NN(m); NN(v);
     WN_CHECK_ARG(n > 0, "wn_adam_step: n <= 0");
     return generic_adam(param, grad, m, v, n, lr_t, beta1, beta2, eps, weight_decay, sqnorm, clip, grad_mult,

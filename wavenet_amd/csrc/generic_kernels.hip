@@ -185,23 +185,28 @@ static int launch_wgrad(WgradArgs a, hipStream_t s) {
 // column sums:  out[m] += sum_b sum_{t in [tmin,nT)} A(b,t,m)
 __global__ void k_colsum(const float* __restrict__ A, long long a_bs, int a_t0, int lda, int nB,
                          int tmin, int nT, int M, float* __restrict__ out, int t_chunk) {
-    int m = blockIdx.x * blockDim.x + threadIdx.x;
+    // blockDim = (64 columns, 4 row lanes)
+    __shared__ float part[4][64];
+    int m = blockIdx.x * 64 + threadIdx.x;
     int nchunk = (nT - tmin + t_chunk - 1) / t_chunk;
     int b = blockIdx.y / nchunk, ch = blockIdx.y % nchunk;
-    if (m >= M) return;
     int t0 = tmin + ch * t_chunk, t1 = min(nT, t0 + t_chunk);
     float acc = 0.f;
-    for (int t = t0; t < t1; ++t) acc += A[(long long)b * a_bs + (long long)(a_t0 + t) * lda + m];
-    atomicAdd(&out[m], acc);
+    if (m < M)
+        for (int t = t0 + threadIdx.y; t < t1; t += 4) acc += A[(long long)b * a_bs + (long long)(a_t0 + t) * lda + m];
+    part[threadIdx.y][threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.y == 0 && m < M)
+        atomicAdd(&out[m], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 static int launch_colsum(const float* A, long long a_bs, int a_t0, int lda, int nB, int tmin, int nT,
                          int M, float* out, hipStream_t s) {
     if (nT <= tmin || nB <= 0) return WN_OK;
-    int t_chunk = 1024;
+    int t_chunk = 256;
     int nchunk = (nT - tmin + t_chunk - 1) / t_chunk;
     dim3 grid(cdiv(M, 64), nB * nchunk);
-    hipLaunchKernelGGL(k_colsum, grid, dim3(64), 0, s, A, a_bs, a_t0, lda, nB, tmin, nT, M, out, t_chunk);
+    hipLaunchKernelGGL(k_colsum, grid, dim3(64, 4), 0, s, A, a_bs, a_t0, lda, nB, tmin, nT, M, out, t_chunk);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }
@@ -415,26 +420,46 @@ __global__ void k_softmax(const float* __restrict__ logits, float* __restrict__ 
 
 __global__ void k_softmax_xent(const float* __restrict__ logits, const int32_t* __restrict__ target,
                                float* __restrict__ loss, float* __restrict__ dlogits, long long N, int Q) {
+    // one wave per row; rows of up to 256 logits live in registers (one float4 per lane)
     long long row = (long long)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
     int lane = threadIdx.x & 63;
     __shared__ float part[16];
     float rl = 0.f;
     if (row < N) {
         const float* r = logits + row * Q;
-        float m = -INFINITY;
-        for (int q = lane; q < Q; q += 64) m = fmaxf(m, r[q]);
-        m = wave_max(m);
-        float s = 0.f;
-        for (int q = lane; q < Q; q += 64) s += expf(r[q] - m);
-        s = wave_sum(s);
-        int tg = target[row];
-        float lse = m + logf(s);
-        rl = lse - r[tg];
-        if (dlogits) {
-            float inv = 1.f / s, invN = 1.f / (float)N;
-            for (int q = lane; q < Q; q += 64) {
-                float p = expf(r[q] - m) * inv;
-                dlogits[row * Q + q] = (p - (q == tg ? 1.f : 0.f)) * invN;
+        const int tg = target[row];
+        const float invN = 1.f / (float)N;
+        if (Q <= 256 && (Q & 3) == 0) {
+            const bool on = 4 * lane < Q;
+            float4 v = on ? *reinterpret_cast<const float4*>(r + 4 * lane) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            float m = wave_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            float4 e = make_float4(__expf(v.x - m), __expf(v.y - m), __expf(v.z - m), __expf(v.w - m));
+            float s = wave_sum(e.x + e.y + e.z + e.w);
+            float tv = 0.f;
+            if (on && (tg >> 2) == lane) tv = (tg & 3) == 0 ? v.x : (tg & 3) == 1 ? v.y : (tg & 3) == 2 ? v.z : v.w;
+            tv = wave_sum(tv);
+            rl = m + logf(s) - tv;
+            if (dlogits && on) {
+                float inv = invN / s;
+                float4 d = make_float4(e.x * inv, e.y * inv, e.z * inv, e.w * inv);
+                if ((tg >> 2) == lane) {
+                    if ((tg & 3) == 0) d.x -= invN; else if ((tg & 3) == 1) d.y -= invN;
+                    else if ((tg & 3) == 2) d.z -= invN; else d.w -= invN;
+                }
+                *reinterpret_cast<float4*>(dlogits + row * Q + 4 * lane) = d;
+            }
+        } else {
+            float m = -INFINITY;
+            for (int q = lane; q < Q; q += 64) m = fmaxf(m, r[q]);
+            m = wave_max(m);
+            float s = 0.f;
+            for (int q = lane; q < Q; q += 64) s += __expf(r[q] - m);
+            s = wave_sum(s);
+            rl = m + logf(s) - r[tg];
+            if (dlogits) {
+                float inv = 1.f / s;
+                for (int q = lane; q < Q; q += 64)
+                    dlogits[row * Q + q] = (__expf(r[q] - m) * inv - (q == tg ? 1.f : 0.f)) * invN;
             }
         }
     }
@@ -554,7 +579,13 @@ int generic_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* d
                       int Q, int C, int fw, hipStream_t s) {
     size_t lds = ((size_t)Q * fw * C + C) * sizeof(float);
     long long ncol = (long long)B * T;
-    if (lds <= 64 * 1024) {
+    if (lds <= 150 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_embed_bwd_lds),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_set = true;
+        }
         int nblk = (int)(ncol < 512 ? (ncol + 63) / 64 : 512);
         int cpb = (int)((ncol + nblk - 1) / nblk);
         nblk = (int)((ncol + cpb - 1) / cpb);

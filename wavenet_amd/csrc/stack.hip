@@ -1,0 +1,112 @@
+// Whole residual stack in one call (WaveNet.forward_residual_block, wavenet.py:572-582, and its
+// backward): the per-layer loop of the reference runs here, in C++, on one stream, so the host
+// enqueues a 40-layer stack with two calls instead of ~250.  Pure orchestration: every kernel is
+// reached through the per-op entry points of this library.
+#include <vector>
+
+#include "wn_kernels.hpp"
+
+namespace wn {
+static int zero_prefix(int T, int d, int fw) {           // wavenet.py:303-340
+    if (d == 1) return 0;
+    int pad = ((-T) % d + d) % d;
+    int height = (T + pad) / d;
+    if (height < fw) pad += (fw - height) * d;
+    int z = (fw - 1) * d - pad;
+    return z > 0 ? z : 0;
+}
+static int check_desc(const WnStackDesc* d) {
+    WN_CHECK_ARG(d, "stack: desc is NULL");
+    WN_CHECK_ARG(d->n_layers > 0 && d->Cr > 0 && d->Cs > 0 && d->fw > 0, "stack: non-positive size");
+    WN_CHECK_ARG(d->cd && d->dilation && d->Wf && d->Wg && d->Wp && d->Ws, "stack: NULL table");
+    return WN_OK;
+}
+}  // namespace wn
+
+using namespace wn;
+
+extern "C" {
+
+size_t wn_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T) {
+    if (!d || B <= 0 || T <= 0) return 0;
+    size_t n = (size_t)B * T, tot = 0;
+    int maxcd = 0;
+    for (int l = 0; l < d->n_layers; ++l) { tot += n * d->cd[l]; if (d->cd[l] > maxcd) maxcd = d->cd[l]; }
+    tot += n * 2 * maxcd;           // (da, dg) scratch
+    tot += 2 * n * d->Cr;           // ping-pong gradient of the residual stream
+    return tot * sizeof(float);
+}
+
+int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, float* f, float* g, float* skip,
+                 int B, int T, int t_off, int compat_zero_prefix, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    WN_CHECK_ARG(x && xs && z && B > 0 && T > 0, "wn_stack_fwd: bad argument");
+    WN_CHECK_ARG((f == nullptr) == (g == nullptr), "wn_stack_fwd: f and g go together");
+    WN_CHECK_ARG(t_off >= 0 && t_off < T, "wn_stack_fwd: t_off outside [0,T)");
+    const size_t n = (size_t)B * T;
+    const int L = d->n_layers;
+    std::vector<const float*> zp(L);
+    size_t zoff = 0;
+    const float* in = x;
+    for (int l = 0; l < L; ++l) {
+        float* out = xs + (size_t)l * n * d->Cr;
+        int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
+        rc = wn_layer_fwd(in, d->Wf[l], d->bf ? d->bf[l] : nullptr, d->Wg[l], d->bg ? d->bg[l] : nullptr, d->Wp[l],
+                          d->bp ? d->bp[l] : nullptr, out, z + zoff, f ? f + zoff : nullptr, g ? g + zoff : nullptr,
+                          B, T, d->Cr, d->cd[l], d->fw, d->dilation[l], Z, stream);
+        if (rc) return rc;
+        zp[l] = z + zoff;
+        zoff += n * d->cd[l];
+        in = out;
+    }
+    if (skip)
+        return wn_skip_sum_fwd(L, zp.data(), d->Ws, d->bs, d->cd, skip, B, T, t_off, T - t_off, d->Cs, 0, stream);
+    return WN_OK;
+}
+
+int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const float* z, const float* f,
+                 const float* g, const float* dout, const float* dskip, float* dx,
+                 float* const* dWf, float* const* dbf, float* const* dWg, float* const* dbg, float* const* dWp,
+                 float* const* dbp, float* const* dWs, float* const* dbs, float* ws, size_t ws_bytes, int B, int T,
+                 int t_off, int compat_zero_prefix, void* stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    WN_CHECK_ARG(x && xs && z && f && g && ws && dWf && dWg && dWp, "wn_stack_bwd: NULL argument");
+    WN_CHECK_ARG(dout || dskip, "wn_stack_bwd: no incoming gradient");
+    WN_CHECK_ARG(ws_bytes >= wn_stack_bwd_workspace_bytes(d, B, T), "wn_stack_bwd: workspace too small");
+    const size_t n = (size_t)B * T;
+    const int L = d->n_layers;
+    int maxcd = 0;
+    std::vector<const float*> zp(L);
+    std::vector<float*> dzp(L);
+    std::vector<size_t> off(L);
+    size_t zoff = 0;
+    for (int l = 0; l < L; ++l) { off[l] = zoff; zp[l] = z + zoff; dzp[l] = ws + zoff; zoff += n * d->cd[l]; if (d->cd[l] > maxcd) maxcd = d->cd[l]; }
+    float* dab = ws + zoff;
+    float* gbuf[2] = {dab + n * 2 * maxcd, dab + n * 2 * maxcd + n * d->Cr};
+    const int Tw = T - t_off;
+    if (dskip) {
+        rc = wn_skip_sum_bwd_dz(L, d->Ws, d->cd, dskip, dzp.data(), B, T, t_off, Tw, d->Cs, stream);
+        if (rc) return rc;
+        if (dWs) {
+            rc = wn_skip_sum_bwd_dw(L, zp.data(), d->cd, dskip, dWs, dbs, B, T, t_off, Tw, d->Cs, stream);
+            if (rc) return rc;
+        }
+    }
+    const float* gout = dout;
+    for (int l = L - 1; l >= 0; --l) {
+        const float* in = l == 0 ? x : xs + (size_t)(l - 1) * n * d->Cr;
+        float* gin = (l == 0) ? dx : gbuf[l & 1];
+        int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
+        rc = wn_layer_bwd(in, f + off[l], g + off[l], d->Wf[l], d->Wg[l], d->Wp[l], gout, dskip ? dzp[l] : nullptr, gin,
+                          dWf[l], dbf ? dbf[l] : nullptr, dWg[l], dbg ? dbg[l] : nullptr, gout ? dWp[l] : nullptr,
+                          (gout && dbp) ? dbp[l] : nullptr, dab, B, T, d->Cr, d->cd[l], d->fw, d->dilation[l], Z, stream);
+        if (rc) return rc;
+        gout = gin;
+        if (!gin) break;          // l == 0 and the caller does not want dx
+    }
+    return WN_OK;
+}
+
+}  // extern "C"

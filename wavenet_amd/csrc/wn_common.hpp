@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <string.h>
 
 #include "../../include/wavenet_hip.h"
 
@@ -48,6 +49,13 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// prof.hip: brackets an entry point's kernels with hipEvents when wn_prof_enable(1) is in effect
+struct ProfScope {
+    int id = 0; hipStream_t s = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr; bool on;
+    ProfScope(const char* name, void* stream);
+    ~ProfScope();
+};
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- device math shared by the generic and the MFMA kernels ---------------------------------

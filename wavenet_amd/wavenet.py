@@ -14,6 +14,7 @@ the hot path.  T-contiguous inputs (numpy one-hot images) are converted once at 
 """
 from __future__ import annotations
 
+import ctypes as C
 import json
 import math
 import os
@@ -232,7 +233,7 @@ class _XentFn(_Fn):
 
 
 class _StackFn(_Fn):
-    """All residual layers + the deferred skip sum as ONE autograd node
+    """All residual layers + the deferred skip sum as ONE autograd node and ONE library call each way
     (WaveNet.forward_residual_block, wavenet.py:572-582)."""
 
     @staticmethod
@@ -242,78 +243,43 @@ class _StackFn(_Fn):
         ctx.set_materialize_grads(False)
         B, T, Cr = x.shape
         x = x.contiguous()
-        lib, st = _lib.lib(), stream_ptr()
-        L = net._flat_layers
-        nL = len(L)
-        xs = [x]
-        zs, fs, gs = [], [], []
-        for lay in L:
-            Z = net._Z(T, lay.dilation)
-            out = torch.empty((B, T, Cr), device=x.device, dtype=torch.float32)
-            z = torch.empty((B, T, lay.cd), device=x.device, dtype=torch.float32)
-            f = torch.empty_like(z) if train else None
-            g = torch.empty_like(z) if train else None
-            check(lib.wn_layer_fwd(ptr(xs[-1]), ptr(lay.wf.W), ptr(lay.wf.b), ptr(lay.wg.W), ptr(lay.wg.b),
-                                   ptr(lay.projection_block.W), ptr(lay.projection_block.b), ptr(out), ptr(z),
-                                   ptr(f), ptr(g), B, T, Cr, lay.cd, lay.fw, lay.dilation, Z, st), "wn_layer_fwd")
-            xs.append(out)
-            zs.append(z); fs.append(f); gs.append(g)
-        Tw = T - t_off
-        Cs = net._Cs
-        skip = torch.empty((B, Tw, Cs), device=x.device, dtype=torch.float32)
-        net._skip_sum(zs, skip, B, T, t_off, Tw)
+        desc = net._stack_desc()
+        L = len(net._flat_layers)
+        ncd = sum(lay.cd for lay in net._flat_layers)
+        dev_ = x.device
+        xs = torch.empty((L, B, T, Cr), device=dev_, dtype=torch.float32)
+        z = torch.empty((B * T * ncd,), device=dev_, dtype=torch.float32)
+        f = torch.empty_like(z) if train else None
+        g = torch.empty_like(z) if train else None
+        skip = torch.empty((B, T - t_off, net._Cs), device=dev_, dtype=torch.float32)
+        check(_lib.lib().wn_stack_fwd(desc, ptr(x), ptr(xs), ptr(z), ptr(f), ptr(g), ptr(skip), B, T, t_off,
+                                      1 if net.compat_zero_prefix else 0, stream_ptr()), "wn_stack_fwd")
         ctx.net, ctx.t_off, ctx.shape = net, t_off, (B, T, Cr)
-        ctx.xs = xs[:-1] if train else None      # inputs of every layer
-        ctx.zs, ctx.fs, ctx.gs = (zs, fs, gs) if train else (None, None, None)
-        net._last_layer_inputs = xs[:-1]         # FasterWaveNet seeds its rings from these
-        return xs[-1], skip
+        ctx.saved = (x, xs, z, f, g) if train else None
+        net._last_layer_inputs = [x] + [xs[l] for l in range(L - 1)]      # FasterWaveNet seeds its rings from these
+        return xs[L - 1], skip
 
     @staticmethod
     def backward(ctx, dout, dskip):
         net, t_off = ctx.net, ctx.t_off
         B, T, Cr = ctx.shape
-        if ctx.xs is None:
+        if ctx.saved is None:
             raise _lib.WaveNetHipError("backward through a forward that ran without grad enabled")
-        lib, st = _lib.lib(), stream_ptr()
-        L = net._flat_layers
-        nL = len(L)
-        Tw = T - t_off
-        dev = ctx.xs[0].device
-        dzs = [None] * nL
-        if dskip is not None:
-            dskip = dskip.contiguous()
-            dzs = [torch.empty((B, T, lay.cd), device=dev, dtype=torch.float32) for lay in L]
-            cds = int_array([lay.cd for lay in L])
-            check(lib.wn_skip_sum_bwd_dz(nL, ptr_array([lay.projection_softmax.W for lay in L]), cds, ptr(dskip),
-                                         ptr_array(dzs), B, T, t_off, Tw, net._Cs, st), "wn_skip_sum_bwd_dz")
-            check(lib.wn_skip_sum_bwd_dw(nL, ptr_array(ctx.zs), cds, ptr(dskip),
-                                         ptr_array([lay.projection_softmax.W.grad for lay in L]),
-                                         ptr_array([None if lay.projection_softmax.b is None
-                                                    else lay.projection_softmax.b.grad for lay in L]),
-                                         B, T, t_off, Tw, net._Cs, st), "wn_skip_sum_bwd_dw")
-        g_out = None if dout is None else dout.contiguous()
-        maxcd = max(lay.cd for lay in L)
-        dab = torch.empty((B, T, 2 * maxcd), device=dev, dtype=torch.float32)
-        for j in range(nL - 1, -1, -1):
-            lay = L[j]
-            if g_out is None and dzs[j] is None:
-                continue
-            Z = net._Z(T, lay.dilation)
-            need_dx = j > 0 or ctx.needs_input_grad[0]
-            dx = torch.empty((B, T, Cr), device=dev, dtype=torch.float32) if need_dx else None
-            pb = lay.projection_block
-            has_do = g_out is not None
-            check(lib.wn_layer_bwd(ptr(ctx.xs[j]), ptr(ctx.fs[j]), ptr(ctx.gs[j]), ptr(lay.wf.W), ptr(lay.wg.W),
-                                   ptr(pb.W), ptr(g_out), ptr(dzs[j]), ptr(dx),
-                                   ptr(lay.wf.W.grad), ptr(None if lay.wf.b is None else lay.wf.b.grad),
-                                   ptr(lay.wg.W.grad), ptr(None if lay.wg.b is None else lay.wg.b.grad),
-                                   ptr(pb.W.grad if has_do else None),
-                                   ptr(pb.b.grad if (has_do and pb.b is not None) else None),
-                                   ptr(dab), B, T, Cr, lay.cd, lay.fw, lay.dilation, Z, st), "wn_layer_bwd")
-            g_out = dx
-            dzs[j] = None
-        ctx.xs = ctx.zs = ctx.fs = ctx.gs = None
-        return g_out, None, None, None, None
+        x, xs, z, f, g = ctx.saved
+        lib = _lib.lib()
+        desc = net._stack_desc()
+        gt = net._grad_tables()
+        nbytes = lib.wn_stack_bwd_workspace_bytes(desc, B, T)
+        ws = torch.empty((nbytes // 4,), device=x.device, dtype=torch.float32)
+        dout = None if dout is None else dout.contiguous()
+        dskip = None if dskip is None else dskip.contiguous()
+        dx = torch.empty((B, T, Cr), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        check(lib.wn_stack_bwd(desc, ptr(x), ptr(xs), ptr(z), ptr(f), ptr(g), ptr(dout), ptr(dskip), ptr(dx),
+                               gt["wf"], gt["bf"], gt["wg"], gt["bg"], gt["wp"], gt["bp"], gt["ws"], gt["bs"],
+                               ptr(ws), nbytes, B, T, t_off, 1 if net.compat_zero_prefix else 0, stream_ptr()),
+              "wn_stack_bwd")
+        ctx.saved = None
+        return dx, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -559,6 +525,36 @@ class WaveNet(object):
 
     def _weights_changed(self):
         pass
+
+    def _stack_desc(self):
+        """WnStackDesc over the current arena (rebuilt when the arena moves, e.g. to_gpu)."""
+        key = self._arena.data_ptr()
+        if getattr(self, "_desc_key", None) != key:
+            L = self._flat_layers
+            keep = dict(
+                cd=int_array([l.cd for l in L]), dil=int_array([l.dilation for l in L]),
+                Wf=ptr_array([l.wf.W for l in L]), bf=ptr_array([l.wf.b for l in L]),
+                Wg=ptr_array([l.wg.W for l in L]), bg=ptr_array([l.wg.b for l in L]),
+                Wp=ptr_array([l.projection_block.W for l in L]), bp=ptr_array([l.projection_block.b for l in L]),
+                Ws=ptr_array([l.projection_softmax.W for l in L]), bs=ptr_array([l.projection_softmax.b for l in L]))
+            d = _lib.WnStackDesc()
+            d.n_layers, d.Cr, d.Cs, d.fw = len(L), self._Cr, self._Cs, self.params.residual_conv_filter_width
+            d.cd, d.dilation = keep["cd"], keep["dil"]
+            for k in ("Wf", "bf", "Wg", "bg", "Wp", "bp", "Ws", "bs"):
+                setattr(d, k, C.cast(keep[k], C.POINTER(C.c_void_p)))
+            g = lambda t: None if t is None else t.grad
+            gt = dict(
+                wf=ptr_array([l.wf.W.grad for l in L]), bf=ptr_array([g(l.wf.b) for l in L]),
+                wg=ptr_array([l.wg.W.grad for l in L]), bg=ptr_array([g(l.wg.b) for l in L]),
+                wp=ptr_array([l.projection_block.W.grad for l in L]), bp=ptr_array([g(l.projection_block.b) for l in L]),
+                ws=ptr_array([l.projection_softmax.W.grad for l in L]),
+                bs=ptr_array([g(l.projection_softmax.b) for l in L]))
+            self._desc_key, self._desc, self._desc_keep, self._gt = key, d, keep, gt
+        return C.byref(self._desc)
+
+    def _grad_tables(self):
+        self._stack_desc()
+        return self._gt
 
     # -- optimiser (wavenet.py:457-519) ---------------------------------------------------------
     def setup_optimizer(self):
