@@ -510,3 +510,29 @@ def test_layer_bwd(Cr, Cd, fw, d, B, T, bias, with_dout):
     if bias:
         for k in range(3 if with_dout else 2):
             np.testing.assert_allclose(to_np(gb_[k]), db_ref[k].numpy(), atol=2e-4 * max(1.0, float(db_ref[k].abs().max())))
+
+
+@pytest.mark.parametrize("blocks,layers", [(2, 5), (4, 10)])
+def test_fast_decoder_specialised_kernel(blocks, layers):
+    """decoder_fast.hip (32/32/256, fw 2): on-device generate loop and step API vs the oracle's literal
+    full-window fast generation (faster_wavenet.py:50-113), ELU head, bit-exact tokens."""
+    over = dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * layers,
+                residual_num_blocks=blocks, softmax_conv_channels=[256, 256])
+    p, w, net = build(over, cls=FasterWaveNet, seed=77)
+    w["softmax_0/b"] = (np.random.RandomState(1).standard_normal(256) * 0.5).astype(np.float32)
+    net.load_state_dict(w)
+    n = 40 if layers == 5 else 12
+    u = np.random.RandomState(11).random_sample(n)
+    tr = []
+    want = R.generate(p, w, n, u, fast=True, fast_head_act="elu", trace=tr)
+    toks, probs = net.generate(n, u, return_probs=True)
+    np.testing.assert_allclose(to_np(probs), np.array(tr), atol=2e-5)
+    np.testing.assert_array_equal(to_np(toks), want)
+    # step API on the same handle: reset, prefill, then feed the oracle's tokens one at a time
+    net.prev_causal_outputs = None
+    iw = net.input_width
+    buf = np.full((iw,), 127, np.int32)
+    for step in range(min(n, 8)):
+        pr = net._forward_one_step(buf[-iw:].reshape(1, -1), as_numpy=True)[0, :, 0, -1]
+        np.testing.assert_allclose(pr, tr[step], atol=2e-5)
+        buf = np.append(buf, [want[step]]).astype(np.int32)

@@ -17,18 +17,11 @@
 #include <vector>
 
 #include "wn_kernels.hpp"
+#include "decoder_types.hpp"
 
 namespace wn {
 
 static constexpr int kDecThreads = 512;
-
-struct DecCausal { int w, b, ring, cin, cout; };            // float offsets into the arena; b < 0: none
-struct DecLayer { int wfg, bfg, wps, bps, ring, d, cd; };
-struct DecHead { int w, b, cin, cout; };
-struct DecMeta {
-    int Q, fwc, ncausal, fw, nlayers, Cr, Cs, nhead, head_act;
-    int maxc;          // widest vector that has to sit in LDS
-};
 
 struct Decoder {
     DecMeta meta{};
@@ -45,7 +38,25 @@ struct Decoder {
     DecHead* d_heads = nullptr;
     long long step = 0;           // index of the next column to be consumed
     size_t lds_bytes = 0;
+    float* fastP = nullptr;       // packed weights of the specialised kernel (decoder_fast.hip), or NULL
+    int head_bias_off = -1;
 };
+
+// the shape decoder_fast.hip is written for (BASELINE.json config 4 with the reference's default biases)
+static bool fast_shape(const WnDecoderDesc* d) {
+    const char* e = getenv("WAVENET_HIP_FORCE_GENERIC");
+    if (e && e[0] == '1') return false;
+    if (!(d->Q == 256 && d->n_causal == 1 && d->fw_causal == 2 && d->fw == 2 && d->Cr == 32 && d->Cs == 256 &&
+          d->n_head == 1 && d->head_channels[0] == 256 && d->head_channels[1] == 256 &&
+          d->n_blocks * d->n_layers <= 128))
+        return false;
+    if (d->causal_b && d->causal_b[0]) return false;
+    for (int l = 0; l < d->n_layers; ++l)
+        if (d->cd[l] != 32) return false;
+    for (int j = 0; j < d->n_blocks * d->n_layers; ++j)
+        if ((d->bf && d->bf[j]) || (d->bg && d->bg[j]) || (d->bp && d->bp[j]) || (d->bs && d->bs[j])) return false;
+    return true;
+}
 
 // ---- packing ---------------------------------------------------------------------------------
 // dst[(k*Cin + c)*ostride + ooff + o] = src[(o*Cin + c)*fw + k]
@@ -323,6 +334,7 @@ static int pack_weights(Decoder* D, const WnDecoderDesc* d, hipStream_t s) {
             hipLaunchKernelGGL(k_copy_off, dim3(cdiv(H.cout, T)), dim3(T), 0, s, d->head_b[i], D->arena + H.b, H.cout);
     }
     WN_LAUNCH_CHECK();
+    if (D->fastP) return decode_fast_pack(d, D->fastP, s);
     return WN_OK;
 }
 
@@ -410,6 +422,10 @@ int wn_decoder_create(void** handle, const WnDecoderDesc* d, void* stream) {
     DEC_HIP(hipMemcpyAsync(D->d_layers, D->layers.data(), D->layers.size() * sizeof(DecLayer), hipMemcpyHostToDevice, s));
     DEC_HIP(hipMemcpyAsync(D->d_heads, D->heads.data(), D->heads.size() * sizeof(DecHead), hipMemcpyHostToDevice, s));
     DEC_HIP(hipStreamSynchronize(s));      // the host vectors above must outlive the copies
+    if (fast_shape(d)) {
+        DEC_HIP(hipMalloc(&D->fastP, decode_fast_pack_floats(M.nlayers) * sizeof(float)));
+        D->head_bias_off = D->heads[0].b;
+    }
 #undef DEC_HIP
     rc = pack_weights(D, d, s);
     if (rc) { wn_decoder_destroy(D); return rc; }
@@ -421,6 +437,7 @@ int wn_decoder_destroy(void* handle) {
     Decoder* D = (Decoder*)handle;
     if (!D) return WN_OK;
     if (D->arena) (void)hipFree(D->arena);
+    if (D->fastP) (void)hipFree(D->fastP);
     if (D->tok_ring) (void)hipFree(D->tok_ring);
     if (D->dmeta) (void)hipFree(D->dmeta);
     delete D;
@@ -468,6 +485,16 @@ int wn_decoder_step(void* handle, int32_t token, float* prob, int apply_softmax,
     Decoder* D = (Decoder*)handle;
     WN_CHECK_ARG(D && prob, "wn_decoder_step: bad argument");
     WN_CHECK_ARG(token >= 0 && token < D->meta.Q, "wn_decoder_step: token %d outside [0,%d)", token, D->meta.Q);
+    WN_CHECK_ARG(D->step + 1 < (1ll << 31), "wn_decoder_step: step counter overflow");
+    if (D->fastP) {
+        int rc = decode_fast_launch(D->fastP, D->meta.nlayers, D->head_bias_off >= 0 ? D->arena + D->head_bias_off : nullptr,
+                                    D->arena + D->causal[0].w, D->d_layers, D->arena, D->tok_ring, D->step, 1, (int)token,
+                                    nullptr, nullptr, prob, D->meta.Q, apply_softmax, 0, D->meta.head_act,
+                                    as_stream(stream));
+        if (rc) return rc;
+        D->step += 1;
+        return WN_OK;
+    }
     hipLaunchKernelGGL(k_decode, dim3(1), dim3(kDecThreads), D->lds_bytes, as_stream(stream), D->meta, D->d_causal,
                        D->d_layers, D->d_heads, D->arena, D->tok_ring, D->step, 1, (int)token,
                        (const double*)nullptr, (int32_t*)nullptr, prob, D->meta.Q, apply_softmax, 0);
@@ -481,6 +508,16 @@ int wn_decoder_run(void* handle, int32_t first_token, const double* uniforms, in
     Decoder* D = (Decoder*)handle;
     WN_CHECK_ARG(D && uniforms && out_tokens && n > 0, "wn_decoder_run: bad argument");
     WN_CHECK_ARG(first_token >= 0 && first_token < D->meta.Q, "wn_decoder_run: token outside [0,Q)");
+    WN_CHECK_ARG(D->step + n < (1ll << 31), "wn_decoder_run: step counter overflow");
+    if (D->fastP) {
+        int rc = decode_fast_launch(D->fastP, D->meta.nlayers, D->head_bias_off >= 0 ? D->arena + D->head_bias_off : nullptr,
+                                    D->arena + D->causal[0].w, D->d_layers, D->arena, D->tok_ring, D->step, n,
+                                    (int)first_token, uniforms, out_tokens, prob_trace, D->meta.Q, 1, 1,
+                                    D->meta.head_act, as_stream(stream));
+        if (rc) return rc;
+        D->step += n;
+        return WN_OK;
+    }
     hipLaunchKernelGGL(k_decode, dim3(1), dim3(kDecThreads), D->lds_bytes, as_stream(stream), D->meta, D->d_causal,
                        D->d_layers, D->d_heads, D->arena, D->tok_ring, D->step, n, (int)first_token, uniforms,
                        out_tokens, prob_trace, D->meta.Q, 1, 1);

@@ -1,0 +1,368 @@
+// Specialised persistent decode kernel for the shape of BASELINE.json config 4:
+//   Q = 256, one causal layer (fw 2), Cr = Cd = 32, Cs = 256, residual fw 2, one head conv 256 -> 256,
+//   no biases except the head's (the reference's defaults, wavenet.py:108,116-117,138).
+// Same algorithm and state as k_decode in decoder.hip (FasterWaveNet._forward_one_step restated with
+// rings instead of rolled windows); what changes is how ONE workgroup is used so that a step is not
+// a chain of L2 round trips and wide barriers:
+//   * 256 threads = one wave per SIMD: a workgroup barrier costs ~130 cycles instead of ~500 with 16
+//     waves (measured), and there are two per layer (gate -> z, projection -> next x);
+//   * the 64 KB embedding table of the causal layer sits in LDS for the whole launch;
+//   * the head's 256x256 weights live in registers for the whole launch (256 per thread: one wave
+//     per SIMD owns the whole 512-entry register file);
+//   * a layer's 13,312 weights are 52 per thread, fetched ONE LAYER AHEAD (the loads of layer l+1 are
+//     in flight while layer l computes; the in-loop barriers wait for LDS only, never for vmcnt), as
+//     is the ring column x[n-d] of the next layer;
+//   * the waves are specialised: waves 0-1 run only the dependent chain (gate rows over 2 lanes, the
+//     residual projection over 4, DPP reductions), waves 2-3 run the skip projection (61 % of the
+//     MACs) ONE LAYER BEHIND from a table of z columns in LDS, two rows per thread accumulated in
+//     registers over all 40 layers -- off the critical path, no reduction, no extra barrier.
+#include "wn_kernels.hpp"
+#include "decoder_types.hpp"
+
+namespace wn {
+
+static constexpr int kFT = 256;      // waves 0-1: the dependent chain; waves 2-3: skip rows, one layer behind
+static constexpr int kMaxFastLayers = 128;
+static constexpr int kLayerFloats = 4096 + 1024 + 8192;     // gate | residual projection | skip projection
+
+__device__ __forceinline__ float dpp_f(float v, int ctrl_sel) {
+    int r;
+    switch (ctrl_sel) {
+        case 101: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true); break;  // quad xor 1
+        default: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true); break;   // quad xor 2
+    }
+    return __int_as_float(r);
+}
+__device__ __forceinline__ float quad_allsum(float v) {
+    v += dpp_f(v, 101);
+    v += dpp_f(v, 102);
+    return v;
+}
+__device__ __forceinline__ float wave_allmax(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_allsum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// ---- packing: every per-thread weight group is a float4 at [plane][thread] (coalesced 16-byte loads) --
+// chain threads t = 0..127:  gate  row r = t/2 = 2c + (0 filter | 1 gate), k = 32*(t%2) + 4j + e  (8 planes)
+//                            Wp    row o = t/4, k = 8*(t%4) + 4j + e                                (2 planes)
+// skip threads  t = 0..127:  rows cs = 2t (planes 0-7) and 2t+1 (planes 8-15), k = 4(j%8) + e
+__global__ void k_pack_fast_layer(const float* __restrict__ Wf, const float* __restrict__ Wg,
+                                  const float* __restrict__ Wp, const float* __restrict__ Ws,
+                                  float* __restrict__ dst) {
+    const int t = threadIdx.x;     // 0..127
+    {
+        const int r = t >> 1, kp = t & 1, c = r >> 1;
+        const float* W = (r & 1) ? Wg : Wf;
+        for (int j = 0; j < 8; ++j)
+            for (int e = 0; e < 4; ++e) {
+                const int k = 32 * kp + 4 * j + e, tap = k >> 5, ch = k & 31;     // [x_old(32) | x_cur(32)]
+                dst[(j * 128 + t) * 4 + e] = W[(c * 32 + ch) * 2 + tap];
+            }
+    }
+    {
+        const int o = t >> 2, kp = t & 3;
+        for (int j = 0; j < 2; ++j)
+            for (int e = 0; e < 4; ++e) dst[4096 + (j * 128 + t) * 4 + e] = Wp[o * 32 + 8 * kp + 4 * j + e];
+    }
+    for (int j = 0; j < 16; ++j)
+        for (int e = 0; e < 4; ++e)
+            dst[5120 + (j * 128 + t) * 4 + e] = Ws[(2 * t + (j >> 3)) * 32 + 4 * (j & 7) + e];
+}
+// head: row q = tid, k = 4j+e  ->  Ph[j][tid][4], j = 0..63
+__global__ void k_pack_fast_head(const float* __restrict__ Wh, float* __restrict__ dst) {
+    const int tid = threadIdx.x;
+    for (int j = 0; j < 64; ++j)
+        for (int e = 0; e < 4; ++e) dst[(j * 256 + tid) * 4 + e] = Wh[tid * 256 + 4 * j + e];
+}
+
+struct ChainW { float4 g[8]; float4 p[2]; };
+struct SkipW { float4 s[16]; };
+
+// uniform plane base (SGPRs) + a 32-bit per-lane offset: global_load with an saddr, no 64-bit VALU adds
+__device__ __forceinline__ void load_chain(ChainW& w, const float* __restrict__ P, int l, unsigned t4) {
+    const float* b = P + (long long)l * kLayerFloats;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w.g[j] = *reinterpret_cast<const float4*>(b + j * 512 + t4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) w.p[j] = *reinterpret_cast<const float4*>(b + 4096 + j * 512 + t4);
+}
+__device__ __forceinline__ void load_skip(SkipW& w, const float* __restrict__ P, int l, unsigned t4) {
+    const float* b = P + (long long)l * kLayerFloats + 5120;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w.s[j] = *reinterpret_cast<const float4*>(b + j * 512 + t4);
+}
+
+// LDS-only barrier: waits for this wave's LDS traffic, not for its outstanding global loads, so the
+// one-layer-ahead weight prefetch stays in flight across it (__syncthreads() would drain vmcnt).
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+struct FastLds { const float* xold; float* xcur; float* zall; };
+
+// chain waves: one residual layer of one step.  x_old = xold[l], x_cur = xcur[l]; writes z to zall[l]
+// and x of layer l+1 to xcur[l+1].
+__device__ __forceinline__ void chain_layer(const FastLds& S, const ChainW& wc, int l, int t) {
+    {   // gate: 64 rows x K=64, 2 lanes per row (lane 0: x_old, lane 1: x_cur)
+        const float* xk = ((t & 1) == 0 ? S.xold : S.xcur) + l * 32;
+        float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            p0 += dot4(wc.g[j], *reinterpret_cast<const float4*>(xk + 4 * j));
+            p1 += dot4(wc.g[j + 1], *reinterpret_cast<const float4*>(xk + 4 * j + 4));
+        }
+        float p = p0 + p1;
+        p += dpp_f(p, 101);                               // both lanes of the pair hold the row's sum
+        const float fsum = dpp_f(p, 102);                 // gate pair (lanes 4c+2,3) <- filter pair (4c, 4c+1)
+        if ((t & 3) == 2) S.zall[l * 32 + (t >> 2)] = fast_tanh(fsum) * fast_sigmoid(p);
+    }
+    lds_barrier();
+    {   // residual projection: 32 rows x K=32, 4 lanes per row
+        const float* zk = S.zall + l * 32 + 8 * (t & 3);
+        float p = dot4(wc.p[0], *reinterpret_cast<const float4*>(zk)) + dot4(wc.p[1], *reinterpret_cast<const float4*>(zk + 4));
+        p = quad_allsum(p);
+        if ((t & 3) == 0) S.xcur[(l + 1) * 32 + (t >> 2)] = p + S.xcur[l * 32 + (t >> 2)];
+    }
+    lds_barrier();
+}
+
+// skip waves: rows 2t and 2t+1 of Ws_l z_l, accumulated over the layers
+__device__ __forceinline__ void skip_layer(const FastLds& S, const SkipW& w, int l, float& s0, float& s1) {
+    const float* z = S.zall + l * 32;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 z4 = *reinterpret_cast<const float4*>(z + 4 * j);
+        s0 += dot4(w.s[j], z4);
+        s1 += dot4(w.s[8 + j], z4);
+    }
+}
+
+#ifdef WN_DECODE_STAMPS
+#define STAMP(k) do { if (tid == 0) stamps[k] = clock64(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+static constexpr int kUnroll = 10;      // layers per trip of the layer loop (one block of the 4 x 10 stack)
+
+__global__ __launch_bounds__(kFT, 1) void k_decode_fast(
+    const float* __restrict__ P, const float* __restrict__ Ph, const float* __restrict__ hbias,
+    const float* __restrict__ E, const DecLayer* __restrict__ layers, int nlayers, float* __restrict__ arena,
+    int* __restrict__ tok_ring, long long n0, int nsteps, int first_token, const double* __restrict__ uniforms,
+    int32_t* __restrict__ out_tokens, float* __restrict__ prob_out, int prob_stride, int apply_softmax,
+    int do_sample, int head_act) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Elds = sm;                                   // [256][2][32] embedding table of the causal layer
+    float* xold = Elds + 256 * 2 * 32;                  // [L][32]   x_l[n-d] of every layer, fetched at step start
+    float* xcur = xold + kMaxFastLayers * 32;           // [L+1][32] x_l[n]: input of layer l (output of l-1)
+    float* zall = xcur + (kMaxFastLayers + 1) * 32;     // [L][32]   gate output of every layer of this step
+    float* hvec = zall + kMaxFastLayers * 32;           // [256]
+    float* lg = hvec + 256;                             // [256] logits / probabilities
+    float* red = lg + 256;                              // [16]
+    double* cdf = reinterpret_cast<double*>(red + 16);  // [256]
+    int* s_tok = reinterpret_cast<int*>(cdf + 256);     // [4]: current token, previous token
+    int* ringt = s_tok + 4;                             // [L] ring offset per layer
+    int* dmask = ringt + kMaxFastLayers;                // [L] d - 1 (d is a power of two: fw = 2)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    for (int i = tid; i < 256 * 2 * 32 / 4; i += kFT)
+        reinterpret_cast<float4*>(Elds)[i] = reinterpret_cast<const float4*>(E)[i];
+    for (int i = tid; i < nlayers; i += kFT) { ringt[i] = layers[i].ring; dmask[i] = layers[i].d - 1; }
+    const float hb = hbias ? hbias[tid] : 0.f;
+    if (tid == 0) { s_tok[0] = first_token; s_tok[1] = tok_ring[0]; }     // fwc = 2: ring depth 1
+    __syncthreads();
+    FastLds S{xold, xcur, zall};
+    const unsigned t4 = 4u * (tid & 127);
+#ifdef WN_DECODE_STAMPS
+    long long stamps[8];
+#endif
+
+    for (int it = 0; it < nsteps; ++it) {
+        const unsigned n = (unsigned)(n0 + it);
+        const int token = s_tok[0], tprev = s_tok[1];
+        const double u_draw = do_sample ? uniforms[it] : 0.0;      // fetched here, used after the network
+        STAMP(0);
+        // every layer's x[n-d] was written at least one step ago: fetch them all now, off the layer chain
+        for (int i = tid; i < nlayers * 32; i += kFT) {
+            const int l = i >> 5;
+            xold[i] = arena[ringt[l] + (long long)(n & (unsigned)dmask[l]) * 32 + (i & 31)];
+        }
+        if (tid < 32) xcur[tid] = Elds[(tprev * 2 + 0) * 32 + tid] + Elds[(token * 2 + 1) * 32 + tid];
+        if (tid < 128) {
+            ChainW w[2];
+            load_chain(w[0], P, 0, t4);
+            __syncthreads();
+            STAMP(1);
+            for (int l0 = 0; l0 < nlayers; l0 += kUnroll) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const int l = l0 + u;
+                    if (l < nlayers) {
+                        if (l + 1 < nlayers) load_chain(w[(u + 1) & 1], P, l + 1, t4);   // in flight during layer l
+                        chain_layer(S, w[u & 1], l, tid);
+                    }
+                }
+            }
+        } else {
+            float skip0 = 0.f, skip1 = 0.f;
+            SkipW w[2];
+            load_skip(w[0], P, 0, t4);
+            __syncthreads();
+            for (int l0 = 0; l0 < nlayers; l0 += kUnroll) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const int l = l0 + u;
+                    if (l < nlayers) {
+                        // one layer behind the chain: fetch layer l's rows, use layer l-1's (loaded a trip ago)
+                        if (l > 0) {
+                            load_skip(w[u & 1], P, l, t4);
+                            skip_layer(S, w[(u + 1) & 1], l - 1, skip0, skip1);
+                        }
+                        lds_barrier();
+                        lds_barrier();
+                    }
+                }
+            }
+            if ((nlayers - 1) & 1) skip_layer(S, w[1], nlayers - 1, skip0, skip1);
+            else skip_layer(S, w[0], nlayers - 1, skip0, skip1);
+            hvec[2 * (tid - 128)] = act_apply(skip0, head_act);
+            hvec[2 * (tid - 128) + 1] = act_apply(skip1, head_act);
+        }
+        STAMP(2);
+        // ---- head on the newest column: thread q owns logit q; its 256 weights stream in from L2 -------
+        float v;
+        {
+            const float* Phs = Ph;
+            asm volatile("" : "+s"(Phs));                 // keep the loads here (no hoisting above the layer loop)
+            const unsigned q4 = 4u * tid;
+            float4 wa[16], wb[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wa[j] = *reinterpret_cast<const float4*>(Phs + j * 1024 + q4);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wb[j] = *reinterpret_cast<const float4*>(Phs + (16 + j) * 1024 + q4);
+            // this step's x_cur of every layer becomes the newest ring column
+            for (int i = tid; i < nlayers * 32; i += kFT) {
+                const int l = i >> 5;
+                arena[ringt[l] + (long long)(n & (unsigned)dmask[l]) * 32 + (i & 31)] = xcur[i];
+            }
+            lds_barrier();                                // hvec complete (LDS only: the weight loads stay in flight)
+            float p0 = hb, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+#define HEAD_ACC(W, J0)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 16; j += 4) {                                                   \
+        p0 += dot4(W[j], *reinterpret_cast<const float4*>(hvec + 4 * ((J0) + j)));                        \
+        p1 += dot4(W[j + 1], *reinterpret_cast<const float4*>(hvec + 4 * ((J0) + j) + 4));                \
+        p2 += dot4(W[j + 2], *reinterpret_cast<const float4*>(hvec + 4 * ((J0) + j) + 8));                \
+        p3 += dot4(W[j + 3], *reinterpret_cast<const float4*>(hvec + 4 * ((J0) + j) + 12));               \
+    }
+            HEAD_ACC(wa, 0)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wa[j] = *reinterpret_cast<const float4*>(Phs + (32 + j) * 1024 + q4);
+            HEAD_ACC(wb, 16)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) wb[j] = *reinterpret_cast<const float4*>(Phs + (48 + j) * 1024 + q4);
+            HEAD_ACC(wa, 32)
+            HEAD_ACC(wb, 48)
+#undef HEAD_ACC
+            v = (p0 + p1) + (p2 + p3);
+        }
+        if (apply_softmax) {
+            float m = wave_allmax(v);
+            if (lane == 0) red[wv] = m;
+            lds_barrier();
+            m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            const float e = expf(v - m);
+            float s = wave_allsum(e);
+            if (lane == 0) red[4 + wv] = s;
+            lds_barrier();
+            s = red[4] + red[5] + red[6] + red[7];
+            v = e * (1.f / s);
+        }
+        lg[tid] = v;
+#ifndef WN_DECODE_STAMPS
+        if (prob_out) prob_out[(long long)it * prob_stride + tid] = v;
+#endif
+        lds_barrier();
+        STAMP(3);
+        if (do_sample) {
+            if (tid == 0) {                        // numpy's float64 running sum, in index order
+                double c = 0.0;
+#pragma unroll 1
+                for (int i = 0; i < 256; i += 16) {     // batches of 16 so the LDS reads are pipelined
+                    float t[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) t[e] = lg[i + e];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { c += (double)t[e]; cdf[i + e] = c; }
+                }
+            }
+            lds_barrier();
+            {
+                const double tot = cdf[255];
+                const bool gt = cdf[tid] / tot > u_draw;
+                const unsigned long long bal = __ballot(gt);
+                if (lane == 0) reinterpret_cast<int*>(red)[8 + wv] = bal ? wv * 64 + __ffsll((long long)bal) - 1 : 256;
+            }
+            lds_barrier();
+            if (tid == 0) {
+                const int* r = reinterpret_cast<const int*>(red) + 8;
+                int idx = min(min(r[0], r[1]), min(r[2], r[3]));
+                if (idx > 255) idx = 255;
+                out_tokens[it] = idx;
+                s_tok[1] = token;
+                s_tok[0] = idx;
+            }
+        } else if (tid == 0) {
+            s_tok[1] = token;
+        }
+        __syncthreads();                           // full barrier: orders this step's ring stores before the next step's loads
+#ifdef WN_DECODE_STAMPS
+        STAMP(4);
+        if (tid == 0 && prob_out)
+            for (int k = 0; k < 4; ++k) prob_out[(long long)it * prob_stride + k] = (float)(stamps[k + 1] - stamps[k]);
+#endif
+    }
+    if (tid == 0) tok_ring[0] = s_tok[1];          // the token before the next one to be consumed
+}
+
+size_t decode_fast_lds_bytes() {
+    return (size_t)(256 * 2 * 32 + kMaxFastLayers * 32 + (kMaxFastLayers + 1) * 32 + kMaxFastLayers * 32 + 256 + 256 + 16) * 4 +
+           256 * 8 + (4 + 2 * kMaxFastLayers) * 4;
+}
+size_t decode_fast_pack_floats(int nlayers) { return (size_t)nlayers * kLayerFloats + 256 * 256; }
+
+int decode_fast_pack(const WnDecoderDesc* d, float* dst, hipStream_t s) {
+    const int L = d->n_blocks * d->n_layers;
+    for (int l = 0; l < L; ++l)
+        hipLaunchKernelGGL(k_pack_fast_layer, dim3(1), dim3(128), 0, s, d->Wf[l], d->Wg[l], d->Wp[l], d->Ws[l],
+                           dst + (size_t)l * kLayerFloats);
+    hipLaunchKernelGGL(k_pack_fast_head, dim3(1), dim3(256), 0, s, d->head_W[0], dst + (size_t)L * kLayerFloats);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int decode_fast_launch(const float* P, int nlayers, const float* hbias, const float* E, const DecLayer* layers,
+                       float* arena, int* tok_ring, long long n0, int nsteps, int first_token,
+                       const double* uniforms, int32_t* out_tokens, float* prob_out, int prob_stride,
+                       int apply_softmax, int do_sample, int head_act, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_fast),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)decode_fast_lds_bytes()));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_decode_fast, dim3(1), dim3(kFT), decode_fast_lds_bytes(), s, P,
+                       P + (size_t)nlayers * kLayerFloats, hbias, E, layers, nlayers, arena, tok_ring, n0, nsteps,
+                       first_token, uniforms, out_tokens, prob_out, prob_stride, apply_softmax, do_sample, head_act);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+}  // namespace wn

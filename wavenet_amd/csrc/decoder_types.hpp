@@ -1,0 +1,17 @@
+// Tables shared by the generic (decoder.hip) and the specialised (decoder_fast.hip) decode kernels.
+#pragma once
+namespace wn {
+struct DecCausal { int w, b, ring, cin, cout; };            // float offsets into the arena; b < 0: none
+struct DecLayer { int wfg, bfg, wps, bps, ring, d, cd; };
+struct DecHead { int w, b, cin, cout; };
+struct DecMeta {
+    int Q, fwc, ncausal, fw, nlayers, Cr, Cs, nhead, head_act;
+    int maxc;          // widest vector that has to sit in LDS
+};
+size_t decode_fast_pack_floats(int nlayers);
+int decode_fast_pack(const WnDecoderDesc* d, float* dst, hipStream_t s);
+int decode_fast_launch(const float* P, int nlayers, const float* hbias, const float* E, const DecLayer* layers,
+                       float* arena, int* tok_ring, long long n0, int nsteps, int first_token,
+                       const double* uniforms, int32_t* out_tokens, float* prob_out, int prob_stride,
+                       int apply_softmax, int do_sample, int head_act, hipStream_t s);
+}  // namespace wn

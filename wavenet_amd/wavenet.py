@@ -549,8 +549,8 @@ class WaveNet(object):
                 wp=ptr_array([l.projection_block.W.grad for l in L]), bp=ptr_array([g(l.projection_block.b) for l in L]),
                 ws=ptr_array([l.projection_softmax.W.grad for l in L]),
                 bs=ptr_array([g(l.projection_softmax.b) for l in L]))
-            self._desc_key, self._desc, self._desc_keep, self._gt = key, d, keep, gt
-        return C.byref(self._desc)
+            self._desc_key, self._sdesc, self._desc_keep, self._gt = key, d, keep, gt
+        return C.byref(self._sdesc)
 
     def _grad_tables(self):
         self._stack_desc()
