@@ -86,7 +86,10 @@ int wn_layer_fwd(const float* x,
  *   dx[t] = dout[t] + sum_k (Wf_k^T da + Wg_k^T dg)[t + (fw-1-k)d]
  * dz_skip (B,T,Cd) is this layer's slice of Ws^T dskip (wn_skip_sum_bwd_dz); NULL = none.
  * dout NULL = zero (the last layer's residual output is discarded, train_audio/train.py:72).
- * dab_ws is caller-provided scratch of B*T*2*Cd floats.  dWp/dbp may be NULL (last layer).    */
+ * dab_ws is caller-provided scratch of wn_layer_bwd_workspace_floats() floats ((da,dg) for every
+ * column, plus per-workgroup partial weight-gradient tiles on the MFMA path).  dWp/dbp may be
+ * NULL (last layer).                                                                            */
+size_t wn_layer_bwd_workspace_floats(int B, int T, int Cr, int Cd, int fw);
 int wn_layer_bwd(const float* x, const float* f, const float* g,
                  const float* Wf, const float* Wg, const float* Wp,
                  const float* dout, const float* dz_skip,

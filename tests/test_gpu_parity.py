@@ -497,7 +497,7 @@ def test_layer_bwd(Cr, Cd, fw, d, B, T, bias, with_dout):
     dx = torch.empty_like(xb)
     gW = [torch.zeros_like(w) for w in wt]
     gb_ = [torch.zeros(n, device="cuda") if bias else None for n in (Cd, Cd, Cr)]
-    dab = torch.empty((B, T, 2 * Cd), device="cuda")
+    dab = torch.empty((lib.wn_layer_bwd_workspace_floats(B, T, Cr, Cd, fw),), device="cuda")
     check(lib.wn_layer_bwd(ptr(xb), ptr(fb), ptr(gb), ptr(wt[0]), ptr(wt[1]), ptr(wt[2]), ptr(do), ptr(dz), ptr(dx),
                            ptr(gW[0]), ptr(gb_[0]), ptr(gW[1]), ptr(gb_[1]),
                            ptr(gW[2] if with_dout else None), ptr(gb_[2] if with_dout else None), ptr(dab),

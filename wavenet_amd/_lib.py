@@ -52,6 +52,7 @@ _SIGS = {
     "wn_conv_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "wn_layer_fwd": (_i, [_p] * 11 + [_i] * 7 + [_p]),
     "wn_layer_bwd": (_i, [_p] * 16 + [_i] * 7 + [_p]),
+    "wn_layer_bwd_workspace_floats": (C.c_size_t, [_i, _i, _i, _i, _i]),
     "wn_pointwise_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "wn_pointwise_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "wn_skip_sum_fwd": (_i, [_i, _pp, _pp, _pp, _ip, _p, _i, _i, _i, _i, _i, _i, _p]),

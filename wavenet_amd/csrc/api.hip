@@ -82,6 +82,13 @@ int wn_layer_fwd(const float* x, const float* Wf, const float* bf, const float* 
                              as_stream(stream));
 }
 
+size_t wn_layer_bwd_workspace_floats(int B, int T, int Cr, int Cd, int fw) {
+    if (B <= 0 || T <= 0 || Cd <= 0) return 0;
+    size_t n = (size_t)B * T * 2 * Cd;
+    if (wn_layer_fast_path(Cr, Cd, fw)) n += mfma_layer_bwd_extra_ws_floats();
+    return n;
+}
+
 int wn_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
                  const float* Wp, const float* dout, const float* dz_skip, float* dx, float* dWf, float* dbf,
                  float* dWg, float* dbg, float* dWp, float* dbp, float* dab_ws, int B, int T, int Cr, int Cd,

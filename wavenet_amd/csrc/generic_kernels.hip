@@ -394,6 +394,39 @@ __global__ void k_skip_bwd_dz(const float* __restrict__ Ws, const float* __restr
 // ---------------------------------------------------------------------------------------------
 // softmax / cross entropy: one wave per row
 // ---------------------------------------------------------------------------------------------
+// full-wave reductions on the DPP path (row shifts + row broadcasts + one readlane) instead of six
+// ds_bpermute round trips; the result is uniform (broadcast through an SGPR)
+__device__ __forceinline__ float dpp_mov(float old, float v, int which) {
+    int r;
+    switch (which) {
+        case 1: r = __builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x111, 0xf, 0xf, false); break;
+        case 2: r = __builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x112, 0xf, 0xf, false); break;
+        case 4: r = __builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x114, 0xf, 0xf, false); break;
+        case 8: r = __builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x118, 0xf, 0xf, false); break;
+        case 15: r = __builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x142, 0xa, 0xf, false); break;  // row_bcast:15
+        default: r = __builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x143, 0xc, 0xf, false); break;  // row_bcast:31
+    }
+    return __int_as_float(r);
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    const float ninf = -INFINITY;
+    v = fmaxf(v, dpp_mov(ninf, v, 1));
+    v = fmaxf(v, dpp_mov(ninf, v, 2));
+    v = fmaxf(v, dpp_mov(ninf, v, 4));
+    v = fmaxf(v, dpp_mov(ninf, v, 8));
+    v = fmaxf(v, dpp_mov(ninf, v, 15));
+    v = fmaxf(v, dpp_mov(ninf, v, 31));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_mov(0.f, v, 1);
+    v += dpp_mov(0.f, v, 2);
+    v += dpp_mov(0.f, v, 4);
+    v += dpp_mov(0.f, v, 8);
+    v += dpp_mov(0.f, v, 15);
+    v += dpp_mov(0.f, v, 31);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
@@ -420,24 +453,25 @@ __global__ void k_softmax(const float* __restrict__ logits, float* __restrict__ 
 
 __global__ void k_softmax_xent(const float* __restrict__ logits, const int32_t* __restrict__ target,
                                float* __restrict__ loss, float* __restrict__ dlogits, long long N, int Q) {
-    // one wave per row; rows of up to 256 logits live in registers (one float4 per lane)
-    long long row = (long long)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64;
+    // one wave per row; rows of up to 256 logits live in registers (one float4 per lane).  Waves stride
+    // over rows so that the loss leaves with ONE atomic per block: thousands of adds to one address
+    // would serialise at ~13 ns each.
     int lane = threadIdx.x & 63;
     __shared__ float part[16];
-    float rl = 0.f;
-    if (row < N) {
+    float rl_acc = 0.f;
+    for (long long row = (long long)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64; row < N;
+         row += (long long)gridDim.x * (blockDim.x / 64)) {
+        float rl = 0.f;
         const float* r = logits + row * Q;
         const int tg = target[row];
         const float invN = 1.f / (float)N;
         if (Q <= 256 && (Q & 3) == 0) {
             const bool on = 4 * lane < Q;
             float4 v = on ? *reinterpret_cast<const float4*>(r + 4 * lane) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-            float m = wave_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            float m = wave_max_dpp(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
             float4 e = make_float4(__expf(v.x - m), __expf(v.y - m), __expf(v.z - m), __expf(v.w - m));
-            float s = wave_sum(e.x + e.y + e.z + e.w);
-            float tv = 0.f;
-            if (on && (tg >> 2) == lane) tv = (tg & 3) == 0 ? v.x : (tg & 3) == 1 ? v.y : (tg & 3) == 2 ? v.z : v.w;
-            tv = wave_sum(tv);
+            float s = wave_sum_dpp(e.x + e.y + e.z + e.w);
+            const float tv = r[tg];                       // uniform address: one scalar-ish load
             rl = m + logf(s) - tv;
             if (dlogits && on) {
                 float inv = invN / s;
@@ -462,8 +496,9 @@ __global__ void k_softmax_xent(const float* __restrict__ logits, const int32_t* 
                     dlogits[row * Q + q] = (__expf(r[q] - m) * inv - (q == tg ? 1.f : 0.f)) * invN;
             }
         }
+        rl_acc += rl;
     }
-    if (lane == 0) part[threadIdx.x / 64] = rl;
+    if (lane == 0) part[threadIdx.x / 64] = rl_acc;
     __syncthreads();
     if (threadIdx.x == 0) {
         float s = 0.f;
@@ -780,7 +815,9 @@ int generic_softmax(const float* logits, float* prob, long long N, int Q, hipStr
 int generic_softmax_xent(const float* logits, const int32_t* target, float* loss, float* dlogits, long long N,
                          int Q, hipStream_t s) {
     WN_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
-    hipLaunchKernelGGL(k_softmax_xent, dim3(cdiv(N, 4)), dim3(256), 0, s, logits, target, loss, dlogits, N, Q);
+    int blocks = cdiv(N, 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_softmax_xent, dim3(blocks), dim3(256), 0, s, logits, target, loss, dlogits, N, Q);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

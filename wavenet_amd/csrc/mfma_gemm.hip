@@ -28,7 +28,7 @@ struct CGArgs {
     int K[WN_MAX_SRC];               // per source; row stride of X_src is K
     int wsm[WN_MAX_SRC];             // W row (m) stride per source / problem
     int wsk;                         // W column (k) stride: 1 = row-major W[m][k], else transposed view
-    int nsrc, M, ldo;
+    int nsrc, nprob, M, ldo;
     long long N;                     // output rows
     int rows_out_per_b, rows_src_per_b, off;   // src row = b*rows_src_per_b + (n % rows_out_per_b) + off
     int act;                         // applied to X on load
@@ -38,12 +38,15 @@ struct CGArgs {
 
 __device__ __forceinline__ int cg_ch(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
 
-template <int MT, bool MP>
+// MODE 0: multi-source (sum over sources, one output);  MODE 1: one problem per workgroup (M = MT*32 rows);
+// MODE 2: MT problems of 32 rows each per workgroup (all share X): X is streamed once per MT problems.
+template <int MT, int MODE>
 __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
+    constexpr bool MP = MODE != 0;
     __shared__ __attribute__((aligned(16))) float Alds[MT * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int prob = MP ? blockIdx.y : 0;
+    const int prob = MODE == 1 ? blockIdx.y : (MODE == 2 ? blockIdx.y * MT : 0);
     const int m0 = MP ? 0 : blockIdx.y * (MT * 32);
     const long long n = ((long long)blockIdx.x * 4 + wave) * 32 + j;
     const bool nvalid = n < a.N;
@@ -64,8 +67,8 @@ __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
     const int fq = fc4 >> 1, fh = fc4 & 1;
 
     for (int src = 0; src < a.nsrc; ++src) {
-        const float* __restrict__ Wb = a.W[MP ? prob : src];
-        const int wsm = a.wsm[MP ? prob : src];
+        const float* __restrict__ Wb = a.W[MODE == 1 ? prob : src];
+        const int wsm = a.wsm[MODE == 1 ? prob : src];
         const float* __restrict__ Xb = a.X[src];
         const int K = a.K[src];
         if (a.bias[src] && !MP) {
@@ -79,6 +82,10 @@ __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
 #pragma unroll
             for (int it = 0; it < MT; ++it) {
                 const float* wp = Wb + (long long)(m0 + it * 32 + fi) * wsm + (long long)(k0 + 4 * fc4) * a.wsk;
+                if (MODE == 2) {
+                    const int pi = prob + it < a.nprob ? prob + it : a.nprob - 1;
+                    wp = a.W[pi] + (long long)fi * a.wsm[pi] + (long long)(k0 + 4 * fc4) * a.wsk;
+                }
                 float4 v;
                 if (a.wsk == 1) {
                     v = *reinterpret_cast<const float4*>(wp);
@@ -89,11 +96,11 @@ __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
             }
             float xb[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (srow >= 0) v = *reinterpret_cast<const float4*>(Xb + srow * K + k0 + 8 * q + 4 * h);
-                xb[4 * q + 0] = act_apply(v.x, a.act); xb[4 * q + 1] = act_apply(v.y, a.act);
-                xb[4 * q + 2] = act_apply(v.z, a.act); xb[4 * q + 3] = act_apply(v.w, a.act);
+            for (int q = 0; q < 4; ++q) {      // unconditional load from a clamped row, masked afterwards
+                const float4 v = *reinterpret_cast<const float4*>(Xb + (srow >= 0 ? srow : 0) * K + k0 + 8 * q + 4 * h);
+                const float ms = srow >= 0 ? 1.f : 0.f;
+                xb[4 * q + 0] = act_apply(v.x, a.act) * ms; xb[4 * q + 1] = act_apply(v.y, a.act) * ms;
+                xb[4 * q + 2] = act_apply(v.z, a.act) * ms; xb[4 * q + 3] = act_apply(v.w, a.act) * ms;
             }
             __syncthreads();
 #pragma unroll
@@ -110,9 +117,13 @@ __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
         }
     }
     if (!nvalid) return;
-    float* __restrict__ orow = a.out[prob] + n * a.ldo + m0 + 4 * h;
+    float* __restrict__ orow = a.out[MODE == 2 ? 0 : prob] + n * a.ldo + m0 + 4 * h;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        if (MODE == 2) {
+            if (prob + mt >= a.nprob) break;
+            orow = a.out[prob + mt] + n * a.ldo + 4 * h - mt * 32;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 v = make_float4(acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
@@ -132,16 +143,24 @@ __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
 }
 
 template <bool MP>
-static int launch_colgemm(const CGArgs& a, int nprob, hipStream_t s) {
+static int launch_colgemm(CGArgs& a, int nprob, hipStream_t s) {
     const int M = a.M;
+    a.nprob = nprob;
+    if (MP && M == 32 && nprob > 1) {          // 32-row problems: 8 per workgroup, X streamed once per 8
+        dim3 grid(cdiv(a.N, 128), cdiv(nprob, 8));
+        hipLaunchKernelGGL((k_colgemm<8, 2>), grid, dim3(256), 0, s, a);
+        WN_LAUNCH_CHECK();
+        return WN_OK;
+    }
     int mt = (M % 256 == 0) ? 8 : (M % 128 == 0) ? 4 : (M % 64 == 0) ? 2 : 1;
     if (MP) mt = M / 32;      // multi-problem: the whole (small) M in one workgroup
     dim3 grid(cdiv(a.N, 128), MP ? nprob : M / (mt * 32));
+    constexpr int MODE = MP ? 1 : 0;
     switch (mt) {
-        case 8: hipLaunchKernelGGL((k_colgemm<8, MP>), grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((k_colgemm<4, MP>), grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((k_colgemm<2, MP>), grid, dim3(256), 0, s, a); break;
-        case 1: hipLaunchKernelGGL((k_colgemm<1, MP>), grid, dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_colgemm<8, MODE>), grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((k_colgemm<4, MODE>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_colgemm<2, MODE>), grid, dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_colgemm<1, MODE>), grid, dim3(256), 0, s, a); break;
         default: wn::set_error("colgemm: unsupported M=%d", M); return WN_ESHAPE;
     }
     WN_LAUNCH_CHECK();
@@ -281,9 +300,12 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WGArgs a) {
         for (int s = 0; s < 16; ++s) {
             const int r = r0 + 2 * s + h;
             const int rb = r + a.off;
-            float v = 0.f;
-            if (active && r < r_end && rb >= 0 && rb < a.rows_B_per_b) v = act_apply(Bb[(long long)r * a.ldb], a.act);
-            bv[s] = v;
+            const bool ok = active && r < r_end && rb >= 0 && rb < a.rows_B_per_b;
+            int rc = r < r_end ? r : r_end - 1;                              // clamped row, masked value
+            if (rc + a.off < 0) rc = -a.off;
+            if (rc + a.off >= a.rows_B_per_b) rc = a.rows_B_per_b - 1 - a.off;
+            const float v = active ? act_apply(Bb[(long long)rc * a.ldb], a.act) : 0.f;
+            bv[s] = ok ? v : 0.f;
         }
         __syncthreads();
 #pragma unroll

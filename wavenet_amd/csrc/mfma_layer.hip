@@ -69,14 +69,19 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
         const bool valid = t < T;
         const bool has_old = valid && (t - d) >= 0;
         const long long row = ((long long)b * T + t) * 32 + 4 * h;
+        // loads are unconditional on clamped rows and masked afterwards: a "cond ? load : 0" makes hipcc
+        // branch around every load and drain vmcnt per element
+        const int tc = valid ? t : T - 1;
+        const long long rowc = ((long long)b * T + tc) * 32 + 4 * h;
+        const long long rowo = ((long long)b * T + (tc - d >= 0 ? tc - d : 0)) * 32 + 4 * h;
+        const float mc = valid ? 1.f : 0.f, mo = has_old ? 1.f : 0.f;
         float xc[16], xo[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 v = valid ? *reinterpret_cast<const float4*>(x + row + 8 * q) : make_float4(0, 0, 0, 0);
-            float4 o = has_old ? *reinterpret_cast<const float4*>(x + row - (long long)d * 32 + 8 * q)
-                               : make_float4(0, 0, 0, 0);
-            xc[4 * q + 0] = v.x; xc[4 * q + 1] = v.y; xc[4 * q + 2] = v.z; xc[4 * q + 3] = v.w;
-            xo[4 * q + 0] = o.x; xo[4 * q + 1] = o.y; xo[4 * q + 2] = o.z; xo[4 * q + 3] = o.w;
+            const float4 v = *reinterpret_cast<const float4*>(x + rowc + 8 * q);
+            const float4 o = *reinterpret_cast<const float4*>(x + rowo + 8 * q);
+            xc[4 * q + 0] = v.x * mc; xc[4 * q + 1] = v.y * mc; xc[4 * q + 2] = v.z * mc; xc[4 * q + 3] = v.w * mc;
+            xo[4 * q + 0] = o.x * mo; xo[4 * q + 1] = o.y * mo; xo[4 * q + 2] = o.z * mo; xo[4 * q + 3] = o.w * mo;
         }
         f32x16 aa = bias_f, ag = bias_g;
 #pragma unroll

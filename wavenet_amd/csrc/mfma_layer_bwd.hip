@@ -23,12 +23,14 @@ __device__ __forceinline__ int bch(int s, int h) { return (s & 3) + 8 * (s >> 2)
 
 static constexpr int kPad = 36;                 // LDS row stride (floats) of a transposed 32x32 patch
 static constexpr int kWaves = 4;
+static constexpr int kPartFloats = 5 * 16 * 64;   // five 32x32 accumulator tiles per workgroup
+static constexpr int kMaxBlocks = 512;
 
+template <bool HAS_DO, bool HAS_DZ>
 __global__ __launch_bounds__(256, 2) void k_layer_bwd_p1(
     const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
     const float* __restrict__ Wp, const float* __restrict__ dout, const float* __restrict__ dzs,
-    float* __restrict__ dab, float* __restrict__ dWf, float* __restrict__ dWg, float* __restrict__ dWp,
-    int B, int T, int d, int Z, int tiles_per_b, int ntiles) {
+    float* __restrict__ dab, float* __restrict__ part, int B, int T, int d, int Z, int tiles_per_b, int ntiles) {
     __shared__ __attribute__((aligned(16))) float lds[kWaves * 2 * 32 * kPad + 5 * 16 * 64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -37,8 +39,6 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p1(
     float* red = lds + kWaves * 2 * 32 * kPad;
     const int wave = blockIdx.x * kWaves + wv;
     const int nwaves = gridDim.x * kWaves;
-    const bool has_do = dout != nullptr;
-
     float wpT[16];                                   // A operand of dz: lane (i=cd,h), step s: Wp[ch(s,h)][i]
 #pragma unroll
     for (int s = 0; s < 16; ++s) wpT[s] = Wp[bch(s, h) * 32 + j];
@@ -53,23 +53,22 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p1(
         const int t = t0 + j;
         const bool valid = t < T;
         const long long row = ((long long)b * T + t) * 32 + 4 * h;
+        const long long rowc = ((long long)b * T + (valid ? t : T - 1)) * 32 + 4 * h;   // clamped: loads are unconditional
         f32x16 acc;
         float ff[16], gg[16], dob[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 z4 = make_float4(0, 0, 0, 0), f4 = z4, g4 = z4, o4 = z4;
-            if (valid) {
-                f4 = *reinterpret_cast<const float4*>(f + row + 8 * q);
-                g4 = *reinterpret_cast<const float4*>(g + row + 8 * q);
-                if (dzs) z4 = *reinterpret_cast<const float4*>(dzs + row + 8 * q);
-                if (has_do) o4 = *reinterpret_cast<const float4*>(dout + row + 8 * q);
-            }
+            float4 z4 = make_float4(0, 0, 0, 0), o4 = z4;
+            const float4 f4 = *reinterpret_cast<const float4*>(f + rowc + 8 * q);
+            const float4 g4 = *reinterpret_cast<const float4*>(g + rowc + 8 * q);
+            if (HAS_DZ) z4 = *reinterpret_cast<const float4*>(dzs + rowc + 8 * q);
+            if (HAS_DO) o4 = *reinterpret_cast<const float4*>(dout + rowc + 8 * q);
             acc[4 * q] = z4.x; acc[4 * q + 1] = z4.y; acc[4 * q + 2] = z4.z; acc[4 * q + 3] = z4.w;
             ff[4 * q] = f4.x; ff[4 * q + 1] = f4.y; ff[4 * q + 2] = f4.z; ff[4 * q + 3] = f4.w;
             gg[4 * q] = g4.x; gg[4 * q + 1] = g4.y; gg[4 * q + 2] = g4.z; gg[4 * q + 3] = g4.w;
             dob[4 * q] = o4.x; dob[4 * q + 1] = o4.y; dob[4 * q + 2] = o4.z; dob[4 * q + 3] = o4.w;
         }
-        if (has_do) {
+        if (HAS_DO) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wpT[s], dob[s], acc, 0, 0, 0);
         }
@@ -96,24 +95,36 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p1(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // contraction over the tile's 32 time columns: step s covers columns 2s and 2s+1
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const int tt = t0 + 2 * s + h;
-            const bool tv = tt < T;
-            const long long r0 = ((long long)b * T + tt) * 32 + j;
-            float a_da = lda[(2 * s + h) * kPad + j];
-            float a_dg = ldg[(2 * s + h) * kPad + j];
-            float b_xc = tv ? x[r0] : 0.f;
-            float b_xo = (tv && tt - d >= 0) ? x[r0 - (long long)d * 32] : 0.f;
-            aWf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xc, aWf1, 0, 0, 0);
-            aWf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xo, aWf0, 0, 0, 0);
-            aWg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xc, aWg1, 0, 0, 0);
-            aWg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xo, aWg0, 0, 0, 0);
-            if (dWp) {
-                float a_do = tv ? dout[r0] : 0.f;
-                float b_z = tv ? f[r0] * g[r0] : 0.f;
-                aWp = __builtin_amdgcn_mfma_f32_32x32x2f32(a_do, b_z, aWp, 0, 0, 0);
+        // contraction over the tile's 32 time columns: step s covers columns 2s and 2s+1.  Two halves
+        // of 8 steps; each half first issues ALL its loads (straight-line code, no branch in between),
+        // then runs its MFMAs, so the L2 round trips overlap instead of queueing one behind the other.
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float bxc[8], bxo[8], ado[8], bfz[8], bgz[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int tt = t0 + 2 * (8 * half + u) + h;
+                const bool tv = tt < T;
+                const int ttc = tv ? tt : T - 1;                              // clamped rows, masked values
+                const long long r0 = ((long long)b * T + ttc) * 32 + j;
+                const long long r1 = ((long long)b * T + (ttc - d >= 0 ? ttc - d : 0)) * 32 + j;
+                bxc[u] = x[r0];
+                bxo[u] = x[r1];
+                if (HAS_DO) { ado[u] = dout[r0]; bfz[u] = f[r0]; bgz[u] = g[r0]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = 8 * half + u;
+                const int tt = t0 + 2 * s + h;
+                const float mv = tt < T ? 1.f : 0.f, mo = (tt < T && tt - d >= 0) ? 1.f : 0.f;
+                const float a_da = lda[(2 * s + h) * kPad + j];
+                const float a_dg = ldg[(2 * s + h) * kPad + j];
+                const float b_xc = bxc[u] * mv, b_xo = bxo[u] * mo;
+                aWf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xc, aWf1, 0, 0, 0);
+                aWf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xo, aWf0, 0, 0, 0);
+                aWg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xc, aWg1, 0, 0, 0);
+                aWg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xo, aWg0, 0, 0, 0);
+                if (HAS_DO) aWp = __builtin_amdgcn_mfma_f32_32x32x2f32(ado[u] * mv, bfz[u] * bgz[u], aWp, 0, 0, 0);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -141,20 +152,39 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p1(
         }
     }
     if (wv == 0) {
-        // D layout: lane (j,h), register r  <->  element [row bch(r,h)][column j]
+        // this workgroup's five partial tiles leave with plain coalesced stores: part[wg][tile][r][lane].
+        // (512 workgroups adding atomically into the same 20 KB cost ~35 us per layer; k_layer_bwd_reduce
+        // sums the partials instead.)
+        float* __restrict__ o = part + (long long)blockIdx.x * kPartFloats + lane;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int i = bch(r, h);
-            if (dWf) {                                   // dWf[cd=i][cr=j][k]
-                atomicAdd(dWf + (i * 32 + j) * 2 + 0, aWf0[r]);
-                atomicAdd(dWf + (i * 32 + j) * 2 + 1, aWf1[r]);
-            }
-            if (dWg) {
-                atomicAdd(dWg + (i * 32 + j) * 2 + 0, aWg0[r]);
-                atomicAdd(dWg + (i * 32 + j) * 2 + 1, aWg1[r]);
-            }
-            if (dWp) atomicAdd(dWp + i * 32 + j, aWp[r]);  // dWp[cr=i][cd=j]
+            o[(0 * 16 + r) * 64] = aWf0[r]; o[(1 * 16 + r) * 64] = aWf1[r];
+            o[(2 * 16 + r) * 64] = aWg0[r]; o[(3 * 16 + r) * 64] = aWg1[r];
+            o[(4 * 16 + r) * 64] = aWp[r];
         }
+    }
+}
+
+// dW += sum over workgroups of the partial tiles.  Thread = one element of the five tiles; blockIdx.y
+// splits the workgroup range so that enough loads are in flight; kRedParts light atomics per address.
+static constexpr int kRedParts = 16;
+__global__ void k_layer_bwd_reduce(const float* __restrict__ part, int nwg, float* __restrict__ dWf,
+                                   float* __restrict__ dWg, float* __restrict__ dWp) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;      // 0 .. 5119: tile*1024 + r*64 + lane
+    if (e >= kPartFloats) return;
+    const int per = (nwg + kRedParts - 1) / kRedParts;
+    const int w0 = blockIdx.y * per, w1 = min(nwg, w0 + per);
+    float acc = 0.f;
+#pragma unroll 8
+    for (int w = w0; w < w1; ++w) acc += part[(long long)w * kPartFloats + e];
+    if (w1 <= w0) return;
+    const int tile = e >> 10, r = (e >> 6) & 15, lane = e & 63;
+    const int j = lane & 31, i = bch(r, lane >> 5);           // D layout: element [row bch(r,h)][column j]
+    if (tile < 4) {                                           // dW[cd=i][cr=j][k]
+        float* dW = tile < 2 ? dWf : dWg;
+        if (dW) atomicAdd(dW + (i * 32 + j) * 2 + (tile & 1), acc);
+    } else if (dWp) {
+        atomicAdd(dWp + i * 32 + j, acc);                     // dWp[cr=i][cd=j]
     }
 }
 
@@ -179,21 +209,23 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p2(
         const bool valid = t < T;
         const bool has_new = valid && (t + d) < T;
         const long long row = ((long long)b * T + t) * 32 + 4 * h;
-        const long long drow = ((long long)b * T + t) * 64 + 4 * h;
+        const int tc = valid ? t : T - 1;                                     // clamped rows, masked values
+        const long long rowc = ((long long)b * T + tc) * 32 + 4 * h;
+        const long long drow = ((long long)b * T + tc) * 64 + 4 * h;
+        const long long nrow = ((long long)b * T + (tc + d < T ? tc + d : T - 1)) * 64 + 4 * h;
+        const float mn = has_new ? 1.f : 0.f;
         f32x16 acc;
         float a0[16], g0[16], a1[16], g1[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float4 z = make_float4(0, 0, 0, 0), o = z, va = z, vg = z, na = z, ng = z;
-            if (valid) {
-                if (dout) o = *reinterpret_cast<const float4*>(dout + row + 8 * q);
-                va = *reinterpret_cast<const float4*>(dab + drow + 8 * q);
-                vg = *reinterpret_cast<const float4*>(dab + drow + 32 + 8 * q);
-            }
-            if (has_new) {
-                na = *reinterpret_cast<const float4*>(dab + drow + (long long)d * 64 + 8 * q);
-                ng = *reinterpret_cast<const float4*>(dab + drow + (long long)d * 64 + 32 + 8 * q);
-            }
+            float4 o = make_float4(0, 0, 0, 0);
+            if (dout) o = *reinterpret_cast<const float4*>(dout + rowc + 8 * q);          // uniform condition
+            const float4 va = *reinterpret_cast<const float4*>(dab + drow + 8 * q);
+            const float4 vg = *reinterpret_cast<const float4*>(dab + drow + 32 + 8 * q);
+            float4 na = *reinterpret_cast<const float4*>(dab + nrow + 8 * q);
+            float4 ng = *reinterpret_cast<const float4*>(dab + nrow + 32 + 8 * q);
+            na.x *= mn; na.y *= mn; na.z *= mn; na.w *= mn;
+            ng.x *= mn; ng.y *= mn; ng.z *= mn; ng.w *= mn;
             acc[4 * q] = o.x; acc[4 * q + 1] = o.y; acc[4 * q + 2] = o.z; acc[4 * q + 3] = o.w;
             a0[4 * q] = va.x; a0[4 * q + 1] = va.y; a0[4 * q + 2] = va.z; a0[4 * q + 3] = va.w;
             g0[4 * q] = vg.x; g0[4 * q + 1] = vg.y; g0[4 * q + 2] = vg.z; g0[4 * q + 3] = vg.w;
@@ -224,9 +256,18 @@ int mfma_layer_bwd(const float* x, const float* f, const float* g, const float* 
     WN_CHECK_SHAPE(nt < (1ll << 31), "mfma_layer_bwd: too many tiles");
     const int ntiles = (int)nt;
     int blocks = (ntiles + 3) / 4;
-    if (blocks > 512) blocks = 512;
-    hipLaunchKernelGGL(k_layer_bwd_p1, dim3(blocks), dim3(256), 0, s, x, f, g, Wp, dout, dzs, dab, dWf, dWg,
-                       dout ? dWp : (float*)nullptr, B, T, d, Z, tiles_per_b, ntiles);
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    float* part = dab + (size_t)B * T * 64;          // workspace tail: blocks x kPartFloats partial tiles
+#define P1_LAUNCH(DO, DZ)                                                                                  \
+    hipLaunchKernelGGL((k_layer_bwd_p1<DO, DZ>), dim3(blocks), dim3(256), 0, s, x, f, g, Wp, dout, dzs, dab, part, \
+                       B, T, d, Z, tiles_per_b, ntiles)
+    if (dout && dzs) P1_LAUNCH(true, true);
+    else if (dout) P1_LAUNCH(true, false);
+    else P1_LAUNCH(false, true);
+#undef P1_LAUNCH
+    WN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_layer_bwd_reduce, dim3(kPartFloats / 256, kRedParts), dim3(256), 0, s, part, blocks, dWf, dWg,
+                       dout ? dWp : (float*)nullptr);
     WN_LAUNCH_CHECK();
     if (dx) {
         hipLaunchKernelGGL(k_layer_bwd_p2, dim3(blocks), dim3(256), 0, s, Wf, Wg, dout, dab, dx, B, T, d,
@@ -235,5 +276,7 @@ int mfma_layer_bwd(const float* x, const float* f, const float* g, const float* 
     }
     return WN_OK;
 }
+
+size_t mfma_layer_bwd_extra_ws_floats() { return (size_t)kMaxBlocks * kPartFloats; }
 
 }  // namespace wn

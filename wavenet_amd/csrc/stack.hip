@@ -32,7 +32,13 @@ size_t wn_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T) {
     size_t n = (size_t)B * T, tot = 0;
     int maxcd = 0;
     for (int l = 0; l < d->n_layers; ++l) { tot += n * d->cd[l]; if (d->cd[l] > maxcd) maxcd = d->cd[l]; }
-    tot += n * 2 * maxcd;           // (da, dg) scratch
+    size_t lw = 0;                  // per-layer scratch: (da, dg) + the MFMA path's partial weight-gradient tiles
+    for (int l = 0; l < d->n_layers; ++l) {
+        size_t w = wn_layer_bwd_workspace_floats(B, T, d->Cr, d->cd[l], d->fw);
+        if (w > lw) lw = w;
+    }
+    if (lw < n * 2 * maxcd) lw = n * 2 * maxcd;
+    tot += lw;
     tot += 2 * n * d->Cr;           // ping-pong gradient of the residual stream
     return tot * sizeof(float);
 }
@@ -84,7 +90,12 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
     size_t zoff = 0;
     for (int l = 0; l < L; ++l) { off[l] = zoff; zp[l] = z + zoff; dzp[l] = ws + zoff; zoff += n * d->cd[l]; if (d->cd[l] > maxcd) maxcd = d->cd[l]; }
     float* dab = ws + zoff;
-    float* gbuf[2] = {dab + n * 2 * maxcd, dab + n * 2 * maxcd + n * d->Cr};
+    size_t lw = n * 2 * maxcd;
+    for (int l = 0; l < L; ++l) {
+        size_t w = wn_layer_bwd_workspace_floats(B, T, d->Cr, d->cd[l], d->fw);
+        if (w > lw) lw = w;
+    }
+    float* gbuf[2] = {dab + lw, dab + lw + n * d->Cr};
     const int Tw = T - t_off;
     if (dskip) {
         rc = wn_skip_sum_bwd_dz(L, d->Ws, d->cd, dskip, dzp.data(), B, T, t_off, Tw, d->Cs, stream);

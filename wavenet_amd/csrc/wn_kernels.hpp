@@ -47,6 +47,7 @@ int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float
 int mfma_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
                    const float* Wp, const float* dout, const float* dzs, float* dx, float* dWf, float* dWg,
                    float* dWp, float* dab, int B, int T, int d, int Z, hipStream_t s);
+size_t mfma_layer_bwd_extra_ws_floats();
 int generic_layer_bwd_biases(const float* dab, const float* dout, float* dbf, float* dbg, float* dbp, int B,
                              int T, int Cr, int Cd, int Z, hipStream_t s);
 
