@@ -204,17 +204,47 @@ def main():
             "frac_of_hbm_8TBps": nl * alg_bytes_layer / (stack_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "TFLOPs": nl * alg_flops_layer / (stack_ms * 1e-3) / 1e12,
         }
-        # dominant kernel of the stack forward: the deferred skip contraction or the layer kernel
-        skip_flops = 2.0 * Cs * Cd * nl * B_PER_GPU * T
-        layer_flops = 2.0 * (2 * 2 * Cr * Cd + Cd * Cr) * B_PER_GPU * T
-        if skip_ms >= layer_ms * nl:
-            kname, kflops, kms_ = "wn_skip_sum_fwd", skip_flops, skip_ms
+        # ---- roofline of the dominant unit of the TIMED REGION (the training step) -------------------
+        # Units = the library's per-op entry points; times are HIP-event means over the timed steps.
+        # Algorithmic bytes / flops are SURVEY.md section 8(d)'s per-sample-layer figures x the
+        # sample-layers one launch processes (B*T columns of one layer; or all layers for the
+        # skip contractions).  `traffic` = real HBM bytes per launch from the rocprofv3 PMC passes
+        # kept in profiles/ (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), null if absent.
+        n_col = B_PER_GPU * T
+        n_colw = B_PER_GPU * (T - iw)
+        es = 4
+        units = {
+            # name: (bound, algorithmic amount per launch, launches per step, kernels for PMC traffic)
+            "wn_layer_bwd": ("hbm", es * (3 * Cr + Cs + 2 * Cd) * n_col, nl,
+                             ["wn::k_layer_bwd_p1<true, true>", "wn::k_layer_bwd_p1", "wn::k_layer_bwd_p2", "wn::k_layer_bwd_reduce"]),
+            "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl, ["wn::k_layer_fwd_mfma32<true>"]),
+            "wn_skip_sum_fwd": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm<8, 0>"]),
+            "wn_skip_sum_bwd_dw": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_wgrad_mfma<8>"]),
+            "wn_skip_sum_bwd_dz": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm<8, 2>"]),
+        }
+        dom = max(units, key=lambda k: per_step.get(k, 0.0))
+        bound, amount, launches, knames = units[dom]
+        launch_ms = per_step[dom] / launches
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
+        if os.path.exists(tf):
+            kk = json.load(open(tf))["kernels"]
+            got = [kk[k]["hbm_bytes_per_launch"] for k in knames if k in kk]
+            traffic = float(sum(got)) if got else None
+        if bound == "hbm":
+            ach = amount / (launch_ms * 1e-3) / 1e9
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": launch_ms,
+                               "algorithmic_bytes_per_launch": amount,
+                               "note": "algorithmic bytes per SURVEY 8(d) (include the per-layer skip traffic the deferred "
+                                       "skip sum avoids); traffic = measured HBM bytes per launch"}
         else:
-            kname, kflops, kms_ = "wn_layer_fwd", layer_flops, layer_ms
-        ach = kflops / (kms_ * 1e-3) / 1e12
-        out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TF,
-                           "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TF, "traffic": None,
-                           "launch_ms": kms_, "flops_per_launch": kflops}
+            ach = amount / (launch_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TF,
+                               "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TF, "traffic": traffic,
+                               "launch_ms": launch_ms, "flops_per_launch": amount}
+        out["mfma_units"] = {k: {"ms": per_step[k], "TFLOPs": units[k][1] / (per_step[k] * 1e-3) / 1e12}
+                             for k in units if units[k][0] == "mfma" and k in per_step}
         # ---- AR decode, config 4: 16k samples on one GPU, persistent per-layer state -----------
         if not args.no_decode:
             n = args.decode_samples

@@ -65,56 +65,74 @@ __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
     // fill mapping: thread -> (row i of the tile, 4-channel group c4)
     const int fi = tid & 31, fc4 = tid >> 5;
     const int fq = fc4 >> 1, fh = fc4 & 1;
+    const float ms = srow >= 0 ? 1.f : 0.f;
+    const long long srowc = srow >= 0 ? srow : 0;          // clamped: loads are unconditional, values masked
 
-    for (int src = 0; src < a.nsrc; ++src) {
-        const float* __restrict__ Wb = a.W[MODE == 1 ? prob : src];
-        const int wsm = a.wsm[MODE == 1 ? prob : src];
+    if (!MP) {
+        for (int src = 0; src < a.nsrc; ++src)
+            if (a.bias[src]) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][r] += a.bias[src][m0 + mt * 32 + cg_ch(r, h)];
+            }
+    }
+
+    // Software pipeline over the (source, 32-channel chunk) sequence: the global loads of chunk c+1 (the W
+    // slice for LDS and this wave's X columns) are issued BEFORE the MFMAs of chunk c and land behind them.
+    float4 wr[MT], xr[4];
+    auto issue = [&](int src, int k0) {
         const float* __restrict__ Xb = a.X[src];
         const int K = a.K[src];
-        if (a.bias[src] && !MP) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][r] += a.bias[src][m0 + mt * 32 + cg_ch(r, h)];
-        }
-        for (int k0 = 0; k0 < K; k0 += 32) {
-            __syncthreads();
-#pragma unroll
-            for (int it = 0; it < MT; ++it) {
-                const float* wp = Wb + (long long)(m0 + it * 32 + fi) * wsm + (long long)(k0 + 4 * fc4) * a.wsk;
-                if (MODE == 2) {
-                    const int pi = prob + it < a.nprob ? prob + it : a.nprob - 1;
-                    wp = a.W[pi] + (long long)fi * a.wsm[pi] + (long long)(k0 + 4 * fc4) * a.wsk;
-                }
-                float4 v;
-                if (a.wsk == 1) {
-                    v = *reinterpret_cast<const float4*>(wp);
-                } else {
-                    v.x = wp[0]; v.y = wp[a.wsk]; v.z = wp[2 * (long long)a.wsk]; v.w = wp[3 * (long long)a.wsk];
-                }
-                *reinterpret_cast<float4*>(&Alds[(((it * 4 + fq) * 64) + fi + 32 * fh) * 4]) = v;
+        for (int it = 0; it < MT; ++it) {
+            const float* wp;
+            if (MODE == 2) {
+                const int pi = prob + it < a.nprob ? prob + it : a.nprob - 1;
+                wp = a.W[pi] + (long long)fi * a.wsm[pi] + (long long)(k0 + 4 * fc4) * a.wsk;
+            } else {
+                const int wi = MODE == 1 ? prob : src;
+                wp = a.W[wi] + (long long)(m0 + it * 32 + fi) * a.wsm[wi] + (long long)(k0 + 4 * fc4) * a.wsk;
             }
-            float xb[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {      // unconditional load from a clamped row, masked afterwards
-                const float4 v = *reinterpret_cast<const float4*>(Xb + (srow >= 0 ? srow : 0) * K + k0 + 8 * q + 4 * h);
-                const float ms = srow >= 0 ? 1.f : 0.f;
-                xb[4 * q + 0] = act_apply(v.x, a.act) * ms; xb[4 * q + 1] = act_apply(v.y, a.act) * ms;
-                xb[4 * q + 2] = act_apply(v.z, a.act) * ms; xb[4 * q + 3] = act_apply(v.w, a.act) * ms;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    float4 a4 = *reinterpret_cast<const float4*>(&Alds[((mt * 4 + q) * 64 + lane) * 4]);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, xb[4 * q + 0], acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, xb[4 * q + 1], acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, xb[4 * q + 2], acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, xb[4 * q + 3], acc[mt], 0, 0, 0);
-                }
+            if (a.wsk == 1) {
+                wr[it] = *reinterpret_cast<const float4*>(wp);
+            } else {
+                wr[it].x = wp[0]; wr[it].y = wp[a.wsk]; wr[it].z = wp[2 * (long long)a.wsk]; wr[it].w = wp[3 * (long long)a.wsk];
             }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xr[q] = *reinterpret_cast<const float4*>(Xb + srowc * K + k0 + 8 * q + 4 * h);
+    };
+    int src = 0, k0 = 0;
+    issue(0, 0);
+    while (true) {
+        __syncthreads();                                     // the previous chunk's MFMAs are done with Alds
+#pragma unroll
+        for (int it = 0; it < MT; ++it)
+            *reinterpret_cast<float4*>(&Alds[(((it * 4 + fq) * 64) + fi + 32 * fh) * 4]) = wr[it];
+        float xb[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xb[4 * q + 0] = act_apply(xr[q].x, a.act) * ms; xb[4 * q + 1] = act_apply(xr[q].y, a.act) * ms;
+            xb[4 * q + 2] = act_apply(xr[q].z, a.act) * ms; xb[4 * q + 3] = act_apply(xr[q].w, a.act) * ms;
+        }
+        __syncthreads();
+        k0 += 32;
+        if (k0 >= a.K[src]) { k0 = 0; ++src; }
+        const bool more = src < a.nsrc;
+        if (more) issue(src, k0);                            // in flight during the MFMAs below
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float4 a4 = *reinterpret_cast<const float4*>(&Alds[((mt * 4 + q) * 64 + lane) * 4]);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, xb[4 * q + 0], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, xb[4 * q + 1], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, xb[4 * q + 2], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, xb[4 * q + 3], acc[mt], 0, 0, 0);
+            }
+        }
+        if (!more) break;
     }
     if (!nvalid) return;
     float* __restrict__ orow = a.out[MODE == 2 ? 0 : prob] + n * a.ldo + m0 + 4 * h;
@@ -285,17 +303,20 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WGArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
-        __syncthreads();
+    // software pipeline over 32-row chunks: the loads of chunk c+1 are issued before the MFMAs of chunk c
+    float4 ar[MT];
+    float br[16];
+    auto issue = [&](int r0) {
 #pragma unroll
         for (int it = 0; it < MT; ++it) {
             const int idx = it * 256 + tid;                 // float4 index inside the [32][MT*32] chunk
             const int row = idx / (MT * 8), c4 = idx - row * (MT * 8);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r0 + row < r_end) v = *reinterpret_cast<const float4*>(Ab + (long long)(r0 + row) * a.lda + 4 * c4);
-            *reinterpret_cast<float4*>(&Alds[row * (MT * 32) + 4 * c4]) = v;
+            const int rr = r0 + row < r_end ? r0 + row : r_end - 1;              // clamped row, masked below
+            float4 v = *reinterpret_cast<const float4*>(Ab + (long long)rr * a.lda + 4 * c4);
+            const float m = r0 + row < r_end ? 1.f : 0.f;
+            v.x *= m; v.y *= m; v.z *= m; v.w *= m;
+            ar[it] = v;
         }
-        float bv[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int r = r0 + 2 * s + h;
@@ -305,9 +326,23 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WGArgs a) {
             if (rc + a.off < 0) rc = -a.off;
             if (rc + a.off >= a.rows_B_per_b) rc = a.rows_B_per_b - 1 - a.off;
             const float v = active ? act_apply(Bb[(long long)rc * a.ldb], a.act) : 0.f;
-            bv[s] = ok ? v : 0.f;
+            br[s] = ok ? v : 0.f;
         }
+    };
+    if (r_begin < r_end) issue(r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
         __syncthreads();
+#pragma unroll
+        for (int it = 0; it < MT; ++it) {
+            const int idx = it * 256 + tid;
+            const int row = idx / (MT * 8), c4 = idx - row * (MT * 8);
+            *reinterpret_cast<float4*>(&Alds[row * (MT * 32) + 4 * c4]) = ar[it];
+        }
+        float bv[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) bv[s] = br[s];
+        __syncthreads();
+        if (r0 + 32 < r_end) issue(r0 + 32);                 // in flight during the MFMAs below
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
 #pragma unroll

@@ -25,7 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int ch_of(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
 
-template <bool SAVE_FG>
+template <bool SAVE_FG, bool HAS_BIAS>
 __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
     const float* __restrict__ x, const float* __restrict__ Wf, const float* __restrict__ bf,
     const float* __restrict__ Wg, const float* __restrict__ bg, const float* __restrict__ Wp,
@@ -53,29 +53,19 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
         float4 p4 = *reinterpret_cast<const float4*>(Wp + j * 32 + 8 * q + 4 * h);
         wp[4 * q + 0] = p4.x; wp[4 * q + 1] = p4.y; wp[4 * q + 2] = p4.z; wp[4 * q + 3] = p4.w;
     }
-    // biases in accumulator layout: register r of lane (.,h) is channel ch(r,h)
-    f32x16 bias_f, bias_g, bias_p;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int c = ch_of(r, h);
-        bias_f[r] = bf ? bf[c] : 0.f;
-        bias_g[r] = bg ? bg[c] : 0.f;
-        bias_p[r] = bp ? bp[c] : 0.f;
-    }
+    // biases (off by default in the reference, wavenet.py:116-117) are re-read per tile in accumulator
+    // layout -- register r of lane (.,h) is channel ch(r,h) -- instead of occupying 48 registers
 
-    for (int tile = wave; tile < ntiles; tile += nwaves) {
+    // x[t] and x[t-d] of a tile: unconditional loads from clamped rows, masked afterwards (a "cond ? load : 0"
+    // makes hipcc branch around every load and drain vmcnt per element)
+    auto load_tile = [&](int tile, float (&xc)[16], float (&xo)[16]) {
         const int b = tile / tiles_per_b;
         const int t = (tile - b * tiles_per_b) * 32 + j;
         const bool valid = t < T;
-        const bool has_old = valid && (t - d) >= 0;
-        const long long row = ((long long)b * T + t) * 32 + 4 * h;
-        // loads are unconditional on clamped rows and masked afterwards: a "cond ? load : 0" makes hipcc
-        // branch around every load and drain vmcnt per element
         const int tc = valid ? t : T - 1;
         const long long rowc = ((long long)b * T + tc) * 32 + 4 * h;
         const long long rowo = ((long long)b * T + (tc - d >= 0 ? tc - d : 0)) * 32 + 4 * h;
-        const float mc = valid ? 1.f : 0.f, mo = has_old ? 1.f : 0.f;
-        float xc[16], xo[16];
+        const float mc = valid ? 1.f : 0.f, mo = (valid && t - d >= 0) ? 1.f : 0.f;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 v = *reinterpret_cast<const float4*>(x + rowc + 8 * q);
@@ -83,7 +73,24 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
             xc[4 * q + 0] = v.x * mc; xc[4 * q + 1] = v.y * mc; xc[4 * q + 2] = v.z * mc; xc[4 * q + 3] = v.w * mc;
             xo[4 * q + 0] = o.x * mo; xo[4 * q + 1] = o.y * mo; xo[4 * q + 2] = o.z * mo; xo[4 * q + 3] = o.w * mo;
         }
-        f32x16 aa = bias_f, ag = bias_g;
+    };
+
+    float xc[16], xo[16], xcn[16], xon[16];
+    if (wave < ntiles) load_tile(wave, xc, xo);
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int b = tile / tiles_per_b;
+        const int t = (tile - b * tiles_per_b) * 32 + j;
+        const bool valid = t < T;
+        const long long row = ((long long)b * T + t) * 32 + 4 * h;
+        // the next tile's columns are fetched while this tile computes
+        const bool more = tile + nwaves < ntiles;
+        if (more) load_tile(tile + nwaves, xcn, xon);
+        f32x16 aa, ag;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            aa[r] = (HAS_BIAS && bf) ? bf[ch_of(r, h)] : 0.f;
+            ag[r] = (HAS_BIAS && bg) ? bg[ch_of(r, h)] : 0.f;
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             aa = __builtin_amdgcn_mfma_f32_32x32x2f32(wf0[s], xo[s], aa, 0, 0, 0);
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
         }
         f32x16 ao;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ao[r] = xc[r] + bias_p[r];
+        for (int r = 0; r < 16; ++r) ao[r] = xc[r] + ((HAS_BIAS && bp) ? bp[ch_of(r, h)] : 0.f);
 #pragma unroll
         for (int s = 0; s < 16; ++s) ao = __builtin_amdgcn_mfma_f32_32x32x2f32(wp[s], zz[s], ao, 0, 0, 0);
         if (valid) {
@@ -121,6 +128,10 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
                 }
             }
         }
+        if (more) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { xc[r] = xcn[r]; xo[r] = xon[r]; }
+        }
     }
 }
 
@@ -135,12 +146,15 @@ int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float
     const int ntiles = (int)nt;
     int blocks = (ntiles + 3) / 4;
     if (blocks > 512) blocks = 512;          // 256 CUs x 2 resident workgroups; waves stride over tiles
-    if (fs)
-        hipLaunchKernelGGL(k_layer_fwd_mfma32<true>, dim3(blocks), dim3(256), 0, s, x, Wf, bf, Wg, bg, Wp, bp, out,
-                           z, fs, gs, B, T, d, Z, tiles_per_b, ntiles);
-    else
-        hipLaunchKernelGGL(k_layer_fwd_mfma32<false>, dim3(blocks), dim3(256), 0, s, x, Wf, bf, Wg, bg, Wp, bp,
-                           out, z, fs, gs, B, T, d, Z, tiles_per_b, ntiles);
+    const bool hb = bf || bg || bp;
+#define FWD_LAUNCH(SAVE, BIAS)                                                                               \
+    hipLaunchKernelGGL((k_layer_fwd_mfma32<SAVE, BIAS>), dim3(blocks), dim3(256), 0, s, x, Wf, bf, Wg, bg, Wp, bp, \
+                       out, z, fs, gs, B, T, d, Z, tiles_per_b, ntiles)
+    if (fs && hb) FWD_LAUNCH(true, true);
+    else if (fs) FWD_LAUNCH(true, false);
+    else if (hb) FWD_LAUNCH(false, true);
+    else FWD_LAUNCH(false, false);
+#undef FWD_LAUNCH
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

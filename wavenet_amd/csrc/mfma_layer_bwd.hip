@@ -95,37 +95,32 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p1(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // contraction over the tile's 32 time columns: step s covers columns 2s and 2s+1.  Two halves
-        // of 8 steps; each half first issues ALL its loads (straight-line code, no branch in between),
-        // then runs its MFMAs, so the L2 round trips overlap instead of queueing one behind the other.
+        // contraction over the tile's 32 time columns: step s covers columns 2s and 2s+1.  ALL operand
+        // loads are issued first (straight-line code, no branch in between), then the MFMAs run, so
+        // the L2 round trips overlap instead of queueing one behind the other.
+        float bxc[16], bxo[16], ado[16], bfz[16], bgz[16];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float bxc[8], bxo[8], ado[8], bfz[8], bgz[8];
+        for (int u = 0; u < 16; ++u) {                                        // all 80 (32 without dout) loads in flight
+            const int tt = t0 + 2 * u + h;
+            const int ttc = tt < T ? tt : T - 1;                              // clamped rows, masked values
+            const long long r0 = ((long long)b * T + ttc) * 32 + j;
+            const long long r1 = ((long long)b * T + (ttc - d >= 0 ? ttc - d : 0)) * 32 + j;
+            bxc[u] = x[r0];
+            bxo[u] = x[r1];
+            if (HAS_DO) { ado[u] = dout[r0]; bfz[u] = f[r0]; bgz[u] = g[r0]; }
+        }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int tt = t0 + 2 * (8 * half + u) + h;
-                const bool tv = tt < T;
-                const int ttc = tv ? tt : T - 1;                              // clamped rows, masked values
-                const long long r0 = ((long long)b * T + ttc) * 32 + j;
-                const long long r1 = ((long long)b * T + (ttc - d >= 0 ? ttc - d : 0)) * 32 + j;
-                bxc[u] = x[r0];
-                bxo[u] = x[r1];
-                if (HAS_DO) { ado[u] = dout[r0]; bfz[u] = f[r0]; bgz[u] = g[r0]; }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int s = 8 * half + u;
-                const int tt = t0 + 2 * s + h;
-                const float mv = tt < T ? 1.f : 0.f, mo = (tt < T && tt - d >= 0) ? 1.f : 0.f;
-                const float a_da = lda[(2 * s + h) * kPad + j];
-                const float a_dg = ldg[(2 * s + h) * kPad + j];
-                const float b_xc = bxc[u] * mv, b_xo = bxo[u] * mo;
-                aWf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xc, aWf1, 0, 0, 0);
-                aWf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xo, aWf0, 0, 0, 0);
-                aWg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xc, aWg1, 0, 0, 0);
-                aWg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xo, aWg0, 0, 0, 0);
-                if (HAS_DO) aWp = __builtin_amdgcn_mfma_f32_32x32x2f32(ado[u] * mv, bfz[u] * bgz[u], aWp, 0, 0, 0);
-            }
+        for (int s = 0; s < 16; ++s) {
+            const int tt = t0 + 2 * s + h;
+            const float mv = tt < T ? 1.f : 0.f, mo = (tt < T && tt - d >= 0) ? 1.f : 0.f;
+            const float a_da = lda[(2 * s + h) * kPad + j];
+            const float a_dg = ldg[(2 * s + h) * kPad + j];
+            const float b_xc = bxc[s] * mv, b_xo = bxo[s] * mo;
+            aWf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xc, aWf1, 0, 0, 0);
+            aWf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xo, aWf0, 0, 0, 0);
+            aWg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xc, aWg1, 0, 0, 0);
+            aWg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xo, aWg0, 0, 0, 0);
+            if (HAS_DO) aWp = __builtin_amdgcn_mfma_f32_32x32x2f32(ado[s] * mv, bfz[s] * bgz[s], aWp, 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
     }
