@@ -178,7 +178,7 @@ def main():
                                "16 kHz, %d clips x 16384 samples per GPU, loss over last 12290 columns, "
                                "fwd + bwd + clip + Adam%s" % (B_PER_GPU, " + RCCL all-reduce" if world > 1 else ""),
                    "global_batch": world * B_PER_GPU, "seq_len": T, "parallelism": "dp%d" % world},
-        "loss": float(loss),
+        "loss": float(loss.detach()),
         "entry_point_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
     }
 

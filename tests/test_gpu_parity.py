@@ -536,3 +536,45 @@ def test_fast_decoder_specialised_kernel(blocks, layers):
         pr = net._forward_one_step(buf[-iw:].reshape(1, -1), as_numpy=True)[0, :, 0, -1]
         np.testing.assert_allclose(pr, tr[step], atol=2e-5)
         buf = np.append(buf, [want[step]]).astype(np.int32)
+
+
+def test_config5_topology_fp32_forward_and_grads():
+    """BASELINE config 5's widths (128 residual / 512 skip) run through the generic layer kernel and the fp32
+    MFMA channel GEMMs; parity in fp32 (the bf16 MFMA layer kernel for this shape is a later round)."""
+    over = dict(quantization_steps=256, causal_conv_channels=[128], residual_conv_channels=[128] * 3,
+                residual_num_blocks=2, softmax_conv_channels=[512, 256])
+    p, w, net = build(over, seed=9)
+    B, T, tw = 2, 160, 100
+    idx = np.random.RandomState(1).randint(0, 256, (B, T)).astype(np.int32)
+    tgt = np.random.RandomState(2).randint(0, 256, (B, tw)).astype(np.int32)
+    loss_ref, logits_ref, g = R.train_step_grads(p, w, idx, tgt)
+    c = net.forward_causal_block(idx)
+    _, s = net.forward_residual_block(c, t_off=T - tw)
+    lg = net.forward_softmax_block(s, apply_softmax=False)
+    loss = net.cross_entropy(lg, tgt)
+    net.zero_grads()
+    loss.backward()
+    np.testing.assert_allclose(to_np(lg), logits_ref, atol=ATOL)
+    assert abs(float(loss.detach()) - loss_ref) < 1e-4
+    for ln, kind, off, n, shape in net._spans:
+        want = g["%s/%s" % (ln.name, kind)]
+        got = to_np(net._grad_arena[off:off + n].view(shape))
+        assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-6) + 1e-7, (ln.name, kind)
+
+
+def test_c_abi_rejects_bad_arguments_without_touching_memory():
+    lib = _lib.lib()
+    x = torch.zeros((1, 8, 32), device="cuda")
+    W = torch.zeros((32, 32, 2), device="cuda")
+    Wp = torch.zeros((32, 32), device="cuda")
+    out = torch.empty_like(x)
+    z = torch.empty_like(x)
+    # out aliasing x, negative Z, f without g, non-positive sizes: all refused with a message
+    assert lib.wn_layer_fwd(ptr(x), ptr(W), None, ptr(W), None, ptr(Wp), None, ptr(x), ptr(z), None, None, 1, 8, 32, 32, 2, 1, 0, None) == -1
+    assert b"alias" in lib.wn_last_error()
+    assert lib.wn_layer_fwd(ptr(x), ptr(W), None, ptr(W), None, ptr(Wp), None, ptr(out), ptr(z), None, None, 1, 8, 32, 32, 2, 1, -3, None) == -1
+    assert lib.wn_layer_fwd(ptr(x), ptr(W), None, ptr(W), None, ptr(Wp), None, ptr(out), ptr(z), ptr(z), None, 1, 8, 32, 32, 2, 1, 0, None) == -1
+    assert lib.wn_layer_fwd(ptr(x), ptr(W), None, ptr(W), None, ptr(Wp), None, ptr(out), ptr(z), None, None, 0, 8, 32, 32, 2, 1, 0, None) == -1
+    assert lib.wn_skip_sum_fwd(1, None, None, None, None, None, 1, 8, 0, 8, 32, 0, None) == -1
+    with pytest.raises(_lib.WaveNetHipError):
+        check(lib.wn_softmax_xent(None, None, None, None, 4, 4, None), "wn_softmax_xent")
