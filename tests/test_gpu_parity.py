@@ -578,3 +578,58 @@ def test_c_abi_rejects_bad_arguments_without_touching_memory():
     assert lib.wn_skip_sum_fwd(1, None, None, None, None, None, 1, 8, 0, 8, 32, 0, None) == -1
     with pytest.raises(_lib.WaveNetHipError):
         check(lib.wn_softmax_xent(None, None, None, None, 4, 4, None), "wn_softmax_xent")
+
+
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 2), (3, 5), (2, 33), (1, 513)])
+def test_tiny_and_ragged_windows_full_model(B, T):
+    """Edge cases: windows far shorter than the dilations (every old tap out of range, extra padding branch of
+    wavenet.py:315-317), one column, ragged tiles -- MFMA topology (32 ch) and generic topology (16 ch)."""
+    for over in (dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 10,
+                      residual_num_blocks=2, softmax_conv_channels=[256, 256]),
+                 dict(quantization_steps=64, causal_conv_channels=[16], residual_conv_channels=[16] * 6,
+                      residual_num_blocks=1, softmax_conv_channels=[32, 64])):
+        p, w, net = build(over, seed=T)
+        Q = p["quantization_steps"]
+        idx = np.random.RandomState(T).randint(0, Q, (B, T)).astype(np.int32)
+        ref = R.RefWaveNet(p, w)
+        with torch.no_grad():
+            want = ref.forward_one_step(R.onehot_t(idx, Q), apply_softmax=False).numpy()
+            got = net.forward_one_step(idx, apply_softmax=False)
+        np.testing.assert_allclose(to_np(got), want, atol=ATOL)
+    # and a training step on the last configuration with a one-column loss
+    tgt = np.random.RandomState(1).randint(0, Q, (B, 1)).astype(np.int32)
+    loss_ref, _, g = R.train_step_grads(p, w, idx, tgt)
+    c = net.forward_causal_block(idx)
+    _, s = net.forward_residual_block(c, t_off=T - 1)
+    loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt)
+    net.zero_grads()
+    loss.backward()
+    assert abs(float(loss.detach()) - loss_ref) < 1e-4
+    for ln, kind, off, n, shape in net._spans:
+        want = g["%s/%s" % (ln.name, kind)]
+        got = to_np(net._grad_arena[off:off + n].view(shape))
+        assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-6) + 1e-7, (ln.name, kind)
+
+
+def test_training_is_reproducible_enough_and_zero_grad_accumulates():
+    """Two identical steps from identical state give the same loss and (up to float-atomic ordering) the same
+    gradients; backward without zero_grads accumulates exactly twice."""
+    p, w, net = build(dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 4,
+                           residual_num_blocks=2, softmax_conv_channels=[256, 256]))
+    idx = np.random.RandomState(0).randint(0, 256, (2, 500)).astype(np.int32)
+    tgt = np.random.RandomState(1).randint(0, 256, (2, 400)).astype(np.int32)
+
+    def step(zero=True):
+        c = net.forward_causal_block(idx)
+        _, s = net.forward_residual_block(c, t_off=100)
+        loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt)
+        if zero:
+            net.zero_grads()
+        loss.backward()
+        return float(loss.detach()), net._grad_arena.clone()
+    l1, g1 = step()
+    l2, g2 = step()
+    assert abs(l1 - l2) < 1e-5            # the loss is summed with float atomics: a few ulp of run-to-run jitter
+    assert float((g1 - g2).abs().max()) <= 1e-5 * float(g1.abs().max())
+    _, g3 = step(zero=False)
+    assert float((g3 - 2 * g1).abs().max()) <= 2e-5 * float(g1.abs().max())
