@@ -129,12 +129,17 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if os.environ.get("WAVENET_BENCH_SHARE_GPU") == "1":      # test hook: several ranks on one device over gloo
+        local = 0
     torch.cuda.set_device(local)
     barrier = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("WAVENET_BENCH_SHARE_GPU") == "1":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
         barrier = dist.barrier
 
     p = Params(CFG2)

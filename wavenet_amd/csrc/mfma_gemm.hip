@@ -15,26 +15,11 @@
 // With that permutation a float4 of four consecutive channels lands in one 16-byte LDS slot, and
 // the accumulator layout equals the store layout (float4 stores along the channel axis).
 #include "wn_kernels.hpp"
+#include "mfma_gemm.hpp"
 
 namespace wn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct CGArgs {
-    const float* X[WN_MAX_SRC];      // per source
-    const float* W[WN_MAX_SRC];      // per source (multi-source) or per problem (multi-problem)
-    const float* bias[WN_MAX_SRC];   // per source, may be NULL
-    float* out[WN_MAX_SRC];          // per problem
-    int K[WN_MAX_SRC];               // per source; row stride of X_src is K
-    int wsm[WN_MAX_SRC];             // W row (m) stride per source / problem
-    int wsk;                         // W column (k) stride: 1 = row-major W[m][k], else transposed view
-    int nsrc, nprob, M, ldo;
-    long long N;                     // output rows
-    int rows_out_per_b, rows_src_per_b, off;   // src row = b*rows_src_per_b + (n % rows_out_per_b) + off
-    int act;                         // applied to X on load
-    const float* gate_x; int gate_act;         // out *= act'(gate_x[n][m])   (dx of a pre-activated conv)
-    int accumulate;
-};
 
 __device__ __forceinline__ int cg_ch(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
 
@@ -164,6 +149,10 @@ template <bool MP>
 static int launch_colgemm(CGArgs& a, int nprob, hipStream_t s) {
     const int M = a.M;
     a.nprob = nprob;
+    if (gemm_b3_enabled()) {
+        int rc = launch_colgemm_b3(a, MP ? (M == 32 ? 2 : 1) : 0, nprob, s);
+        if (rc != WN_ESHAPE) return rc;                 // WN_ESHAPE = shape not covered: use the exact-fp32 kernels
+    }
     if (MP && M == 32 && nprob > 1) {          // 32-row problems: 8 per workgroup, X streamed once per 8
         dim3 grid(cdiv(a.N, 128), cdiv(nprob, 8));
         hipLaunchKernelGGL((k_colgemm<8, 2>), grid, dim3(256), 0, s, a);

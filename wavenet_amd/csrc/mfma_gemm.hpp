@@ -1,0 +1,31 @@
+// Shared between the exact-fp32 channel GEMM (mfma_gemm.hip) and its bf16x3 split-product variant
+// (mfma_gemm_b3.hip).
+#pragma once
+#include "wn_kernels.hpp"
+
+namespace wn {
+
+struct CGArgs {
+    const float* X[WN_MAX_SRC];      // per source
+    const float* W[WN_MAX_SRC];      // per source (multi-source) or per problem (multi-problem)
+    const float* bias[WN_MAX_SRC];   // per source, may be NULL
+    float* out[WN_MAX_SRC];          // per problem
+    int K[WN_MAX_SRC];               // per source; row stride of X_src is K
+    int wsm[WN_MAX_SRC];             // W row (m) stride per source / problem
+    int wsk;                         // W column (k) stride: 1 = row-major W[m][k], else transposed view
+    int nsrc, nprob, M, ldo;
+    long long N;                     // output rows
+    int rows_out_per_b, rows_src_per_b, off;   // src row = b*rows_src_per_b + (n % rows_out_per_b) + off
+    int act;                         // applied to X on load
+    const float* gate_x; int gate_act;         // out *= act'(gate_x[n][m])   (dx of a pre-activated conv)
+    int accumulate;
+};
+
+
+// 1 unless WAVENET_HIP_GEMM=fp32: contractions use three-way bf16 splits (6 bf16 MFMAs per product term)
+bool gemm_b3_enabled();
+// mode 0: multi-source, one output; mode 2: nprob problems of 32 rows sharing X.  Returns WN_ESHAPE when
+// the shape is not covered (the caller then uses the exact-fp32 kernel).
+int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s);
+
+}  // namespace wn

@@ -1,0 +1,255 @@
+// bf16x3 variant of the channel GEMM (same contract as k_colgemm in mfma_gemm.hip).
+//
+// fp32-input MFMA runs at the fp32 vector rate (157 TF); bf16 MFMA runs 16x faster.  Every fp32 operand is
+// split into three bf16 parts  x = h + m + l  (h = bf16(x), m = bf16(x-h), l = bf16(x-h-m); |x-h-m-l| <=
+// 2^-27 |x|) and a product w*x is evaluated as the six terms of magnitude >= 2^-18:
+//        wh*xh + (wh*xm + wm*xh) + (wm*xm + wh*xl + wl*xh)
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms are
+// <= 3 * 2^-27 relative, i.e. below fp32 rounding (2^-24): the result is as accurate as the fp32 MFMA path
+// (the parity tests hold the same 1e-4 logit / 1e-4 relative-gradient bars) at 16/6 = 2.7x its matrix rate.
+//
+// The weights are split ONCE per launch by k_split_w into an image that is already in MFMA A-operand order
+// (tile = 32 rows x 32 k x {h,m,l} = 6 KB), so the per-chunk LDS fill is a plain copy done by LDS-DMA
+// (global_load_lds, no staging registers) into a double buffer: the copy of chunk c+1 lands while chunk c
+// computes.  X columns are split in registers right after their (prefetched) float4 loads.
+#include <map>
+#include <mutex>
+
+#include "mfma_gemm.hpp"
+
+namespace wn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int kTileElems = 2 * 3 * 64 * 8;          // bf16 elements of one tile image: [ks][comp][lane][8]
+static constexpr int kTileBytes = kTileElems * 2;          // 6144
+
+bool gemm_b3_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("WAVENET_HIP_GEMM");
+        const char* g = getenv("WAVENET_HIP_FORCE_GENERIC");
+        v = ((e && strcmp(e, "fp32") == 0) || (g && g[0] == '1')) ? 0 : 1;
+    }
+    return v == 1;
+}
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+// ---- weight image: tile (chunk c, m-tile t) at img + (c*mtiles + t)*kTileElems -----------------------------
+//   element [ks][comp][lane = i + 32*hh][j]  =  comp-part of  W_tile[i][16*ks + 8*hh + j]
+// mode 0: chunk c = (source, 32-wide k slice), m-tile t = rows 32t.. of that source's W[m][k]
+// mode 2: m-tile t = problem t (32 rows), chunk c = k slice of W[t]
+__global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __bf16* __restrict__ img) {
+    const int tile = blockIdx.x;
+    const int c = tile / mtiles, t = tile - c * mtiles;
+    const int i = threadIdx.x & 31, c4 = threadIdx.x >> 5;           // row, group of 4 consecutive k
+    const float* W;
+    int wsm, k0;
+    if (mode == 0) {
+        const int src = c / chunks_per_src;
+        k0 = (c - src * chunks_per_src) * 32;
+        W = a.W[src] + (long long)(t * 32) * a.wsm[src];
+        wsm = a.wsm[src];
+    } else {
+        k0 = c * 32;
+        W = a.W[t];
+        wsm = a.wsm[t];
+    }
+    const float* wp = W + (long long)i * wsm + (long long)(k0 + 4 * c4) * a.wsk;
+    float w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = wp[(long long)e * a.wsk];
+    bf16x4 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        __bf16 hh, mm, ll;
+        split3(w[e], hh, mm, ll);
+        h[e] = hh; m[e] = mm; l[e] = ll;
+    }
+    const int ks = c4 >> 2, hh = (c4 >> 1) & 1, jo = 4 * (c4 & 1);
+    __bf16* d = img + (long long)tile * kTileElems + (i + 32 * hh) * 8 + jo;
+    *reinterpret_cast<bf16x4*>(d + (ks * 3 + 0) * 512) = h;
+    *reinterpret_cast<bf16x4*>(d + (ks * 3 + 1) * 512) = m;
+    *reinterpret_cast<bf16x4*>(d + (ks * 3 + 2) * 512) = l;
+}
+
+__device__ __forceinline__ int b3_ch(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// MT m-tiles per workgroup (one per wave for the LDS-DMA fill: MT == 4 waves)
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* __restrict__ img, int mtiles,
+                                                       int nchunks, int chunks_per_src) {
+    constexpr int MT = 4;
+    __shared__ __attribute__((aligned(16))) char lds[2 * MT * kTileBytes];      // double-buffered tile images
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int t0 = blockIdx.y * MT;                        // first m-tile (mode 2: first problem) of this workgroup
+    const long long n = ((long long)blockIdx.x * 4 + wave) * 32 + j;
+    const bool nvalid = n < a.N;
+    long long srow = -1;
+    if (nvalid) {
+        long long b = n / a.rows_out_per_b;
+        int r = (int)(n - b * a.rows_out_per_b) + a.off;
+        if (r >= 0 && r < a.rows_src_per_b) srow = b * a.rows_src_per_b + r;
+    }
+    const float ms = srow >= 0 ? 1.f : 0.f;
+    const long long srowc = srow >= 0 ? srow : 0;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    if (MODE == 0) {
+        for (int src = 0; src < a.nsrc; ++src)
+            if (a.bias[src]) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    if (t0 + mt < mtiles) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mt][r] += a.bias[src][(t0 + mt) * 32 + b3_ch(r, h)];
+                    }
+            }
+    }
+
+    // this wave copies m-tile (t0 + wave) of a chunk: 6 KB = six 1 KB LDS-DMA pieces
+    const int my_tile = (t0 + wave < mtiles) ? t0 + wave : mtiles - 1;
+    auto dma_chunk = [&](int c, int buf) {
+        const char* src = reinterpret_cast<const char*>(img) + ((long long)c * mtiles + my_tile) * kTileBytes + lane * 16;
+        char* dst = lds + (buf * MT + wave) * kTileBytes;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            __builtin_amdgcn_global_load_lds(src + q * 1024, (__attribute__((address_space(3))) void*)(dst + q * 1024), 16,
+                                             0, 0);
+    };
+    float4 xr[4];
+    auto load_x = [&](int c) {
+        const int src = MODE == 0 ? c / chunks_per_src : 0;
+        const int k0 = (MODE == 0 ? c - src * chunks_per_src : c) * 32;
+        const float* __restrict__ Xb = a.X[src] + srowc * a.K[src] + k0 + 8 * h;
+        xr[0] = *reinterpret_cast<const float4*>(Xb);             // k-step 0: channels 8h .. 8h+7
+        xr[1] = *reinterpret_cast<const float4*>(Xb + 4);
+        xr[2] = *reinterpret_cast<const float4*>(Xb + 16);        // k-step 1: channels 16+8h .. 16+8h+7
+        xr[3] = *reinterpret_cast<const float4*>(Xb + 20);
+    };
+
+    dma_chunk(0, 0);
+    load_x(0);
+    for (int c = 0; c < nchunks; ++c) {
+        // split this chunk's X columns (the loads were issued one iteration ago)
+        bf16x8 xh[2], xm[2], xl[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float v[8] = {xr[2 * ks].x, xr[2 * ks].y, xr[2 * ks].z, xr[2 * ks].w,
+                                xr[2 * ks + 1].x, xr[2 * ks + 1].y, xr[2 * ks + 1].z, xr[2 * ks + 1].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 hh, mm, ll;
+                split3(act_apply(v[e], a.act) * ms, hh, mm, ll);
+                xh[ks][e] = hh; xm[ks][e] = mm; xl[ks][e] = ll;
+            }
+        }
+        __syncthreads();                 // vmcnt(0): chunk c's image has landed; every wave is done with chunk c-1
+        if (c + 1 < nchunks) {           // next chunk: image into the other buffer, X into registers
+            dma_chunk(c + 1, (c + 1) & 1);
+            load_x(c + 1);
+        }
+        const char* Ab = lds + ((c & 1) * MT) * kTileBytes + lane * 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const char* p = Ab + mt * kTileBytes + ks * 3 * 1024;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(p);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(p + 1024);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(p + 2048);
+                // smallest terms first
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xm[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xh[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xm[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[ks], acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    if (!nvalid) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (t0 + mt >= mtiles) break;
+        float* __restrict__ orow = (MODE == 2) ? a.out[t0 + mt] + n * a.ldo + 4 * h
+                                               : a.out[0] + n * a.ldo + (t0 + mt) * 32 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = make_float4(acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
+            float* p = orow + 8 * q;
+            if (MODE == 0 && a.gate_x) {
+                const float4 gx = *reinterpret_cast<const float4*>(a.gate_x + n * a.ldo + (t0 + mt) * 32 + 4 * h + 8 * q);
+                v.x *= act_grad(gx.x, a.gate_act); v.y *= act_grad(gx.y, a.gate_act);
+                v.z *= act_grad(gx.z, a.gate_act); v.w *= act_grad(gx.w, a.gate_act);
+            }
+            if (a.accumulate) {
+                const float4 o = *reinterpret_cast<const float4*>(p);
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4*>(p) = v;
+        }
+    }
+}
+
+// ---- per-stream scratch for the weight images (grown on first use, then reused: no allocation in steady state)
+struct Scratch { void* buf = nullptr; size_t bytes = 0; };
+static std::mutex g_mu;
+static std::map<hipStream_t, Scratch> g_scratch;
+static void* scratch_for(hipStream_t s, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Scratch& sc = g_scratch[s];
+    if (sc.bytes < bytes) {
+        if (sc.buf) (void)hipFree(sc.buf);
+        sc.buf = nullptr;
+        sc.bytes = 0;
+        size_t want = bytes < (4u << 20) ? (4u << 20) : bytes * 2;
+        if (hipMalloc(&sc.buf, want) != hipSuccess) { sc.buf = nullptr; return nullptr; }
+        sc.bytes = want;
+    }
+    return sc.buf;
+}
+
+int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
+    if (mode != 0 && mode != 2) return WN_ESHAPE;
+    int mtiles, nchunks, cps;
+    if (mode == 0) {
+        if (a.M % 32) return WN_ESHAPE;
+        for (int i = 0; i < a.nsrc; ++i)
+            if (a.K[i] != a.K[0] || a.K[i] % 32) return WN_ESHAPE;
+        mtiles = a.M / 32;
+        cps = a.K[0] / 32;
+        nchunks = a.nsrc * cps;
+    } else {
+        if (a.M != 32 || a.K[0] % 32) return WN_ESHAPE;
+        mtiles = nprob;
+        cps = a.K[0] / 32;
+        nchunks = cps;
+    }
+    const size_t bytes = (size_t)nchunks * mtiles * kTileBytes;
+    __bf16* img = reinterpret_cast<__bf16*>(scratch_for(s, bytes));
+    if (!img) { wn::set_error("colgemm_b3: cannot allocate %zu bytes of weight scratch", bytes); return WN_EHIP; }
+    hipLaunchKernelGGL(k_split_w, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img);
+    dim3 grid(cdiv(a.N, 128), cdiv(mtiles, 4));
+    if (mode == 0)
+        hipLaunchKernelGGL(k_colgemm_b3<0>, grid, dim3(256), 0, s, a, (const __bf16*)img, mtiles, nchunks, cps);
+    else
+        hipLaunchKernelGGL(k_colgemm_b3<2>, grid, dim3(256), 0, s, a, (const __bf16*)img, mtiles, nchunks, cps);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+}  // namespace wn
