@@ -263,15 +263,6 @@ int mfma_pointwise_bwd_dx(const float* x, const float* W, const float* dout, flo
 // =============================================================================================
 namespace wn {
 
-struct WGArgs {
-    const float* A; int lda;
-    const float* Bp[WN_MAX_SRC];
-    float* out[WN_MAX_SRC];
-    int nprob, ldb, ldo;
-    int nB, rows_A_per_b, rows_B_per_b, off;   // B row = b*rows_B_per_b + r + off for A row b*rows_A_per_b + r
-    int act;
-    int rows_per_wg, wgs_per_b;
-};
 
 template <int MT>
 __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WGArgs a) {
@@ -363,6 +354,11 @@ static int launch_wgrad_mfma(WGArgs& a, int M, hipStream_t s) {
     a.rows_per_wg = rows;
     a.wgs_per_b = cdiv(a.rows_A_per_b, rows);
     dim3 grid(a.nB * a.wgs_per_b, cdiv(a.nprob, 4), M / (mt * 32));
+    if (gemm_b3_enabled()) {          // bf16x3: at most 4 row tiles per workgroup (register budget), more groups in z
+        const int mt3 = mt > 4 ? 4 : mt;
+        grid.z = M / (mt3 * 32);
+        return launch_wgrad_b3(a, mt3, grid, s);
+    }
     switch (mt) {
         case 8: hipLaunchKernelGGL(k_wgrad_mfma<8>, grid, dim3(256), 0, s, a); break;
         case 4: hipLaunchKernelGGL(k_wgrad_mfma<4>, grid, dim3(256), 0, s, a); break;

@@ -22,10 +22,23 @@ struct CGArgs {
 };
 
 
+struct WGArgs {
+    const float* A; int lda;
+    const float* Bp[WN_MAX_SRC];
+    float* out[WN_MAX_SRC];
+    int nprob, ldb, ldo;
+    int nB, rows_A_per_b, rows_B_per_b, off;   // B row = b*rows_B_per_b + r + off for A row b*rows_A_per_b + r
+    int act;
+    int rows_per_wg, wgs_per_b;
+};
+
 // 1 unless WAVENET_HIP_GEMM=fp32: contractions use three-way bf16 splits (6 bf16 MFMAs per product term)
 bool gemm_b3_enabled();
 // mode 0: multi-source, one output; mode 2: nprob problems of 32 rows sharing X.  Returns WN_ESHAPE when
 // the shape is not covered (the caller then uses the exact-fp32 kernel).
 int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s);
+
+// bf16x3 form of k_wgrad_mfma (same grid / arguments)
+int launch_wgrad_b3(const WGArgs& a, int mt, dim3 grid, hipStream_t s);
 
 }  // namespace wn

@@ -252,4 +252,155 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     return WN_OK;
 }
 
+// =============================================================================================
+// bf16x3 weight gradient:  dW_p[m][k] += sum_n A[n][m] * act(B_p[row(n)][k])   (contraction over time rows)
+// MFMA K = time (16 rows per instruction), so both operands are needed "8 consecutive rows per lane":
+//   * A (shared by the 4 waves): every thread builds whole lane fragments -- 8 rows of one channel, eight
+//     coalesced dword loads -- splits them into h/m/l and stores each with ONE ds_write_b128 into the same
+//     A-operand image layout as above; raw loads of chunk c+1 are in flight during the MFMAs of chunk c;
+//   * B (one 32-channel tile per wave): eight dword loads per lane per k-step, split in registers.
+// =============================================================================================
+template <int MT>
+__global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[MT * kTileBytes];          // one 32-row chunk of A, split
+    constexpr int NF = MT / 2 > 0 ? MT / 2 : 1;             // A fragments per thread per chunk (MT*128 / 256)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int p = blockIdx.y * 4 + wv;
+    const bool active = p < a.nprob;
+    const int m0 = blockIdx.z * (MT * 32);
+    const int b = blockIdx.x / a.wgs_per_b;
+    const int r_begin = (blockIdx.x - b * a.wgs_per_b) * a.rows_per_wg;
+    const int r_end = min(a.rows_A_per_b, r_begin + a.rows_per_wg);
+    const float* __restrict__ Ab = a.A + ((long long)b * a.rows_A_per_b) * a.lda + m0;
+    const float* __restrict__ Bb = a.Bp[active ? p : 0] + ((long long)b * a.rows_B_per_b + a.off) * a.ldb + j;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    float ar[NF][8], br[2][8];
+    // per-thread fragment coordinates are chunk-invariant
+    int fm[NF], fg[NF];
+#pragma unroll
+    for (int it = 0; it < NF; ++it) {
+        const int f = it * 256 + tid;                        // fragment: channel m, row group g = 2*ks + hh
+        fm[it] = f % (MT * 32);
+        fg[it] = f / (MT * 32);
+    }
+    auto issue = [&](int r0) {
+        // whole chunk inside the slab and inside B's rows (every chunk but possibly the last): no clamps, no masks
+        const bool full = r0 + 32 <= r_end && r0 + a.off >= 0 && r0 + 31 + a.off < a.rows_B_per_b;
+        if (full) {
+#pragma unroll
+            for (int it = 0; it < NF; ++it) {
+                const float* ap = Ab + (long long)(r0 + 8 * (fg[it] & 3)) * a.lda + fm[it];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) ar[it][jj] = ap[(long long)jj * a.lda];
+            }
+            const float* bp = Bb + (long long)(r0 + 8 * h) * a.ldb;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    br[ks][jj] = active ? act_apply(bp[(long long)(16 * ks + jj) * a.ldb], a.act) : 0.f;
+            return;
+        }
+#pragma unroll
+        for (int it = 0; it < NF; ++it) {
+            const int m = fm[it], g = fg[it];
+            const bool fv = MT >= 2 || g < 4;                // MT == 1: only 128 fragments exist
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int r = r0 + 8 * (fv ? g : 0) + jj;
+                const int rc = r < r_end ? r : r_end - 1;    // clamped row, masked value
+                ar[it][jj] = Ab[(long long)rc * a.lda + m] * ((fv && r < r_end) ? 1.f : 0.f);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int r = r0 + 16 * ks + 8 * h + jj;
+                const int rb = r + a.off;
+                const bool ok = active && r < r_end && rb >= 0 && rb < a.rows_B_per_b;
+                int rc = r < r_end ? r : r_end - 1;
+                if (rc + a.off < 0) rc = -a.off;
+                if (rc + a.off >= a.rows_B_per_b) rc = a.rows_B_per_b - 1 - a.off;
+                br[ks][jj] = ok ? act_apply(Bb[(long long)rc * a.ldb], a.act) : 0.f;
+            }
+    };
+    if (r_begin < r_end) issue(r_begin);
+    for (int r0 = r_begin; r0 < r_end; r0 += 32) {
+        // split this chunk's operands (loads were issued one iteration ago)
+        bf16x8 ah[NF], am[NF], al[NF], bh[2], bm[2], bl[2];
+#pragma unroll
+        for (int it = 0; it < NF; ++it)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 x0, x1, x2;
+                split3(ar[it][e], x0, x1, x2);
+                ah[it][e] = x0; am[it][e] = x1; al[it][e] = x2;
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 x0, x1, x2;
+                split3(br[ks][e], x0, x1, x2);
+                bh[ks][e] = x0; bm[ks][e] = x1; bl[ks][e] = x2;
+            }
+        __syncthreads();                                     // the previous chunk's MFMAs are done with the image
+#pragma unroll
+        for (int it = 0; it < NF; ++it) {
+            const int f = it * 256 + tid;
+            const int m = f % (MT * 32), g = f / (MT * 32);
+            if (MT >= 2 || g < 4) {
+                char* d = lds + (m >> 5) * kTileBytes + ((g >> 1) * 3) * 1024 + ((m & 31) + 32 * (g & 1)) * 16;
+                *reinterpret_cast<bf16x8*>(d) = ah[it];
+                *reinterpret_cast<bf16x8*>(d + 1024) = am[it];
+                *reinterpret_cast<bf16x8*>(d + 2048) = al[it];
+            }
+        }
+        __syncthreads();
+        if (r0 + 32 < r_end) issue(r0 + 32);                 // in flight during the MFMAs below
+        const char* Al = lds + lane * 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const char* q = Al + mt * kTileBytes + ks * 3 * 1024;
+                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(q);
+                const bf16x8 xm = *reinterpret_cast<const bf16x8*>(q + 1024);
+                const bf16x8 xl = *reinterpret_cast<const bf16x8*>(q + 2048);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh[ks], acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    if (!active) return;
+    float* __restrict__ o = a.out[p];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            atomicAdd(o + (long long)(m0 + mt * 32 + b3_ch(r, h)) * a.ldo + j, acc[mt][r]);
+}
+
+int launch_wgrad_b3(const WGArgs& a, int mt, dim3 grid, hipStream_t s) {
+    switch (mt) {
+        case 8: hipLaunchKernelGGL(k_wgrad_b3<8>, grid, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(k_wgrad_b3<4>, grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(k_wgrad_b3<2>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(k_wgrad_b3<1>, grid, dim3(256), 0, s, a); break;
+    }
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
 }  // namespace wn
