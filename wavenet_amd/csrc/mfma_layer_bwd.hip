@@ -160,6 +160,194 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p1(
     }
 }
 
+// =============================================================================================
+// Chained backward (no pass 2, no (da,dg) scratch).  The gradient of the residual stream is kept in the
+// split form    dout_l[t] = V[t] + U[t + dU]    where the layer above (dilation dU) wrote
+//     V = dout + [Wf1;Wg1]^T dab      (tap 1 reads x[t])        U = [Wf0;Wg0]^T dab    (tap 0 reads x[t-d])
+// so this kernel reads its dout on the fly from two tensors, does everything k_layer_bwd_p1 does, and
+// additionally runs the two transposed-weight GEMMs on the (da,dg) it still holds in registers (their
+// accumulator layout IS the MFMA B-operand layout) to emit its own V and U.  The transposed weights sit in
+// LDS in A-operand order (shared by the workgroup's waves).  Per layer this removes the pass-2 kernel,
+// the 256 B/column scratch write and its two re-reads.
+// =============================================================================================
+template <bool HAS_DO, bool HAS_U, bool HAS_DZ>
+__global__ __launch_bounds__(256, 2) void k_layer_bwd_chain(
+    const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
+    const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
+    const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, const float* __restrict__ dzs,
+    float* __restrict__ Vout, float* __restrict__ Uout, float* __restrict__ part, int B, int T, int d, int Z,
+    int tiles_per_b, int ntiles) {
+    __shared__ __attribute__((aligned(16))) float lds[kWaves * 2 * 32 * kPad + 5 * 16 * 64 + 4 * 16 * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    float* lda = lds + wv * (2 * 32 * kPad);
+    float* ldg = lda + 32 * kPad;
+    float* red = lds + kWaves * 2 * 32 * kPad;
+    float* wT = red + 5 * 16 * 64;                   // [mat f1,g1,f0,g0][s][lane]: W[cd=ch(s,h)][cr=lane&31][k]
+    const int wave = blockIdx.x * kWaves + wv;
+    const int nwaves = gridDim.x * kWaves;
+    for (int e = threadIdx.x; e < 4 * 16 * 64; e += 256) {
+        const int mat = e >> 10, s2 = (e >> 6) & 15, ln = e & 63;
+        const float* W = (mat & 1) ? Wg : Wf;
+        wT[e] = W[(bch(s2, ln >> 5) * 32 + (ln & 31)) * 2 + (mat < 2 ? 1 : 0)];
+    }
+    float wpT[16];                                   // A operand of dz: lane (i=cd,h), step s: Wp[ch(s,h)][i]
+#pragma unroll
+    for (int s = 0; s < 16; ++s) wpT[s] = Wp[bch(s, h) * 32 + j];
+    __syncthreads();
+
+    f32x16 aWf0, aWf1, aWg0, aWg1, aWp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aWf0[r] = 0.f; aWf1[r] = 0.f; aWg0[r] = 0.f; aWg1[r] = 0.f; aWp[r] = 0.f; }
+
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int b = tile / tiles_per_b;
+        const int t0 = (tile - b * tiles_per_b) * 32;
+        const int t = t0 + j;
+        const bool valid = t < T;
+        const int tc = valid ? t : T - 1;                                         // clamped rows, masked values
+        const long long rowc = ((long long)b * T + tc) * 32 + 4 * h;
+        const long long rowu = ((long long)b * T + (tc + dU < T ? tc + dU : T - 1)) * 32 + 4 * h;
+        const float mu = (HAS_U && valid && t + dU < T) ? 1.f : 0.f;
+        f32x16 acc;
+        float ff[16], gg[16], dob[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 z4 = make_float4(0, 0, 0, 0), o4 = z4;
+            const float4 f4 = *reinterpret_cast<const float4*>(f + rowc + 8 * q);
+            const float4 g4 = *reinterpret_cast<const float4*>(g + rowc + 8 * q);
+            if (HAS_DZ) z4 = *reinterpret_cast<const float4*>(dzs + rowc + 8 * q);
+            if (HAS_DO) o4 = *reinterpret_cast<const float4*>(Vin + rowc + 8 * q);
+            if (HAS_U) {
+                const float4 u4 = *reinterpret_cast<const float4*>(Uin + rowu + 8 * q);
+                o4.x += u4.x * mu; o4.y += u4.y * mu; o4.z += u4.z * mu; o4.w += u4.w * mu;
+            }
+            acc[4 * q] = z4.x; acc[4 * q + 1] = z4.y; acc[4 * q + 2] = z4.z; acc[4 * q + 3] = z4.w;
+            ff[4 * q] = f4.x; ff[4 * q + 1] = f4.y; ff[4 * q + 2] = f4.z; ff[4 * q + 3] = f4.w;
+            gg[4 * q] = g4.x; gg[4 * q + 1] = g4.y; gg[4 * q + 2] = g4.z; gg[4 * q + 3] = g4.w;
+            dob[4 * q] = o4.x; dob[4 * q + 1] = o4.y; dob[4 * q + 2] = o4.z; dob[4 * q + 3] = o4.w;
+        }
+        if (HAS_DO || HAS_U) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wpT[s], dob[s], acc, 0, 0, 0);
+        }
+        const bool live = valid && t >= Z;
+        float da[16], dg[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float dz = live ? acc[r] : 0.f;
+            da[r] = dz * gg[r] * (1.f - ff[r] * ff[r]);
+            dg[r] = dz * ff[r] * gg[r] * (1.f - gg[r]);
+        }
+        // V = dout + [Wf1;Wg1]^T dab,  U = [Wf0;Wg0]^T dab: (da,dg) registers are the B operands as they stand
+        {
+            f32x16 v1, u0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { v1[r] = dob[r]; u0[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wT[(0 * 16 + s) * 64 + lane], da[s], v1, 0, 0, 0);
+                u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wT[(2 * 16 + s) * 64 + lane], da[s], u0, 0, 0, 0);
+                v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wT[(1 * 16 + s) * 64 + lane], dg[s], v1, 0, 0, 0);
+                u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wT[(3 * 16 + s) * 64 + lane], dg[s], u0, 0, 0, 0);
+            }
+            if (valid) {
+                const long long row = ((long long)b * T + t) * 32 + 4 * h;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    *reinterpret_cast<float4*>(Vout + row + 8 * q) = make_float4(v1[4 * q], v1[4 * q + 1], v1[4 * q + 2], v1[4 * q + 3]);
+                    *reinterpret_cast<float4*>(Uout + row + 8 * q) = make_float4(u0[4 * q], u0[4 * q + 1], u0[4 * q + 2], u0[4 * q + 3]);
+                }
+            }
+        }
+        // transposed LDS patches of (da,dg) for the weight gradients
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *reinterpret_cast<float4*>(lda + j * kPad + 8 * q + 4 * h) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
+            *reinterpret_cast<float4*>(ldg + j * kPad + 8 * q + 4 * h) = make_float4(dg[4 * q], dg[4 * q + 1], dg[4 * q + 2], dg[4 * q + 3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float bxc[16], bxo[16], ado[16], adu[16], bfz[16], bgz[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {                                        // all operand loads in flight first
+            const int tt = t0 + 2 * u + h;
+            const int ttc = tt < T ? tt : T - 1;
+            const long long r0 = ((long long)b * T + ttc) * 32 + j;
+            const long long r1 = ((long long)b * T + (ttc - d >= 0 ? ttc - d : 0)) * 32 + j;
+            bxc[u] = x[r0];
+            bxo[u] = x[r1];
+            if (HAS_DO || HAS_U) { bfz[u] = f[r0]; bgz[u] = g[r0]; }
+            if (HAS_DO) ado[u] = Vin[r0];
+            if (HAS_U) adu[u] = Uin[((long long)b * T + (ttc + dU < T ? ttc + dU : T - 1)) * 32 + j];
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int tt = t0 + 2 * s + h;
+            const float mv = tt < T ? 1.f : 0.f, mo = (tt < T && tt - d >= 0) ? 1.f : 0.f;
+            const float a_da = lda[(2 * s + h) * kPad + j];
+            const float a_dg = ldg[(2 * s + h) * kPad + j];
+            const float b_xc = bxc[s] * mv, b_xo = bxo[s] * mo;
+            aWf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xc, aWf1, 0, 0, 0);
+            aWf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xo, aWf0, 0, 0, 0);
+            aWg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xc, aWg1, 0, 0, 0);
+            aWg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xo, aWg0, 0, 0, 0);
+            if (HAS_DO || HAS_U) {
+                float a_do = HAS_DO ? ado[s] * mv : 0.f;
+                if (HAS_U) a_do += adu[s] * ((tt < T && tt + dU < T) ? 1.f : 0.f);
+                aWp = __builtin_amdgcn_mfma_f32_32x32x2f32(a_do, bfz[s] * bgz[s], aWp, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    for (int w = 1; w < kWaves; ++w) {
+        __syncthreads();
+        if (wv == w) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                red[(0 * 16 + r) * 64 + lane] = aWf0[r]; red[(1 * 16 + r) * 64 + lane] = aWf1[r];
+                red[(2 * 16 + r) * 64 + lane] = aWg0[r]; red[(3 * 16 + r) * 64 + lane] = aWg1[r];
+                red[(4 * 16 + r) * 64 + lane] = aWp[r];
+            }
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                aWf0[r] += red[(0 * 16 + r) * 64 + lane]; aWf1[r] += red[(1 * 16 + r) * 64 + lane];
+                aWg0[r] += red[(2 * 16 + r) * 64 + lane]; aWg1[r] += red[(3 * 16 + r) * 64 + lane];
+                aWp[r] += red[(4 * 16 + r) * 64 + lane];
+            }
+        }
+    }
+    if (wv == 0) {
+        float* __restrict__ o = part + (long long)blockIdx.x * kPartFloats + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o[(0 * 16 + r) * 64] = aWf0[r]; o[(1 * 16 + r) * 64] = aWf1[r];
+            o[(2 * 16 + r) * 64] = aWg0[r]; o[(3 * 16 + r) * 64] = aWg1[r];
+            o[(4 * 16 + r) * 64] = aWp[r];
+        }
+    }
+}
+
+// dx[t] = V[t] + U[t + dU]   (the split gradient of the stack input, materialised once at the bottom)
+__global__ void k_chain_combine(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ dx,
+                                int B, int T, int dU) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index
+    const long long n4 = (long long)B * T * 8;
+    if (i >= n4) return;
+    const long long col = i >> 3;
+    const int t = (int)(col % T);
+    float4 v = reinterpret_cast<const float4*>(V)[i];
+    if (t + dU < T) {
+        const float4 u = reinterpret_cast<const float4*>(U)[i + (long long)dU * 8];
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    reinterpret_cast<float4*>(dx)[i] = v;
+}
+
 // dW += sum over workgroups of the partial tiles.  Thread = one element of the five tiles; blockIdx.y
 // splits the workgroup range so that enough loads are in flight; kRedParts light atomics per address.
 static constexpr int kRedParts = 16;
@@ -273,5 +461,45 @@ int mfma_layer_bwd(const float* x, const float* f, const float* g, const float* 
 }
 
 size_t mfma_layer_bwd_extra_ws_floats() { return (size_t)kMaxBlocks * kPartFloats; }
+
+// One layer of the chained backward.  Vin/Uin (either may be NULL): dout[t] = Vin[t] + Uin[t + dU].
+int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
+                         const float* Wp, const float* Vin, const float* Uin, int dU, const float* dzs, float* Vout,
+                         float* Uout, float* dWf, float* dWg, float* dWp, float* part, int B, int T, int d, int Z,
+                         hipStream_t s) {
+    const int tiles_per_b = (T + 31) / 32;
+    const long long nt = (long long)B * tiles_per_b;
+    WN_CHECK_SHAPE(nt < (1ll << 31), "mfma_layer_bwd_chain: too many tiles");
+    WN_CHECK_ARG(Vin || Uin || dzs, "mfma_layer_bwd_chain: no incoming gradient");
+    const int ntiles = (int)nt;
+    int blocks = (ntiles + 3) / 4;
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+#define CH_LAUNCH(DO, UU, DZ)                                                                                      \
+    hipLaunchKernelGGL((k_layer_bwd_chain<DO, UU, DZ>), dim3(blocks), dim3(256), 0, s, x, f, g, Wp, Wf, Wg, Vin, Uin, dU, \
+                       dzs, Vout, Uout, part, B, T, d, Z, tiles_per_b, ntiles)
+    const int key = (Vin ? 4 : 0) | (Uin ? 2 : 0) | (dzs ? 1 : 0);
+    switch (key) {
+        case 7: CH_LAUNCH(true, true, true); break;
+        case 6: CH_LAUNCH(true, true, false); break;
+        case 5: CH_LAUNCH(true, false, true); break;
+        case 4: CH_LAUNCH(true, false, false); break;
+        case 3: CH_LAUNCH(false, true, true); break;
+        case 2: CH_LAUNCH(false, true, false); break;
+        default: CH_LAUNCH(false, false, true); break;
+    }
+#undef CH_LAUNCH
+    WN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_layer_bwd_reduce, dim3(kPartFloats / 256, kRedParts), dim3(256), 0, s, part, blocks, dWf, dWg,
+                       (Vin || Uin) ? dWp : (float*)nullptr);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int mfma_chain_combine(const float* V, const float* U, float* dx, int B, int T, int dU, hipStream_t s) {
+    const long long n4 = (long long)B * T * 8;
+    hipLaunchKernelGGL(k_chain_combine, dim3(cdiv(n4, 256)), dim3(256), 0, s, V, U, dx, B, T, dU);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
 
 }  // namespace wn

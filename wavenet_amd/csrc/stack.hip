@@ -105,6 +105,33 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
             if (rc) return rc;
         }
     }
+    // ---- chained path: every layer on the MFMA kernels and no conv / projection bias gradients --------------
+    bool chain = true;
+    for (int l = 0; l < L && chain; ++l)
+        chain = wn_layer_fast_path(d->Cr, d->cd[l], d->fw) && !(dbf && dbf[l]) && !(dbg && dbg[l]) && !(dbp && dbp[l]);
+    if (chain) {
+        // the (da,dg) scratch is not needed: its room holds the partial weight-gradient tiles and, together with the
+        // two ping-pong buffers, the split gradient (V, U) of two consecutive layers
+        float* part = dab;
+        float* vu = dab + mfma_layer_bwd_extra_ws_floats();
+        float* Vb[2] = {vu, vu + n * d->Cr};
+        float* Ub[2] = {vu + 2 * n * d->Cr, vu + 3 * n * d->Cr};
+        const float* Vin = dout;
+        const float* Uin = nullptr;
+        int dU = 0;
+        for (int l = L - 1; l >= 0; --l) {
+            wn::ProfScope prof__("wn_layer_bwd", stream);
+            const float* in = l == 0 ? x : xs + (size_t)(l - 1) * n * d->Cr;
+            int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
+            rc = mfma_layer_bwd_chain(in, f + off[l], g + off[l], d->Wf[l], d->Wg[l], d->Wp[l], Vin, Uin, dU,
+                                      dskip ? dzp[l] : nullptr, Vb[l & 1], Ub[l & 1], dWf[l], dWg[l], dWp[l], part, B, T,
+                                      d->dilation[l], Z, as_stream(stream));
+            if (rc) return rc;
+            Vin = Vb[l & 1]; Uin = Ub[l & 1]; dU = d->dilation[l];
+        }
+        if (dx) return mfma_chain_combine(Vin, Uin, dx, B, T, dU, as_stream(stream));
+        return WN_OK;
+    }
     const float* gout = dout;
     for (int l = L - 1; l >= 0; --l) {
         const float* in = l == 0 ? x : xs + (size_t)(l - 1) * n * d->Cr;

@@ -48,6 +48,11 @@ int mfma_layer_bwd(const float* x, const float* f, const float* g, const float* 
                    const float* Wp, const float* dout, const float* dzs, float* dx, float* dWf, float* dWg,
                    float* dWp, float* dab, int B, int T, int d, int Z, hipStream_t s);
 size_t mfma_layer_bwd_extra_ws_floats();
+int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
+                         const float* Wp, const float* Vin, const float* Uin, int dU, const float* dzs, float* Vout,
+                         float* Uout, float* dWf, float* dWg, float* dWp, float* part, int B, int T, int d, int Z,
+                         hipStream_t s);
+int mfma_chain_combine(const float* V, const float* U, float* dx, int B, int T, int dU, hipStream_t s);
 int generic_layer_bwd_biases(const float* dab, const float* dout, float* dbf, float* dbg, float* dbp, int B,
                              int T, int Cr, int Cd, int Z, hipStream_t s);
 
