@@ -31,6 +31,7 @@ CFG2 = dict(quantization_steps=256, sampling_rate=16000, causal_conv_channels=[3
 B_PER_GPU, T = 8, 16384
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
+BF16X3_PEAK_TF = 2500.0 / 6.0  # fp32-equivalent peak of a 6-term bf16 split product on the ~2.5 PF dense bf16 MFMA
 
 
 def make_batch(rank, world, iw):
@@ -179,6 +180,8 @@ def main():
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "gemm_mode": ("exact fp32 MFMA" if os.environ.get("WAVENET_HIP_GEMM") == "fp32" else
+                      "bf16x3 split products, fp32 accumulate (fp32-accurate; layer kernels exact fp32 MFMA)"),
         "config": {"workload": "cfg2 train step: 4 blocks x 10 dilations (1..512), 32 residual / 256 skip ch, "
                                "16 kHz, %d clips x 16384 samples per GPU, loss over last 12290 columns, "
                                "fwd + bwd + clip + Adam%s" % (B_PER_GPU, " + RCCL all-reduce" if world > 1 else ""),
@@ -221,11 +224,11 @@ def main():
         units = {
             # name: (bound, algorithmic amount per launch, launches per step, kernels for PMC traffic)
             "wn_layer_bwd": ("hbm", es * (3 * Cr + Cs + 2 * Cd) * n_col, nl,
-                             ["wn::k_layer_bwd_p1<true, true>", "wn::k_layer_bwd_p1", "wn::k_layer_bwd_p2", "wn::k_layer_bwd_reduce"]),
-            "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl, ["wn::k_layer_fwd_mfma32<true>"]),
-            "wn_skip_sum_fwd": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm<8, 0>"]),
-            "wn_skip_sum_bwd_dw": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_wgrad_mfma<8>"]),
-            "wn_skip_sum_bwd_dz": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm<8, 2>"]),
+                             ["wn::k_layer_bwd_chain<true, true, true>", "wn::k_layer_bwd_reduce"]),
+            "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl, ["wn::k_layer_fwd_mfma32<true, false>"]),
+            "wn_skip_sum_fwd": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<0>"]),
+            "wn_skip_sum_bwd_dw": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_wgrad_b3<4>"]),
+            "wn_skip_sum_bwd_dz": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<2>"]),
         }
         dom = max(units, key=lambda k: per_step.get(k, 0.0))
         bound, amount, launches, knames = units[dom]
@@ -245,9 +248,11 @@ def main():
                                        "skip sum avoids); traffic = measured HBM bytes per launch"}
         else:
             ach = amount / (launch_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TF,
-                               "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TF, "traffic": traffic,
-                               "launch_ms": launch_ms, "flops_per_launch": amount}
+            peak = F32_MFMA_PEAK_TF if os.environ.get("WAVENET_HIP_GEMM") == "fp32" else BF16X3_PEAK_TF
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak,
+                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                               "launch_ms": launch_ms, "flops_per_launch": amount,
+                               "note": "fp32-equivalent flops; peak = dense bf16 MFMA / 6 (bf16x3 split products)"}
         out["mfma_units"] = {k: {"ms": per_step[k], "TFLOPs": units[k][1] / (per_step[k] * 1e-3) / 1e12}
                              for k in units if units[k][0] == "mfma" and k in per_step}
         # ---- AR decode, config 4: 16k samples on one GPU, persistent per-layer state -----------

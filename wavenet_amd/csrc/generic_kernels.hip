@@ -621,7 +621,7 @@ int generic_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* d
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             attr_set = true;
         }
-        int nblk = (int)(ncol < 512 ? (ncol + 63) / 64 : 512);
+        int nblk = (int)(ncol < 256 * 64 ? (ncol + 63) / 64 : 256);
         int cpb = (int)((ncol + nblk - 1) / nblk);
         nblk = (int)((ncol + cpb - 1) / cpb);
         hipLaunchKernelGGL(k_embed_bwd_lds, dim3(nblk), dim3(kThreads), lds, s, idx, dout, dW, dbias, B, T,

@@ -35,11 +35,12 @@ __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
     const int m0 = MP ? 0 : blockIdx.y * (MT * 32);
     const long long n = ((long long)blockIdx.x * 4 + wave) * 32 + j;
     const bool nvalid = n < a.N;
-    long long srow = -1;
+    long long rb0 = 0;                 // first source row of this column's clip
+    int rbase = -(1 << 30);            // row inside the clip before the per-source shift (invalid column: far out)
     if (nvalid) {
         long long b = n / a.rows_out_per_b;
-        int r = (int)(n - b * a.rows_out_per_b) + a.off;
-        if (r >= 0 && r < a.rows_src_per_b) srow = b * a.rows_src_per_b + r;
+        rbase = (int)(n - b * a.rows_out_per_b) + a.off;
+        rb0 = b * a.rows_src_per_b;
     }
     f32x16 acc[MT];
 #pragma unroll
@@ -50,8 +51,8 @@ __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
     // fill mapping: thread -> (row i of the tile, 4-channel group c4)
     const int fi = tid & 31, fc4 = tid >> 5;
     const int fq = fc4 >> 1, fh = fc4 & 1;
-    const float ms = srow >= 0 ? 1.f : 0.f;
-    const long long srowc = srow >= 0 ? srow : 0;          // clamped: loads are unconditional, values masked
+    float ms = 0.f;                                        // mask of the chunk in xr (set by issue)
+    float ms_next = 0.f;
 
     if (!MP) {
         for (int src = 0; src < a.nsrc; ++src)
@@ -69,6 +70,10 @@ __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
     auto issue = [&](int src, int k0) {
         const float* __restrict__ Xb = a.X[src];
         const int K = a.K[src];
+        const int rs = rbase + a.soff[src];
+        const bool rv = rs >= 0 && rs < a.rows_src_per_b;
+        const long long srowc = rb0 + (rv ? rs : 0);       // clamped: loads are unconditional, values masked
+        ms_next = rv ? 1.f : 0.f;
 #pragma unroll
         for (int it = 0; it < MT; ++it) {
             const float* wp;
@@ -95,6 +100,7 @@ __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
 #pragma unroll
         for (int it = 0; it < MT; ++it)
             *reinterpret_cast<float4*>(&Alds[(((it * 4 + fq) * 64) + fi + 32 * fh) * 4]) = wr[it];
+        ms = ms_next;
         float xb[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -135,6 +141,10 @@ __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
                 float4 gx = *reinterpret_cast<const float4*>(a.gate_x + n * a.ldo + m0 + 4 * h + mt * 32 + 8 * q);
                 v.x *= act_grad(gx.x, a.gate_act); v.y *= act_grad(gx.y, a.gate_act);
                 v.z *= act_grad(gx.z, a.gate_act); v.w *= act_grad(gx.w, a.gate_act);
+            }
+            if (a.residual && MODE == 0) {
+                const float4 rr = *reinterpret_cast<const float4*>(a.residual + n * a.ldo + m0 + 4 * h + mt * 32 + 8 * q);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
             }
             if (a.accumulate) {
                 float4 o = *reinterpret_cast<const float4*>(p);

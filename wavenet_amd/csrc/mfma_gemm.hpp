@@ -15,9 +15,11 @@ struct CGArgs {
     int wsk;                         // W column (k) stride: 1 = row-major W[m][k], else transposed view
     int nsrc, nprob, M, ldo;
     long long N;                     // output rows
-    int rows_out_per_b, rows_src_per_b, off;   // src row = b*rows_src_per_b + (n % rows_out_per_b) + off
+    int rows_out_per_b, rows_src_per_b, off;   // src row = b*rows_src_per_b + (n % rows_out_per_b) + off + soff[src]
+    int soff[WN_MAX_SRC];            // per-source row shift (dilated taps); rows outside [0, rows_src_per_b) read as 0
     int act;                         // applied to X on load
     const float* gate_x; int gate_act;         // out *= act'(gate_x[n][m])   (dx of a pre-activated conv)
+    const float* residual;           // out += residual[n][m] (row stride ldo), may be NULL
     int accumulate;
 };
 

@@ -94,14 +94,14 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
     const int t0 = blockIdx.y * MT;                        // first m-tile (mode 2: first problem) of this workgroup
     const long long n = ((long long)blockIdx.x * 4 + wave) * 32 + j;
     const bool nvalid = n < a.N;
-    long long srow = -1;
+    long long rb0 = 0;                 // first source row of this column's clip
+    int rbase = -(1 << 30);            // row inside the clip before the per-source shift (invalid column: far out)
     if (nvalid) {
         long long b = n / a.rows_out_per_b;
-        int r = (int)(n - b * a.rows_out_per_b) + a.off;
-        if (r >= 0 && r < a.rows_src_per_b) srow = b * a.rows_src_per_b + r;
+        rbase = (int)(n - b * a.rows_out_per_b) + a.off;
+        rb0 = b * a.rows_src_per_b;
     }
-    const float ms = srow >= 0 ? 1.f : 0.f;
-    const long long srowc = srow >= 0 ? srow : 0;
+    float ms = 0.f, ms_next = 0.f;     // masks of the chunk being computed / being fetched
 
     f32x16 acc[MT];
 #pragma unroll
@@ -134,7 +134,10 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
     auto load_x = [&](int c) {
         const int src = MODE == 0 ? c / chunks_per_src : 0;
         const int k0 = (MODE == 0 ? c - src * chunks_per_src : c) * 32;
-        const float* __restrict__ Xb = a.X[src] + srowc * a.K[src] + k0 + 8 * h;
+        const int rs = rbase + a.soff[src];
+        const bool rv = rs >= 0 && rs < a.rows_src_per_b;
+        ms_next = rv ? 1.f : 0.f;
+        const float* __restrict__ Xb = a.X[src] + (rb0 + (rv ? rs : 0)) * a.K[src] + k0 + 8 * h;
         xr[0] = *reinterpret_cast<const float4*>(Xb);             // k-step 0: channels 8h .. 8h+7
         xr[1] = *reinterpret_cast<const float4*>(Xb + 4);
         xr[2] = *reinterpret_cast<const float4*>(Xb + 16);        // k-step 1: channels 16+8h .. 16+8h+7
@@ -145,6 +148,7 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
     load_x(0);
     for (int c = 0; c < nchunks; ++c) {
         // split this chunk's X columns (the loads were issued one iteration ago)
+        ms = ms_next;
         bf16x8 xh[2], xm[2], xl[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -195,6 +199,10 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
                 const float4 gx = *reinterpret_cast<const float4*>(a.gate_x + n * a.ldo + (t0 + mt) * 32 + 4 * h + 8 * q);
                 v.x *= act_grad(gx.x, a.gate_act); v.y *= act_grad(gx.y, a.gate_act);
                 v.z *= act_grad(gx.z, a.gate_act); v.w *= act_grad(gx.w, a.gate_act);
+            }
+            if (MODE == 0 && a.residual) {
+                const float4 rr = *reinterpret_cast<const float4*>(a.residual + n * a.ldo + (t0 + mt) * 32 + 4 * h + 8 * q);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
             }
             if (a.accumulate) {
                 const float4 o = *reinterpret_cast<const float4*>(p);
