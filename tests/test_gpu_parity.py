@@ -59,8 +59,11 @@ def _run_layer(x, Wf, Wg, Wp, b, Z, Cr, Cd, fw, d, save):
 
 @pytest.mark.parametrize("Cr,Cd,fw,d,B,T,bias", [
     (16, 16, 2, 1, 1, 50, False), (16, 16, 2, 8, 2, 100, True), (8, 12, 3, 9, 2, 77, True), (5, 3, 2, 4, 1, 7, False),
-    (128, 32, 2, 16, 1, 300, False), (24, 24, 2, 512, 1, 600, True), (6, 6, 4, 4, 1, 10, False)])
+    (128, 32, 2, 16, 1, 300, False), (24, 24, 2, 512, 1, 600, True), (6, 6, 4, 4, 1, 10, False),
+    (64, 32, 3, 9, 2, 211, True), (128, 128, 2, 64, 1, 333, False), (32, 64, 2, 4, 2, 100, True), (32, 32, 3, 3, 1, 65, False)])
 def test_layer_fwd_generic(Cr, Cd, fw, d, B, T, bias):
+    """Shapes outside the fused 32/32/2 kernel: the generic kernels, and (widths multiple of 32) the composite
+    matrix-core path of wide_layer.hip; inference (no f/g) and training (f/g saved) variants."""
     assert _lib.lib().wn_layer_fast_path(Cr, Cd, fw) == 0
     x, Wf, Wg, Wp, b, Z, out, z, f_, g_ = _layer_case(Cr, Cd, fw, d, B, T, bias)
     o, zz, f, g = _run_layer(x, Wf, Wg, Wp, b, Z, Cr, Cd, fw, d, True)
@@ -68,6 +71,9 @@ def test_layer_fwd_generic(Cr, Cd, fw, d, B, T, bias):
     np.testing.assert_allclose(to_np(zz), btc(z), atol=ATOL)
     np.testing.assert_allclose(to_np(f), btc(f_), atol=ATOL)
     np.testing.assert_allclose(to_np(g), btc(g_), atol=ATOL)
+    o2, zz2, _, _ = _run_layer(x, Wf, Wg, Wp, b, Z, Cr, Cd, fw, d, False)
+    np.testing.assert_allclose(to_np(o2), btc(out), atol=ATOL)
+    np.testing.assert_allclose(to_np(zz2), btc(z), atol=ATOL)
 
 
 @pytest.mark.parametrize("d,B,T,bias,save", [
@@ -481,7 +487,9 @@ def _layer_bwd_ref(x, Wf, Wg, Wp, b, Z, d, fw, dout, dzs):
 @pytest.mark.parametrize("Cr,Cd,fw,d,B,T,bias,with_dout", [
     (32, 32, 2, 1, 2, 100, False, True), (32, 32, 2, 512, 2, 1100, True, True), (32, 32, 2, 16, 3, 257, False, False),
     (32, 32, 2, 64, 1, 31, True, True), (32, 32, 2, 256, 1, 2048, False, True),
-    (16, 12, 3, 9, 2, 77, True, True), (8, 8, 2, 4, 1, 40, False, False)])
+    (16, 12, 3, 9, 2, 77, True, True), (8, 8, 2, 4, 1, 40, False, False),
+    (64, 32, 3, 9, 2, 211, True, True), (128, 128, 2, 64, 1, 333, False, True), (32, 64, 2, 4, 2, 100, True, False),
+    (32, 32, 3, 3, 1, 65, False, True)])
 def test_layer_bwd(Cr, Cd, fw, d, B, T, bias, with_dout):
     """wn_layer_bwd: MFMA path (32/32/2) and generic path against float64 autograd."""
     rs = np.random.RandomState(T + d)

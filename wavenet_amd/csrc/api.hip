@@ -78,6 +78,9 @@ int wn_layer_fwd(const float* x, const float* Wf, const float* bf, const float* 
     WN_CHECK_ARG(out != x, "wn_layer_fwd: out must not alias x (taps read x[t-d])");
     if (wn_layer_fast_path(Cr, Cd, fw))
         return mfma_layer_fwd(x, Wf, bf, Wg, bg, Wp, bp, out, z, f_save, g_save, B, T, d, Z, as_stream(stream));
+    if (!force_generic() && wide_layer_supported(Cr, Cd, fw) && (f_save || Cd <= Cr))
+        return wide_layer_fwd(x, Wf, bf, Wg, bg, Wp, bp, out, z, f_save, g_save, B, T, Cr, Cd, fw, d, Z,
+                              as_stream(stream));
     return generic_layer_fwd(x, Wf, bf, Wg, bg, Wp, bp, out, z, f_save, g_save, B, T, Cr, Cd, fw, d, Z,
                              as_stream(stream));
 }
@@ -104,6 +107,9 @@ int wn_layer_bwd(const float* x, const float* f, const float* g, const float* Wf
         if (rc) return rc;
         return generic_layer_bwd_biases(dab_ws, dout, dbf, dbg, dbp, B, T, Cr, Cd, Z, as_stream(stream));
     }
+    if (!force_generic() && wide_layer_supported(Cr, Cd, fw))
+        return wide_layer_bwd(x, f, g, Wf, Wg, Wp, dout, dz_skip, dx, dWf, dbf, dWg, dbg, dWp, dbp, dab_ws, B, T, Cr, Cd,
+                              fw, d, Z, as_stream(stream));
     return generic_layer_bwd(x, f, g, Wf, Wg, Wp, dout, dz_skip, dx, dWf, dbf, dWg, dbg, dWp, dbp, dab_ws, B, T,
                              Cr, Cd, fw, d, Z, as_stream(stream));
 }

@@ -721,6 +721,11 @@ int generic_layer_bwd(const float* x, const float* f, const float* g, const floa
     return WN_OK;
 }
 
+// out[m] += sum over rows t in [tmin, nT) of every clip of A[b][t][m]  (dense rows of width lda)
+int generic_colsum(const float* A, int nB, int nT, int tmin, int lda, int M, float* out, hipStream_t s) {
+    return launch_colsum(A, (long long)nT * lda, 0, lda, nB, tmin, nT, M, out, s);
+}
+
 // bias gradients of a residual layer from the (da,dg) scratch: dbf += sum da, dbg += sum dg, dbp += sum dout
 int generic_layer_bwd_biases(const float* dab, const float* dout, float* dbf, float* dbg, float* dbp, int B,
                              int T, int Cr, int Cd, int Z, hipStream_t s) {

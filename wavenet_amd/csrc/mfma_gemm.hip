@@ -184,6 +184,8 @@ static int launch_colgemm(CGArgs& a, int nprob, hipStream_t s) {
     return WN_OK;
 }
 
+int launch_colgemm_multi(CGArgs& a, hipStream_t s) { return launch_colgemm<false>(a, 1, s); }
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---- entry points used by api.hip -------------------------------------------------------------
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WGArgs a) {
     const int r_end = min(a.rows_A_per_b, r_begin + a.rows_per_wg);
     const float* __restrict__ Ab = a.A + ((long long)b * a.rows_A_per_b) * a.lda + m0;
     const float* __restrict__ Bb = active ? a.Bp[p] + ((long long)b * a.rows_B_per_b + a.off) * a.ldb + j : nullptr;
+    const float* __restrict__ B2b = (active && a.B2p[p]) ? a.B2p[p] + ((long long)b * a.rows_B_per_b + a.off) * a.ldb + j : nullptr;
     f32x16 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -315,7 +318,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WGArgs a) {
             int rc = r < r_end ? r : r_end - 1;                              // clamped row, masked value
             if (rc + a.off < 0) rc = -a.off;
             if (rc + a.off >= a.rows_B_per_b) rc = a.rows_B_per_b - 1 - a.off;
-            const float v = active ? act_apply(Bb[(long long)rc * a.ldb], a.act) : 0.f;
+            float v = active ? act_apply(Bb[(long long)rc * a.ldb], a.act) : 0.f;
+            if (B2b) v *= B2b[(long long)rc * a.ldb];
             br[s] = ok ? v : 0.f;
         }
     };
@@ -348,10 +352,12 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WGArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            atomicAdd(o + (long long)(m0 + mt * 32 + cg_ch(r, h)) * a.ldo + j, acc[mt][r]);
+            atomicAdd(o + (long long)(m0 + mt * 32 + cg_ch(r, h)) * a.ldo + (long long)j * (a.osk ? a.osk : 1), acc[mt][r]);
 }
 
-static int launch_wgrad_mfma(WGArgs& a, int M, hipStream_t s) {
+int launch_wgrad(WGArgs& a, int M, hipStream_t s);
+static int launch_wgrad_mfma(WGArgs& a, int M, hipStream_t s) { return launch_wgrad(a, M, s); }
+int launch_wgrad(WGArgs& a, int M, hipStream_t s) {
     int mt = (M % 256 == 0) ? 8 : (M % 128 == 0) ? 4 : (M % 64 == 0) ? 2 : 1;
     // row slabs: enough workgroups to fill the chip, few enough that the atomics stay small
     int groups = cdiv(a.nprob, 4) * (M / (mt * 32));

@@ -27,8 +27,10 @@ struct CGArgs {
 struct WGArgs {
     const float* A; int lda;
     const float* Bp[WN_MAX_SRC];
+    const float* B2p[WN_MAX_SRC];    // optional elementwise factor on B (z = f*g), same addressing; entries may be NULL
     float* out[WN_MAX_SRC];
     int nprob, ldb, ldo;
+    int osk;                         // output column stride (1; fw for a conv weight W[o][c][k]); 0 means 1
     int nB, rows_A_per_b, rows_B_per_b, off;   // B row = b*rows_B_per_b + r + off for A row b*rows_A_per_b + r
     int act;
     int rows_per_wg, wgs_per_b;
@@ -40,6 +42,10 @@ bool gemm_b3_enabled();
 // the shape is not covered (the caller then uses the exact-fp32 kernel).
 int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s);
 
+// dW_p[m*ldo + k*osk] += sum_n A[n][m] * act(B_p[row(n)][k]) (* B2_p);  M rows; picks bf16x3 or exact fp32
+int launch_wgrad(WGArgs& a, int M, hipStream_t s);
+// one channel GEMM launch (multi-source form); picks bf16x3 or exact fp32
+int launch_colgemm_multi(CGArgs& a, hipStream_t s);
 // bf16x3 form of k_wgrad_mfma (same grid / arguments)
 int launch_wgrad_b3(const WGArgs& a, int mt, dim3 grid, hipStream_t s);
 

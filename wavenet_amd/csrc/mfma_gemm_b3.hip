@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
     const int r_end = min(a.rows_A_per_b, r_begin + a.rows_per_wg);
     const float* __restrict__ Ab = a.A + ((long long)b * a.rows_A_per_b) * a.lda + m0;
     const float* __restrict__ Bb = a.Bp[active ? p : 0] + ((long long)b * a.rows_B_per_b + a.off) * a.ldb + j;
+    const float* __restrict__ B2b = a.B2p[active ? p : 0] ? a.B2p[active ? p : 0] + ((long long)b * a.rows_B_per_b + a.off) * a.ldb + j : nullptr;
     f32x16 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -311,8 +312,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj)
-                    br[ks][jj] = active ? act_apply(bp[(long long)(16 * ks + jj) * a.ldb], a.act) : 0.f;
+                for (int jj = 0; jj < 8; ++jj) {
+                    float v = active ? act_apply(bp[(long long)(16 * ks + jj) * a.ldb], a.act) : 0.f;
+                    if (B2b) v *= B2b[(long long)(r0 + 8 * h + 16 * ks + jj) * a.ldb];
+                    br[ks][jj] = v;
+                }
             return;
         }
 #pragma unroll
@@ -336,7 +340,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
                 int rc = r < r_end ? r : r_end - 1;
                 if (rc + a.off < 0) rc = -a.off;
                 if (rc + a.off >= a.rows_B_per_b) rc = a.rows_B_per_b - 1 - a.off;
-                br[ks][jj] = ok ? act_apply(Bb[(long long)rc * a.ldb], a.act) : 0.f;
+                float v = ok ? act_apply(Bb[(long long)rc * a.ldb], a.act) : 0.f;
+                if (B2b) v *= B2b[(long long)rc * a.ldb];
+                br[ks][jj] = v;
             }
     };
     if (r_begin < r_end) issue(r_begin);
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            atomicAdd(o + (long long)(m0 + mt * 32 + b3_ch(r, h)) * a.ldo + j, acc[mt][r]);
+            atomicAdd(o + (long long)(m0 + mt * 32 + b3_ch(r, h)) * a.ldo + (long long)j * (a.osk ? a.osk : 1), acc[mt][r]);
 }
 
 int launch_wgrad_b3(const WGArgs& a, int mt, dim3 grid, hipStream_t s) {

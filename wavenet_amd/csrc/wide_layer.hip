@@ -1,0 +1,158 @@
+// Residual layer for channel widths the fused 32/32/2 kernels do not cover -- any Cr, Cd that are
+// multiples of 32 and any filter width (BASELINE config 5's 128/512, the reference's default 128/32,
+// _tests_' filter width 3 ...): the same maths as ResidualConvLayer.__call__ (wavenet.py:358-368) and its
+// backward, composed from the matrix-core channel GEMMs of mfma_gemm*.hip plus two elementwise kernels.
+//
+//   forward   a = sum_k Wf_k x[t-(fw-1-k)d] (+bf)   g likewise        multi-source GEMM, one source per tap
+//             z = tanh(a) sigmoid(g), zero prefix                      k_gate
+//             out = Wp z + bp + x                                       GEMM with a residual epilogue
+//   backward  dz = Wp^T dout + dz_skip                                  GEMM on the transposed view of Wp
+//             da = dz g (1-f^2), dg = dz f g (1-g), zero prefix         k_gate_bwd
+//             dx = dout + sum_k Wf_k^T da[t+(fw-1-k)d] + Wg_k^T dg[..]  multi-source GEMM, 2 fw sources
+//             dWp, dWf_k, dWg_k                                         weight-gradient GEMMs (contraction over time)
+//             biases                                                    column sums
+#include "mfma_gemm.hpp"
+
+namespace wn {
+
+__global__ void k_wide_gate(float* __restrict__ a, float* __restrict__ g, float* __restrict__ z, float* __restrict__ fs,
+                            float* __restrict__ gs, long long n4, int T, int Cd, int Z) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index
+    if (i >= n4) return;
+    const int t = (int)((i * 4 / Cd) % T);
+    float4 av = reinterpret_cast<const float4*>(a)[i], gv = reinterpret_cast<const float4*>(g)[i];
+    if (t < Z) { av = make_float4(0, 0, 0, 0); gv = av; }                      // reference zero prefix
+    const float4 f = make_float4(fast_tanh(av.x), fast_tanh(av.y), fast_tanh(av.z), fast_tanh(av.w));
+    const float4 s = make_float4(fast_sigmoid(gv.x), fast_sigmoid(gv.y), fast_sigmoid(gv.z), fast_sigmoid(gv.w));
+    reinterpret_cast<float4*>(z)[i] = make_float4(f.x * s.x, f.y * s.y, f.z * s.z, f.w * s.w);
+    if (fs) { reinterpret_cast<float4*>(fs)[i] = f; reinterpret_cast<float4*>(gs)[i] = s; }
+}
+
+__global__ void k_wide_gate_bwd(const float* __restrict__ dz, const float* __restrict__ f, const float* __restrict__ g,
+                                float* __restrict__ da, float* __restrict__ dg, long long n4, int T, int Cd, int Z) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int t = (int)((i * 4 / Cd) % T);
+    float4 d = reinterpret_cast<const float4*>(dz)[i];
+    if (t < Z) d = make_float4(0, 0, 0, 0);
+    const float4 fv = reinterpret_cast<const float4*>(f)[i], gv = reinterpret_cast<const float4*>(g)[i];
+    reinterpret_cast<float4*>(da)[i] = make_float4(d.x * gv.x * (1.f - fv.x * fv.x), d.y * gv.y * (1.f - fv.y * fv.y),
+                                                   d.z * gv.z * (1.f - fv.z * fv.z), d.w * gv.w * (1.f - fv.w * fv.w));
+    reinterpret_cast<float4*>(dg)[i] = make_float4(d.x * fv.x * gv.x * (1.f - gv.x), d.y * fv.y * gv.y * (1.f - gv.y),
+                                                   d.z * fv.z * gv.z * (1.f - gv.z), d.w * fv.w * gv.w * (1.f - gv.w));
+}
+
+bool wide_layer_supported(int Cr, int Cd, int fw) { return Cr % 32 == 0 && Cd % 32 == 0 && 2 * fw <= WN_MAX_SRC; }
+
+static void base_args(CGArgs& a, int B, int T) {
+    a.N = (long long)B * T; a.rows_out_per_b = T; a.rows_src_per_b = T; a.off = 0;
+    a.act = WN_ACT_NONE; a.gate_x = nullptr; a.gate_act = 0; a.residual = nullptr; a.accumulate = 0;
+}
+
+// one dilated conv: out[b,t,:] = sum_k W[:, :, k] x[b, t-(fw-1-k)d, :] + bias
+static int conv_gemm(const float* x, const float* W, const float* bias, float* out, int B, int T, int Cin, int Cout,
+                     int fw, int d, hipStream_t s) {
+    CGArgs a{};
+    base_args(a, B, T);
+    a.nsrc = fw;
+    for (int k = 0; k < fw; ++k) {
+        a.X[k] = x; a.K[k] = Cin; a.W[k] = W + k; a.wsm[k] = Cin * fw; a.soff[k] = -(fw - 1 - k) * d;
+        a.bias[k] = k == 0 ? bias : nullptr;
+    }
+    a.wsk = fw; a.M = Cout; a.ldo = Cout; a.out[0] = out;
+    return launch_colgemm_multi(a, s);
+}
+
+int wide_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg, const float* Wp,
+                   const float* bp, float* out, float* z, float* fs, float* gs, int B, int T, int Cr, int Cd, int fw,
+                   int d, int Z, hipStream_t s) {
+    // pre-activations go where f / sigmoid(g) will live (training) or into z / out (inference, needs Cd <= Cr)
+    float* abuf = fs ? fs : z;
+    float* gbuf = gs ? gs : out;
+    if (!gs && Cd > Cr) { wn::set_error("wide_layer_fwd: inference needs Cd <= Cr"); return WN_ESHAPE; }
+    int rc = conv_gemm(x, Wf, bf, abuf, B, T, Cr, Cd, fw, d, s);
+    if (rc) return rc;
+    rc = conv_gemm(x, Wg, bg, gbuf, B, T, Cr, Cd, fw, d, s);
+    if (rc) return rc;
+    const long long n4 = (long long)B * T * Cd / 4;
+    hipLaunchKernelGGL(k_wide_gate, dim3(cdiv(n4, 256)), dim3(256), 0, s, abuf, gbuf, z, fs, gs, n4, T, Cd, Z);
+    WN_LAUNCH_CHECK();
+    CGArgs a{};
+    base_args(a, B, T);
+    a.nsrc = 1; a.X[0] = z; a.K[0] = Cd; a.W[0] = Wp; a.wsm[0] = Cd; a.wsk = 1; a.bias[0] = bp;
+    a.M = Cr; a.ldo = Cr; a.out[0] = out; a.residual = x;
+    return launch_colgemm_multi(a, s);
+}
+
+// dW[o][c][k] += sum_n A[n][o] * x[n - (fw-1-k)d][c]
+static int conv_wgrad(const float* A, const float* x, float* dW, int B, int T, int Cin, int Cout, int fw, int d,
+                      hipStream_t s) {
+    for (int k = 0; k < fw; ++k)
+        for (int c0 = 0; c0 < Cin; c0 += 32 * WN_MAX_SRC) {
+            WGArgs a{};
+            a.A = A; a.lda = Cout; a.nprob = 0;
+            for (int c = c0; c < Cin && a.nprob < WN_MAX_SRC; c += 32) {
+                a.Bp[a.nprob] = x + c; a.B2p[a.nprob] = nullptr; a.out[a.nprob] = dW + (long long)c * fw + k; ++a.nprob;
+            }
+            a.ldb = Cin; a.ldo = Cin * fw; a.osk = fw;
+            a.nB = B; a.rows_A_per_b = T; a.rows_B_per_b = T; a.off = -(fw - 1 - k) * d; a.act = WN_ACT_NONE;
+            int rc = launch_wgrad(a, Cout, s);
+            if (rc) return rc;
+        }
+    return WN_OK;
+}
+
+int wide_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg, const float* Wp,
+                   const float* dout, const float* dzs, float* dx, float* dWf, float* dbf, float* dWg, float* dbg,
+                   float* dWp, float* dbp, float* ws, int B, int T, int Cr, int Cd, int fw, int d, int Z,
+                   hipStream_t s) {
+    const long long n = (long long)B * T;
+    float* da = ws;                  // (B,T,Cd): dz first, then da in place
+    float* dg = ws + n * Cd;         // (B,T,Cd)
+    int rc;
+    const float* dz = dzs;
+    if (dout) {                      // dz = Wp^T dout + dz_skip
+        CGArgs a{};
+        base_args(a, B, T);
+        a.nsrc = 1; a.X[0] = dout; a.K[0] = Cr; a.W[0] = Wp; a.wsm[0] = 1; a.wsk = Cd; a.bias[0] = nullptr;
+        a.M = Cd; a.ldo = Cd; a.out[0] = da; a.residual = dzs;
+        if ((rc = launch_colgemm_multi(a, s))) return rc;
+        dz = da;
+    }
+    const long long n4 = n * Cd / 4;
+    hipLaunchKernelGGL(k_wide_gate_bwd, dim3(cdiv(n4, 256)), dim3(256), 0, s, dz, f, g, da, dg, n4, T, Cd, Z);
+    WN_LAUNCH_CHECK();
+    if (dx) {                        // dx = dout + sum_k Wf_k^T da[t+(fw-1-k)d] + Wg_k^T dg[t+(fw-1-k)d]
+        CGArgs a{};
+        base_args(a, B, T);
+        a.nsrc = 2 * fw;
+        for (int k = 0; k < fw; ++k)
+            for (int w = 0; w < 2; ++w) {
+                const int i = 2 * k + w;
+                a.X[i] = w ? dg : da; a.K[i] = Cd; a.W[i] = (w ? Wg : Wf) + k; a.wsm[i] = fw;
+                a.soff[i] = (fw - 1 - k) * d; a.bias[i] = nullptr;
+            }
+        a.wsk = Cr * fw; a.M = Cr; a.ldo = Cr; a.out[0] = dx; a.residual = dout;
+        if ((rc = launch_colgemm_multi(a, s))) return rc;
+    }
+    if (dWf && (rc = conv_wgrad(da, x, dWf, B, T, Cr, Cd, fw, d, s))) return rc;
+    if (dWg && (rc = conv_wgrad(dg, x, dWg, B, T, Cr, Cd, fw, d, s))) return rc;
+    if (dWp && dout) {               // dWp[cr][cd] += sum dout[n][cr] * (f g)[n][cd]
+        for (int c0 = 0; c0 < Cd; c0 += 32 * WN_MAX_SRC) {
+            WGArgs a{};
+            a.A = dout; a.lda = Cr; a.nprob = 0;
+            for (int c = c0; c < Cd && a.nprob < WN_MAX_SRC; c += 32) {
+                a.Bp[a.nprob] = f + c; a.B2p[a.nprob] = g + c; a.out[a.nprob] = dWp + c; ++a.nprob;
+            }
+            a.ldb = Cd; a.ldo = Cd; a.osk = 1;
+            a.nB = B; a.rows_A_per_b = T; a.rows_B_per_b = T; a.off = 0; a.act = WN_ACT_NONE;
+            if ((rc = launch_wgrad(a, Cr, s))) return rc;
+        }
+    }
+    if (dbf && (rc = generic_colsum(da, B, T, 0, Cd, Cd, dbf, s))) return rc;     // da, dg are already 0 for t < Z
+    if (dbg && (rc = generic_colsum(dg, B, T, 0, Cd, Cd, dbg, s))) return rc;
+    if (dbp && dout && (rc = generic_colsum(dout, B, T, 0, Cr, Cr, dbp, s))) return rc;
+    return WN_OK;
+}
+
+}  // namespace wn

@@ -29,6 +29,7 @@ int generic_skip_bwd_dz(int L, const float* const* Ws, const int* cd, const floa
                         int B, int T, int t_off, int Tw, int Cs, hipStream_t s);
 int generic_skip_bwd_dw(int L, const float* const* z, const int* cd, const float* dskip, float* const* dWs,
                         float* const* dbs, int B, int T, int t_off, int Tw, int Cs, hipStream_t s);
+int generic_colsum(const float* A, int nB, int nT, int tmin, int lda, int M, float* out, hipStream_t s);
 int generic_softmax(const float*, float*, long long, int, hipStream_t);
 int generic_softmax_xent(const float*, const int32_t*, float*, float*, long long, int, hipStream_t);
 int generic_transpose(const float* src, float* dst, int batch, int R, int Cc, hipStream_t s);
@@ -55,6 +56,16 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
 int mfma_chain_combine(const float* V, const float* U, float* dx, int B, int T, int dU, hipStream_t s);
 int generic_layer_bwd_biases(const float* dab, const float* dout, float* dbf, float* dbg, float* dbp, int B,
                              int T, int Cr, int Cd, int Z, hipStream_t s);
+
+// ---- wide_layer.hip: residual layer for any Cr, Cd multiple of 32 and any fw, composed from the channel GEMMs
+bool wide_layer_supported(int Cr, int Cd, int fw);
+int wide_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg, const float* Wp,
+                   const float* bp, float* out, float* z, float* fs, float* gs, int B, int T, int Cr, int Cd, int fw,
+                   int d, int Z, hipStream_t s);
+int wide_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg, const float* Wp,
+                   const float* dout, const float* dzs, float* dx, float* dWf, float* dbf, float* dWg, float* dbg,
+                   float* dWp, float* dbp, float* ws, int B, int T, int Cr, int Cd, int fw, int d, int Z,
+                   hipStream_t s);
 
 // ---- mfma_gemm.hip: fp32-MFMA channel GEMMs over time columns (all widths multiples of 32) ---
 bool mfma_skip_supported(int L, const int* cd, int Cs);
