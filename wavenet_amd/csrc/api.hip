@@ -168,7 +168,7 @@ int wn_skip_sum_bwd_dz(int L, const float* const* Ws, const int* cd, const float
     if (rc) return rc;
     for (int l = 0; l < L; ++l) WN_CHECK_ARG(dz[l] && Ws[l] && cd[l] > 0, "wn_skip_sum_bwd_dz: bad entry %d", l);
     bool fast = !force_generic() && Cs % 32 == 0;
-    for (int l = 0; l < L && fast; ++l) fast = cd[l] == 32 || cd[l] == 64 || cd[l] == 128 || cd[l] == 256;
+    for (int l = 0; l < L && fast; ++l) fast = cd[l] % 32 == 0;
     if (fast) return mfma_skip_bwd_dz(L, Ws, cd, dskip, dz, B, T, t_off, Tw, Cs, as_stream(stream));
     return generic_skip_bwd_dz(L, Ws, cd, dskip, dz, B, T, t_off, Tw, Cs, as_stream(stream));
 }
@@ -180,9 +180,9 @@ int wn_skip_sum_bwd_dw(int L, const float* const* z, const int* cd, const float*
     int rc = check_skip("wn_skip_sum_bwd_dw", L, B, T, t_off, Tw, Cs);
     if (rc) return rc;
     bool fast = !force_generic() && Cs % 32 == 0 && dWs;
-    for (int l = 0; l < L && fast; ++l) fast = cd[l] == 32;
+    for (int l = 0; l < L && fast; ++l) fast = cd[l] % 32 == 0;
     if (fast) {
-        rc = mfma_skip_bwd_dw(L, z, dskip, dWs, B, T, t_off, Tw, Cs, as_stream(stream));
+        rc = mfma_skip_bwd_dw(L, z, cd, dskip, dWs, B, T, t_off, Tw, Cs, as_stream(stream));
         if (rc) return rc;
         dWs = nullptr;
     }

@@ -218,21 +218,24 @@ int mfma_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, cons
 
 int mfma_skip_bwd_dz(int L, const float* const* Ws, const int* cd, const float* dskip, float* const* dz, int B,
                      int T, int t_off, int Tw, int Cs, hipStream_t s) {
-    // all layers must share cd for the one-launch form; otherwise launch per distinct width
-    for (int l0 = 0; l0 < L;) {
-        int l1 = l0;
-        while (l1 < L && l1 - l0 < WN_MAX_SRC && cd[l1] == cd[l0]) ++l1;
+    // every layer is cd/32 problems of 32 output rows sharing X = dskip; batches of <= WN_MAX_SRC problems with
+    // one row stride (ldo = cd) per launch
+    int l = 0, j = 0;                 // next layer, next 32-row tile inside it
+    while (l < L) {
         CGArgs a{};
+        const int width = cd[l];
+        int np = 0;
+        while (l < L && cd[l] == width && np < WN_MAX_SRC) {
+            a.W[np] = Ws[l] + 32 * j; a.wsm[np] = 1; a.out[np] = dz[l] + 32 * j; ++np;
+            if (++j == width / 32) { j = 0; ++l; }
+        }
         a.nsrc = 1; a.X[0] = dskip; a.K[0] = Cs; a.bias[0] = nullptr;
-        for (int l = l0; l < l1; ++l) { a.W[l - l0] = Ws[l]; a.wsm[l - l0] = 1; a.out[l - l0] = dz[l]; }
-        a.wsk = cd[l0];                                   // W[m][k] = Ws[k][m]
-        a.M = cd[l0]; a.ldo = cd[l0]; a.N = (long long)B * T;
+        a.wsk = width;                                    // W[m][k] = Ws[k][m]
+        a.M = 32; a.ldo = width; a.N = (long long)B * T;
         a.rows_out_per_b = T; a.rows_src_per_b = Tw; a.off = -t_off;
         a.act = WN_ACT_NONE; a.gate_x = nullptr; a.accumulate = 0;
-        if (cd[l0] / 32 > 8) { wn::set_error("skip_bwd_dz: cd > 256 not covered"); return WN_ESHAPE; }
-        int rc = launch_colgemm<true>(a, l1 - l0, s);
+        int rc = launch_colgemm<true>(a, np, s);
         if (rc) return rc;
-        l0 = l1;
     }
     return WN_OK;
 }
@@ -385,21 +388,22 @@ int launch_wgrad(WGArgs& a, int M, hipStream_t s) {
     return WN_OK;
 }
 
-// dWs[l][cs][cd] += sum dskip[b,t',cs] z_l[b,t_off+t',cd]   for every layer with cd == 32
-int mfma_skip_bwd_dw(int L, const float* const* z, const float* dskip, float* const* dWs, int B, int T,
+// dWs[l][cs][cd] += sum dskip[b,t',cs] z_l[b,t_off+t',cd]   (cd any multiple of 32: one problem per 32 columns)
+int mfma_skip_bwd_dw(int L, const float* const* z, const int* cd, const float* dskip, float* const* dWs, int B, int T,
                      int t_off, int Tw, int Cs, hipStream_t s) {
-    for (int l0 = 0; l0 < L; l0 += WN_MAX_SRC) {
+    int l = 0, j = 0;
+    while (l < L) {
         WGArgs a{};
-        a.A = dskip; a.lda = Cs;
-        a.nprob = 0;
-        for (int l = l0; l < L && l - l0 < WN_MAX_SRC; ++l) {
-            if (!dWs[l]) continue;
-            a.Bp[a.nprob] = z[l]; a.out[a.nprob] = dWs[l]; ++a.nprob;
+        a.A = dskip; a.lda = Cs; a.nprob = 0;
+        const int width = cd[l];
+        while (l < L && cd[l] == width && a.nprob < WN_MAX_SRC) {
+            if (dWs[l]) { a.Bp[a.nprob] = z[l] + 32 * j; a.B2p[a.nprob] = nullptr; a.out[a.nprob] = dWs[l] + 32 * j; ++a.nprob; }
+            if (++j == width / 32) { j = 0; ++l; }
         }
         if (a.nprob == 0) continue;
-        a.ldb = 32; a.ldo = 32;
+        a.ldb = width; a.ldo = width; a.osk = 1;
         a.nB = B; a.rows_A_per_b = Tw; a.rows_B_per_b = T; a.off = t_off; a.act = WN_ACT_NONE;
-        int rc = launch_wgrad_mfma(a, Cs, s);
+        int rc = launch_wgrad(a, Cs, s);
         if (rc) return rc;
     }
     return WN_OK;

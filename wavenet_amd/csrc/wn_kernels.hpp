@@ -79,7 +79,7 @@ int mfma_pointwise_fwd(const float* x, const float* W, const float* bias, float*
 int mfma_pointwise_bwd_dx(const float* x, const float* W, const float* dout, float* dx, long long N, int Cin,
                           int Cout, int act, hipStream_t s);
 
-int mfma_skip_bwd_dw(int L, const float* const* z, const float* dskip, float* const* dWs, int B, int T,
+int mfma_skip_bwd_dw(int L, const float* const* z, const int* cd, const float* dskip, float* const* dWs, int B, int T,
                      int t_off, int Tw, int Cs, hipStream_t s);
 int mfma_pointwise_bwd_dw(const float* x, const float* dout, float* dW, long long N, int Cin, int Cout, int act,
                           hipStream_t s);
