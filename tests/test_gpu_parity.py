@@ -546,6 +546,31 @@ def test_fast_decoder_specialised_kernel(blocks, layers):
         buf = np.append(buf, [want[step]]).astype(np.int32)
 
 
+def test_fast_decoder_sampler_boundary_fallback():
+    """The specialised decoder samples with a parallel fp64 scan and falls back to the sequential numpy-order
+    chain when u sits within 1e-12 of a cdf boundary.  Put u exactly ON boundaries of the device's own
+    distribution (np.random.choice: searchsorted side='right' -> the NEXT index) and just beside them."""
+    over = dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 5,
+                residual_num_blocks=2, softmax_conv_channels=[256, 256])
+    p, w, net = build(over, cls=FasterWaveNet, seed=5)
+    n = 6
+    u = np.random.RandomState(4).random_sample(n)
+    toks, probs = net.generate(n, u, return_probs=True)
+    toks, probs = to_np(toks), to_np(probs)
+    for step, shift in [(2, 0.0), (3, 1e-14), (4, -1e-14), (5, 0.0)]:
+        cdf = np.cumsum(probs[step].astype(np.float64))
+        cdf /= cdf[-1]
+        j = int(np.searchsorted(cdf, u[step], side="right"))      # a boundary next to the original draw
+        j = min(max(j, 1), 254)
+        u2 = u.copy()
+        u2[step] = cdf[j] + shift
+        want = R.choice_from_uniform(probs[step], u2[step])
+        net.prev_causal_outputs = None
+        t2 = to_np(net.generate(step + 1, u2[:step + 1]))
+        np.testing.assert_array_equal(t2[:step], toks[:step])
+        assert t2[step] == want, (step, shift, t2[step], want, j)
+
+
 def test_config5_topology_fp32_forward_and_grads():
     """BASELINE config 5's widths (128 residual / 512 skip) run through the generic layer kernel and the fp32
     MFMA channel GEMMs; parity in fp32 (the bf16 MFMA layer kernel for this shape is a later round)."""

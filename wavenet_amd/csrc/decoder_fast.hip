@@ -38,12 +38,45 @@ __device__ __forceinline__ float quad_allsum(float v) {
     v += dpp_f(v, 102);
     return v;
 }
-__device__ __forceinline__ float wave_allmax(float v) {
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+// DPP moves: lane i <- lane i-n inside its 16-lane row (row_shr), or the previous row's last lane (row_bcast)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int old, int v) {
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ float wave_allmax(float v) {      // full-wave max, broadcast through an SGPR
+    const int ninf = __float_as_int(-INFINITY);
+    v = fmaxf(v, __int_as_float(dpp_i<0x111, 0xf>(ninf, __float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x112, 0xf>(ninf, __float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x114, 0xf>(ninf, __float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x118, 0xf>(ninf, __float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x142, 0xa>(ninf, __float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x143, 0xc>(ninf, __float_as_int(v))));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_allsum(float v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v += __int_as_float(dpp_i<0x111, 0xf>(0, __float_as_int(v)));
+    v += __int_as_float(dpp_i<0x112, 0xf>(0, __float_as_int(v)));
+    v += __int_as_float(dpp_i<0x114, 0xf>(0, __float_as_int(v)));
+    v += __int_as_float(dpp_i<0x118, 0xf>(0, __float_as_int(v)));
+    v += __int_as_float(dpp_i<0x142, 0xa>(0, __float_as_int(v)));
+    v += __int_as_float(dpp_i<0x143, 0xc>(0, __float_as_int(v)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// inclusive prefix sum over the 64 lanes of a wave, float64 (both halves travel through the same DPP move)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i<CTRL, ROW_MASK>(0, (int)(b & 0xffffffffll));
+    const int hi = dpp_i<CTRL, ROW_MASK>(0, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_scan_f64(double v) {
+    v += dpp_d<0x111, 0xf>(v);
+    v += dpp_d<0x112, 0xf>(v);
+    v += dpp_d<0x114, 0xf>(v);
+    v += dpp_d<0x118, 0xf>(v);
+    v += dpp_d<0x142, 0xa>(v);       // rows 1,3 += last lane of rows 0,2
+    v += dpp_d<0x143, 0xc>(v);       // rows 2,3 += lane 31
     return v;
 }
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
@@ -292,25 +325,46 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
         lds_barrier();
         STAMP(3);
         if (do_sample) {
-            if (tid == 0) {                        // numpy's float64 running sum, in index order
-                double c = 0.0;
-#pragma unroll 1
-                for (int i = 0; i < 256; i += 16) {     // batches of 16 so the LDS reads are pipelined
-                    float t[16];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) t[e] = lg[i + e];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) { c += (double)t[e]; cdf[i + e] = c; }
+            // numpy: cdf = cumsum(float64(p)); cdf /= cdf[-1]; first index with cdf > u.  The running sum is a
+            // 256-long dependent chain (9.5 k cycles); a parallel scan associates differently, so its cdf may differ
+            // from numpy's by a few ulp (<= 256 * 2^-53).  It is therefore used only when no cdf_i / total lies within
+            // 1e-12 of u -- then both orders give the same index, provably -- and the exact chain runs otherwise.
+            double c = wave_scan_f64((double)lg[tid]);
+            if (lane == 63) cdf[wv] = c;                   // wave totals
+            lds_barrier();
+            {
+                const double w0 = cdf[0], w1 = cdf[1], w2 = cdf[2], w3 = cdf[3];
+                c += wv > 0 ? w0 : 0.0;
+                c += wv > 1 ? w1 : 0.0;
+                c += wv > 2 ? w2 : 0.0;
+                const double tot = ((w0 + w1) + w2) + w3;
+                const double q = c / tot;
+                const bool gt = q > u_draw;
+                const bool near = fabs(q - u_draw) < 1e-12;
+                const unsigned long long bal = __ballot(gt), nb = __ballot(near);
+                if (lane == 0) {
+                    reinterpret_cast<int*>(red)[8 + wv] = bal ? wv * 64 + __ffsll((long long)bal) - 1 : 256;
+                    reinterpret_cast<int*>(red)[12 + wv] = nb ? 1 : 0;
                 }
             }
             lds_barrier();
-            {
-                const double tot = cdf[255];
-                const bool gt = cdf[tid] / tot > u_draw;
-                const unsigned long long bal = __ballot(gt);
-                if (lane == 0) reinterpret_cast<int*>(red)[8 + wv] = bal ? wv * 64 + __ffsll((long long)bal) - 1 : 256;
+            const int* rr = reinterpret_cast<const int*>(red);
+            const bool ambiguous = (rr[12] | rr[13] | rr[14] | rr[15]) != 0;     // uniform over the workgroup
+            if (ambiguous) {
+                if (tid == 0) {                    // numpy's float64 running sum, in index order
+                    double cs = 0.0;
+                    for (int i = 0; i < 256; ++i) { cs += (double)lg[i]; cdf[i] = cs; }
+                }
+                lds_barrier();
+                {
+                    const double tot = cdf[255];
+                    const bool gt = cdf[tid] / tot > u_draw;
+                    const unsigned long long bal = __ballot(gt);
+                    lds_barrier();
+                    if (lane == 0) reinterpret_cast<int*>(red)[8 + wv] = bal ? wv * 64 + __ffsll((long long)bal) - 1 : 256;
+                }
+                lds_barrier();
             }
-            lds_barrier();
             if (tid == 0) {
                 const int* r = reinterpret_cast<const int*>(red) + 8;
                 int idx = min(min(r[0], r[1]), min(r[2], r[3]));

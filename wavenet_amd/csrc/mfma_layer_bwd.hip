@@ -52,7 +52,6 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p1(
         const int t0 = (tile - b * tiles_per_b) * 32;
         const int t = t0 + j;
         const bool valid = t < T;
-        const long long row = ((long long)b * T + t) * 32 + 4 * h;
         const long long rowc = ((long long)b * T + (valid ? t : T - 1)) * 32 + 4 * h;   // clamped: loads are unconditional
         f32x16 acc;
         float ff[16], gg[16], dob[16];
