@@ -13,6 +13,9 @@
 //   workgroup's waves in LDS and leave as one set of float atomics per workgroup.
 // Pass 2 (k_layer_bwd_p2):  dx[t] = dout[t] + [Wf1;Wg1]^T dab[t] + [Wf0;Wg0]^T dab[t+d]
 //   -- the forward kernel's structure with transposed weights (64 MFMAs per tile).
+#include <cstdlib>
+#include <cstring>
+
 #include "wn_kernels.hpp"
 
 namespace wn {
@@ -331,6 +334,243 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_chain(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Same maths, second structure (the one the stack uses): 8 waves per workgroup, one workgroup per CU, 148 KB of LDS.
+// What the s_memtime stamps of the kernel above showed (cycles per wave and tile, 2 tiles per wave): ~15,000 waiting for
+// the 96 channel-on-lanes operand loads of the weight gradients -- they queue behind the V/U stores in vmcnt order
+// and re-read five tensors L2 no longer holds (165 MB fetched per launch for 117 MB of distinct data) -- against
+// 10,240 cycles of MFMA.  Here every tensor is fetched from memory exactly once:
+//   * f, g, dz, V, U: float4 per lane (time on lanes), prefetched one tile ahead into registers;
+//   * x[t], x[t-d]: only the weight gradients need them, channel on lanes -- LDS-DMA (global_load_lds, 1 KB
+//     contiguous per instruction, no registers) into a per-wave tile, issued at the top of the tile;
+//   * da, dg, then dout, z = f g: transposed through two per-wave 4 KB patches (XOR-swizzled float4 columns:
+//     conflict-free both for the float4 writes, time on lanes, and the scalar reads, channel on lanes);
+//   * weights: raw Wf/Wg/Wp copied to LDS with coalesced float4 loads; Wf[cd][cr][0..1] is one ds_read_b64 that
+//     yields the A operands of both the V (tap 1) and the U (tap 0) MFMA.
+// ---------------------------------------------------------------------------------------------
+static constexpr int kCWaves = 4;
+static constexpr int kCWaveFloats = 4096;                       // xc tile, xo tile, patch A, patch B
+static constexpr int kCWFloats = 2048 + 2048 + 1024;            // Wf, Wg, Wp
+static constexpr int kCLdsBytes = (kCWFloats + kCWaves * kCWaveFloats) * 4;
+static constexpr int kCMaxBlocks = 256;
+
+struct ChainPF { float4 f[4], g[4], z[4], v[4], u[4]; };
+
+template <bool HAS_DO, bool HAS_U, bool HAS_DZ>
+__global__ __launch_bounds__(64 * kCWaves, 1) void k_layer_bwd_chain8(
+    const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
+    const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
+    const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, const float* __restrict__ dzs,
+    float* __restrict__ Vout, float* __restrict__ Uout, float* __restrict__ part, int B, int T, int d, int Z,
+    int tiles_per_b, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float* lWf = dyn;
+    float* lWg = dyn + 2048;
+    float* lWp = dyn + 4096;
+    float* wbase = dyn + kCWFloats;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    float* xsc = wbase + wv * kCWaveFloats;
+    float* xso = xsc + 1024;
+    float* pa = xsc + 2048;
+    float* pb = xsc + 3072;
+    const int wave = blockIdx.x * kCWaves + wv;
+    const int nwaves = gridDim.x * kCWaves;
+    constexpr int kPFOps = 4 * (2 + (HAS_DZ ? 1 : 0) + (HAS_DO ? 1 : 0) + (HAS_U ? 1 : 0));
+
+    // phase-A operands of a tile (time on lanes): unconditional loads from clamped rows, masked at use
+    auto load_a = [&](int tile, ChainPF& p) {
+        const int b = tile / tiles_per_b;
+        const int t = (tile - b * tiles_per_b) * 32 + j;
+        const int tc = t < T ? t : T - 1;
+        const long long rowc = ((long long)b * T + tc) * 32 + 4 * h;
+        const long long rowu = ((long long)b * T + (tc + dU < T ? tc + dU : T - 1)) * 32 + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            p.f[q] = *reinterpret_cast<const float4*>(f + rowc + 8 * q);
+            p.g[q] = *reinterpret_cast<const float4*>(g + rowc + 8 * q);
+            if (HAS_DZ) p.z[q] = *reinterpret_cast<const float4*>(dzs + rowc + 8 * q);
+            if (HAS_DO) p.v[q] = *reinterpret_cast<const float4*>(Vin + rowc + 8 * q);
+            if (HAS_U) p.u[q] = *reinterpret_cast<const float4*>(Uin + rowu + 8 * q);
+        }
+    };
+
+    // ---- weights -> LDS (coalesced), first tile's operands in flight meanwhile -------------------
+    constexpr int kThreads = 64 * kCWaves;
+    float4 s_wf[512 / kThreads], s_wg[512 / kThreads];
+#pragma unroll
+    for (int k = 0; k < 512 / kThreads; ++k) {
+        s_wf[k] = reinterpret_cast<const float4*>(Wf)[threadIdx.x + k * kThreads];
+        s_wg[k] = reinterpret_cast<const float4*>(Wg)[threadIdx.x + k * kThreads];
+    }
+    const float4 s_wp = reinterpret_cast<const float4*>(Wp)[threadIdx.x & 255];
+    ChainPF cur;
+    if (wave < ntiles) load_a(wave, cur);
+#pragma unroll
+    for (int k = 0; k < 512 / kThreads; ++k) {
+        reinterpret_cast<float4*>(lWf)[threadIdx.x + k * kThreads] = s_wf[k];
+        reinterpret_cast<float4*>(lWg)[threadIdx.x + k * kThreads] = s_wg[k];
+    }
+    if (threadIdx.x < 256) reinterpret_cast<float4*>(lWp)[threadIdx.x] = s_wp;
+    __syncthreads();
+
+    f32x16 aWf0, aWf1, aWg0, aWg1, aWp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aWf0[r] = 0.f; aWf1[r] = 0.f; aWg0[r] = 0.f; aWg1[r] = 0.f; aWp[r] = 0.f; }
+
+    for (int tile = wave; tile < ntiles; tile += nwaves) {
+        const int b = tile / tiles_per_b;
+        const int t0 = (tile - b * tiles_per_b) * 32;
+        const int t = t0 + j;
+        const bool valid = t < T;
+        const bool more = tile + nwaves < ntiles;
+        // x[t] and x[t-d] of the tile -> LDS, row-major (lane L of piece k: row 8k + L/8, 16-byte chunk L%8)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int tt = t0 + 8 * k + (lane >> 3);
+            const int ttc = tt < T ? tt : T - 1;
+            const int tto = ttc - d >= 0 ? ttc - d : 0;
+            const float* sc = x + ((long long)b * T + ttc) * 32 + (lane & 7) * 4;
+            const float* so = x + ((long long)b * T + tto) * 32 + (lane & 7) * 4;
+            __builtin_amdgcn_global_load_lds(sc, (__attribute__((address_space(3))) void*)(xsc + k * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(so, (__attribute__((address_space(3))) void*)(xso + k * 256), 16, 0, 0);
+        }
+        const float mu = (HAS_U && valid && t + dU < T) ? 1.f : 0.f;
+        f32x16 acc;
+        float ff[16], gg[16], dob[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 z4 = make_float4(0, 0, 0, 0), o4 = z4;
+            if (HAS_DZ) z4 = cur.z[q];
+            if (HAS_DO) o4 = cur.v[q];
+            if (HAS_U) { o4.x += cur.u[q].x * mu; o4.y += cur.u[q].y * mu; o4.z += cur.u[q].z * mu; o4.w += cur.u[q].w * mu; }
+            acc[4 * q] = z4.x; acc[4 * q + 1] = z4.y; acc[4 * q + 2] = z4.z; acc[4 * q + 3] = z4.w;
+            ff[4 * q] = cur.f[q].x; ff[4 * q + 1] = cur.f[q].y; ff[4 * q + 2] = cur.f[q].z; ff[4 * q + 3] = cur.f[q].w;
+            gg[4 * q] = cur.g[q].x; gg[4 * q + 1] = cur.g[q].y; gg[4 * q + 2] = cur.g[q].z; gg[4 * q + 3] = cur.g[q].w;
+            dob[4 * q] = o4.x; dob[4 * q + 1] = o4.y; dob[4 * q + 2] = o4.z; dob[4 * q + 3] = o4.w;
+        }
+        if (HAS_DO || HAS_U) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lWp[bch(s, h) * 32 + j], dob[s], acc, 0, 0, 0);
+        }
+        const bool live = valid && t >= Z;
+        float da[16], dg[16], zz[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float dz = live ? acc[r] : 0.f;
+            da[r] = dz * gg[r] * (1.f - ff[r] * ff[r]);
+            dg[r] = dz * ff[r] * gg[r] * (1.f - gg[r]);
+            zz[r] = ff[r] * gg[r];
+        }
+        // V = dout + [Wf1;Wg1]^T dab,  U = [Wf0;Wg0]^T dab
+        f32x16 v1, u0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { v1[r] = dob[r]; u0[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float2 wf = *reinterpret_cast<const float2*>(lWf + (bch(s, h) * 32 + j) * 2);
+            const float2 wg = *reinterpret_cast<const float2*>(lWg + (bch(s, h) * 32 + j) * 2);
+            v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, da[s], v1, 0, 0, 0);
+            u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, da[s], u0, 0, 0, 0);
+            v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.y, dg[s], v1, 0, 0, 0);
+            u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.x, dg[s], u0, 0, 0, 0);
+        }
+        // transposed patches of (da, dg): float4 column c of row j sits at column c ^ (j & 7)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
+            *reinterpret_cast<float4*>(pa + o) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
+            *reinterpret_cast<float4*>(pb + o) = make_float4(dg[4 * q], dg[4 * q + 1], dg[4 * q + 2], dg[4 * q + 3]);
+        }
+        // next tile's operands: issued BEFORE this tile's stores, so that waiting for them never waits for a store
+        ChainPF nxt;
+        if (more) load_a(tile + nwaves, nxt);
+        if (valid) {
+            const long long row = ((long long)b * T + t) * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                *reinterpret_cast<float4*>(Vout + row + 8 * q) = make_float4(v1[4 * q], v1[4 * q + 1], v1[4 * q + 2], v1[4 * q + 3]);
+                *reinterpret_cast<float4*>(Uout + row + 8 * q) = make_float4(u0[4 * q], u0[4 * q + 1], u0[4 * q + 2], u0[4 * q + 3]);
+            }
+        }
+        // the x tiles must have landed (vector-memory operations retire in order: everything issued after the
+        // eight DMA pieces may stay in flight)
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPFOps + 8) : "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // weight gradients: contraction over the tile's 32 columns, step s covers columns 2s and 2s+1
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int r = 2 * s + h;
+            const int tt = t0 + r;
+            const float mv = tt < T ? 1.f : 0.f, mo = (tt < T && tt - d >= 0) ? 1.f : 0.f;
+            const int po = r * 32 + ((((j >> 2) ^ (r & 7)) << 2) | (j & 3));
+            const float a_da = pa[po], a_dg = pb[po];
+            const float b_xc = xsc[r * 32 + j] * mv, b_xo = xso[r * 32 + j] * mo;
+            aWf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xc, aWf1, 0, 0, 0);
+            aWf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xo, aWf0, 0, 0, 0);
+            aWg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xc, aWg1, 0, 0, 0);
+            aWg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xo, aWg0, 0, 0, 0);
+        }
+        if (HAS_DO || HAS_U) {                       // dWp += dout z^T through the same two patches
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
+                const float mvj = valid ? 1.f : 0.f;
+                *reinterpret_cast<float4*>(pa + o) = make_float4(dob[4 * q] * mvj, dob[4 * q + 1] * mvj, dob[4 * q + 2] * mvj, dob[4 * q + 3] * mvj);
+                *reinterpret_cast<float4*>(pb + o) = make_float4(zz[4 * q], zz[4 * q + 1], zz[4 * q + 2], zz[4 * q + 3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int r = 2 * s + h;
+                const int po = r * 32 + ((((j >> 2) ^ (r & 7)) << 2) | (j & 3));
+                aWp = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[po], pb[po], aWp, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (more) cur = nxt;
+    }
+
+    // ---- sum the five accumulators over the eight waves (tree through the per-wave LDS space) -----
+    __syncthreads();
+    for (int half = kCWaves / 2; half >= 1; half >>= 1) {
+        if (wv >= half && wv < 2 * half) {
+            float* red = wbase + (wv - half) * kPartFloats;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                red[(0 * 16 + r) * 64 + lane] = aWf0[r]; red[(1 * 16 + r) * 64 + lane] = aWf1[r];
+                red[(2 * 16 + r) * 64 + lane] = aWg0[r]; red[(3 * 16 + r) * 64 + lane] = aWg1[r];
+                red[(4 * 16 + r) * 64 + lane] = aWp[r];
+            }
+        }
+        __syncthreads();
+        if (wv < half) {
+            const float* red = wbase + wv * kPartFloats;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                aWf0[r] += red[(0 * 16 + r) * 64 + lane]; aWf1[r] += red[(1 * 16 + r) * 64 + lane];
+                aWg0[r] += red[(2 * 16 + r) * 64 + lane]; aWg1[r] += red[(3 * 16 + r) * 64 + lane];
+                aWp[r] += red[(4 * 16 + r) * 64 + lane];
+            }
+        }
+        __syncthreads();
+    }
+    if (wv == 0) {
+        float* __restrict__ o = part + (long long)blockIdx.x * kPartFloats + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o[(0 * 16 + r) * 64] = aWf0[r]; o[(1 * 16 + r) * 64] = aWf1[r];
+            o[(2 * 16 + r) * 64] = aWg0[r]; o[(3 * 16 + r) * 64] = aWg1[r];
+            o[(4 * 16 + r) * 64] = aWp[r];
+        }
+    }
+}
+
 // dx[t] = V[t] + U[t + dU]   (the split gradient of the stack input, materialised once at the bottom)
 __global__ void k_chain_combine(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ dx,
                                 int B, int T, int dU) {
@@ -471,11 +711,24 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
     WN_CHECK_SHAPE(nt < (1ll << 31), "mfma_layer_bwd_chain: too many tiles");
     WN_CHECK_ARG(Vin || Uin || dzs, "mfma_layer_bwd_chain: no incoming gradient");
     const int ntiles = (int)nt;
-    int blocks = (ntiles + 3) / 4;
-    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    static const bool old_kernel = [] { const char* e = getenv("WAVENET_HIP_CHAIN"); return e && !strcmp(e, "old"); }();
+    int blocks = old_kernel ? (ntiles + 3) / 4 : (ntiles + kCWaves - 1) / kCWaves;
+    const int maxb = old_kernel ? kMaxBlocks : kCMaxBlocks;
+    if (blocks > maxb) blocks = maxb;
 #define CH_LAUNCH(DO, UU, DZ)                                                                                      \
-    hipLaunchKernelGGL((k_layer_bwd_chain<DO, UU, DZ>), dim3(blocks), dim3(256), 0, s, x, f, g, Wp, Wf, Wg, Vin, Uin, dU, \
-                       dzs, Vout, Uout, part, B, T, d, Z, tiles_per_b, ntiles)
+    if (old_kernel) {                                                                                              \
+        hipLaunchKernelGGL((k_layer_bwd_chain<DO, UU, DZ>), dim3(blocks), dim3(256), 0, s, x, f, g, Wp, Wf, Wg, Vin, Uin, \
+                           dU, dzs, Vout, Uout, part, B, T, d, Z, tiles_per_b, ntiles);                            \
+    } else {                                                                                                       \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) {                                                                                           \
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chain8<DO, UU, DZ>),              \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kCLdsBytes));                   \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
+        hipLaunchKernelGGL((k_layer_bwd_chain8<DO, UU, DZ>), dim3(blocks), dim3(64 * kCWaves), kCLdsBytes, s, x, f, g, Wp, \
+                           Wf, Wg, Vin, Uin, dU, dzs, Vout, Uout, part, B, T, d, Z, tiles_per_b, ntiles);          \
+    }
     const int key = (Vin ? 4 : 0) | (Uin ? 2 : 0) | (dzs ? 1 : 0);
     switch (key) {
         case 7: CH_LAUNCH(true, true, true); break;
