@@ -24,7 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from wavenet_amd import FasterWaveNet, Params, _lib, data     # noqa: E402
+from wavenet_amd import FasterWaveNet, Params, TrainStepGraph, _lib, data     # noqa: E402
 
 CFG2 = dict(quantization_steps=256, sampling_rate=16000, causal_conv_channels=[32],
             residual_conv_channels=[32] * 10, residual_num_blocks=4, softmax_conv_channels=[256, 256])
@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--decode-samples", type=int, default=16000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="time op-by-op launches instead of hipGraph replays")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,23 +155,41 @@ def main():
     assert _lib.lib().wn_layer_fast_path(32, 32, 2) == 1
 
     # ---- the timed region: K training steps ------------------------------------------------
+    # Default: the step is captured once into a HIP graph (wavenet_amd.TrainStepGraph: cleargrads, forward, loss,
+    # backward, clip + Adam; with N > 1 the RCCL all-reduce runs between a forward/backward graph and an optimiser
+    # graph) and each timed step is one replay.  --no-graph times the same step launched op by op.
+    graph = None
+    if not args.no_graph:
+        try:
+            graph = TrainStepGraph(net, x, tgt)
+        except Exception as e:                                           # keep the bench alive: fall back to op-by-op
+            sys.stderr.write("graph capture failed (%s: %s); timing op-by-op launches\n" % (type(e).__name__, e))
+            graph = None
+    step_fn = (lambda: graph.step()) if graph is not None else (lambda: train_step(net, x, tgt, iw))
     for _ in range(args.warmup):
-        train_step(net, x, tgt, iw)
+        step_fn()
     if barrier:
         barrier()
     torch.cuda.synchronize()
-    with _lib.profile() as prof:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = train_step(net, x, tgt, iw)
-        if barrier:
-            barrier()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / args.steps
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step_fn()
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # ---- the same K steps launched op by op under the in-library HIP-event profiler: per-entry-point kernel time
+    # (events on the launch stream around every C-ABI call; a replayed graph has no host code to record them)
+    with _lib.profile() as prof:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            train_step(net, x, tgt, iw)
+        torch.cuda.synchronize()
+        eager_dt = (time.perf_counter() - t0) / args.steps
     per_step = {k: v[1] / args.steps for k, v in prof.result().items()}  # ms of each entry point per step
     samples = world * B_PER_GPU * T
     value = samples / dt
@@ -187,6 +206,9 @@ def main():
                                "fwd + bwd + clip + Adam%s" % (B_PER_GPU, " + RCCL all-reduce" if world > 1 else ""),
                    "global_batch": world * B_PER_GPU, "seq_len": T, "parallelism": "dp%d" % world},
         "loss": float(loss.detach()),
+        "launch": ("hipGraph replay, one graph launch per step" + (" (fwd+bwd graph, RCCL all-reduce, optimiser graph)"
+                   if world > 1 else "")) if graph is not None else "op-by-op launches from Python",
+        "eager_ms_per_step": eager_dt * 1e3,
         "entry_point_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
     }
 
@@ -224,7 +246,7 @@ def main():
         units = {
             # name: (bound, algorithmic amount per launch, launches per step, kernels for PMC traffic)
             "wn_layer_bwd": ("hbm", es * (3 * Cr + Cs + 2 * Cd) * n_col, nl,
-                             ["wn::k_layer_bwd_chain<true, true, true>", "wn::k_layer_bwd_reduce"]),
+                             ["wn::k_layer_bwd_chain8<true, true, true>", "wn::k_layer_bwd_reduce"]),
             "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl, ["wn::k_layer_fwd_mfma32<true, false>"]),
             "wn_skip_sum_fwd": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<0>"]),
             "wn_skip_sum_bwd_dw": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_wgrad_b3<4>"]),

@@ -215,6 +215,11 @@ int wn_sqnorm(const float* grad, const float* param, int64_t n, float grad_mult,
 int wn_adam_step(float* param, const float* grad, float* m, float* v, int64_t n,
                  float lr_t, float beta1, float beta2, float eps, float weight_decay,
                  const float* sqnorm, float clip, float grad_mult, void* stream);
+/* The same update with the step size read from device memory (*lr_t_dev) at execution time: a training step
+ * captured once into a hipGraph is replayed with a fresh bias-corrected step size by writing that scalar.  */
+int wn_adam_step_dev(float* param, const float* grad, float* m, float* v, int64_t n,
+                     const float* lr_t_dev, float beta1, float beta2, float eps, float weight_decay,
+                     const float* sqnorm, float clip, float grad_mult, void* stream);
 
 /* ---- measurement aid (bench.py): per-entry-point HIP-event timing on the caller's stream ------- */
 int wn_prof_enable(int on);                    /* 1: clear + start recording, 0: stop               */

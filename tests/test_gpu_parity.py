@@ -571,6 +571,39 @@ def test_fast_decoder_sampler_boundary_fallback():
         assert t2[step] == want, (step, shift, t2[step], want, j)
 
 
+def test_train_step_graph_replay_equals_eager_steps():
+    """wavenet_amd.TrainStepGraph: the captured-and-replayed step (batch and Adam step size fed through device
+    memory) must train exactly like net.backprop() called op by op, including the changing bias correction."""
+    from wavenet_amd import TrainStepGraph
+    from wavenet_amd.graph import default_loss
+    over = dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 4,
+                residual_num_blocks=2, softmax_conv_channels=[256, 256])
+    p, w, eager = build(over, seed=21)
+    _, _, graphed = build(over, seed=21)
+    for n in (eager, graphed):
+        n.update_laerning_rate(0.01)
+    B, T = 2, 700
+    iw = eager.input_width
+    rs = np.random.RandomState(0)
+    batches = [(dev(rs.randint(0, 256, (B, T)).astype(np.int32)), dev(rs.randint(0, 256, (B, T - iw)).astype(np.int32)))
+               for _ in range(4)]
+    w0 = to_np(graphed._arena).copy()
+    g = TrainStepGraph(graphed, *batches[0])
+    np.testing.assert_array_equal(to_np(graphed._arena), w0)          # capture + warm-up did not train
+    assert graphed.optimizer.t == 0
+    for x, tg in batches:
+        eager.backprop(default_loss(eager, x, tg))
+        le = default_loss(eager, x, tg)                               # loss AFTER the update, eager
+        lg_before = g.step(x, tg)
+        lg = default_loss(graphed, x, tg)
+        assert abs(float(le.detach()) - float(lg.detach())) < 2e-5
+        assert np.isfinite(float(lg_before))
+    assert graphed.optimizer.t == eager.optimizer.t == 4
+    a, b = to_np(eager._arena), to_np(graphed._arena)
+    assert np.abs(a - w0).max() > 1e-3                                # the weights did move
+    np.testing.assert_allclose(b, a, atol=2e-5)
+
+
 def test_config5_topology_fp32_forward_and_grads():
     """BASELINE config 5's widths (128 residual / 512 skip) run through the generic layer kernel and the fp32
     MFMA channel GEMMs; parity in fp32 (the bf16 MFMA layer kernel for this shape is a later round)."""

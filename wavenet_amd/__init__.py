@@ -6,4 +6,5 @@
 from .wavenet import Params, WaveNet, zero_prefix      # noqa: F401
 from .faster_wavenet import FasterWaveNet              # noqa: F401
 from . import data                                     # noqa: F401
+from .graph import TrainStepGraph                      # noqa: F401
 from ._lib import WaveNetHipError                      # noqa: F401

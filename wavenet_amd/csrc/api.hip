@@ -236,7 +236,17 @@ int wn_adam_step(float* param, const float* grad, float* m, float* v, int64_t n,
     NN(param); NN(grad); NN(m); NN(v);
     WN_CHECK_ARG(n > 0, "wn_adam_step: n <= 0");
     return generic_adam(param, grad, m, v, n, lr_t, beta1, beta2, eps, weight_decay, sqnorm, clip, grad_mult,
-                        as_stream(stream));
+                        nullptr, as_stream(stream));
+}
+
+int wn_adam_step_dev(float* param, const float* grad, float* m, float* v, int64_t n, const float* lr_t_dev,
+                     float beta1, float beta2, float eps, float weight_decay, const float* sqnorm, float clip,
+                     float grad_mult, void* stream) {
+    wn::ProfScope prof__("wn_adam_step", stream);
+    NN(param); NN(grad); NN(m); NN(v); NN(lr_t_dev);
+    WN_CHECK_ARG(n > 0, "wn_adam_step_dev: n <= 0");
+    return generic_adam(param, grad, m, v, n, 0.f, beta1, beta2, eps, weight_decay, sqnorm, clip, grad_mult,
+                        lr_t_dev, as_stream(stream));
 }
 
 }  // extern "C"

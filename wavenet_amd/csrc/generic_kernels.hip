@@ -570,8 +570,10 @@ __global__ void k_sqnorm(const float* __restrict__ g, const float* __restrict__ 
 
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                        float* __restrict__ v, long long n, float lr_t, float b1, float b2, float eps,
-                       float wd, const float* __restrict__ sqnorm, float clip, float gmult) {
+                       float wd, const float* __restrict__ sqnorm, float clip, float gmult,
+                       const float* __restrict__ lr_dev) {
     // hook order of wavenet.py:477-480: WeightDecay first, then GradientClipping on the result
+    if (lr_dev) lr_t = *lr_dev;          // captured-graph replays: the step size comes from device memory
     float rate = 1.f;
     if (sqnorm && clip > 0.f) {
         float nrm = sqrtf(*sqnorm);
@@ -851,12 +853,13 @@ int generic_sqnorm(const float* g, const float* p, long long n, float gmult, flo
 }
 
 int generic_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2,
-                 float eps, float wd, const float* sqnorm, float clip, float gmult, hipStream_t s) {
+                 float eps, float wd, const float* sqnorm, float clip, float gmult, const float* lr_dev,
+                 hipStream_t s) {
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps, wd, sqnorm, clip,
-                       gmult);
+                       gmult, lr_dev);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

@@ -335,26 +335,33 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_chain(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Same maths, second structure (the one the stack uses): 8 waves per workgroup, one workgroup per CU, 148 KB of LDS.
-// What the s_memtime stamps of the kernel above showed (cycles per wave and tile, 2 tiles per wave): ~15,000 waiting for
-// the 96 channel-on-lanes operand loads of the weight gradients -- they queue behind the V/U stores in vmcnt order
-// and re-read five tensors L2 no longer holds (165 MB fetched per launch for 117 MB of distinct data) -- against
-// 10,240 cycles of MFMA.  Here every tensor is fetched from memory exactly once:
-//   * f, g, dz, V, U: float4 per lane (time on lanes), prefetched one tile ahead into registers;
-//   * x[t], x[t-d]: only the weight gradients need them, channel on lanes -- LDS-DMA (global_load_lds, 1 KB
-//     contiguous per instruction, no registers) into a per-wave tile, issued at the top of the tile;
-//   * da, dg, then dout, z = f g: transposed through two per-wave 4 KB patches (XOR-swizzled float4 columns:
-//     conflict-free both for the float4 writes, time on lanes, and the scalar reads, channel on lanes);
+// Same maths, second structure (the one the stack uses): 4 waves per workgroup, one workgroup per CU (one wave per
+// SIMD, 512 registers), 148 KB of LDS.  What the s_memtime stamps of the kernel above showed (cycles per wave and
+// tile): ~15,000 waiting for the 96 channel-on-lanes operand loads of the weight gradients, which queue behind the
+// V/U stores in vmcnt order and re-read five tensors L2 no longer holds (165 MB fetched per launch for 117 MB of
+// distinct data), and 250+ cycles of issue time for EVERY float4 access in the MFMA operand pattern (lane = row,
+// 32 bytes of each of 32 rows per instruction) -- against 10,240 cycles of MFMA.  Here every tensor crosses the
+// memory pipeline exactly once and in whole 128-byte rows:
+//   * f, g, V, U (time on lanes) and x[t], x[t-d] (channel on lanes, for the weight gradients): LDS-DMA
+//     (global_load_lds: lane L of piece k fetches 16 bytes of row 8k + L/8, 1 KB contiguous per instruction, no
+//     registers), the first four one tile ahead.  The time-on-lanes tiles are stored XOR-swizzled (16-byte chunk c
+//     of row r at position c ^ (r & 7), done by permuting the SOURCE addresses), so that the float4 read of lane
+//     (j,h) -- row j, chunks 2q+h -- is bank-conflict free;
+//   * V, U results: written to the swizzled patches, read back row-wise, stored as whole rows;
+//   * da, dg, then dout, z = f g: transposed through the same two patches for the weight gradients;
 //   * weights: raw Wf/Wg/Wp copied to LDS with coalesced float4 loads; Wf[cd][cr][0..1] is one ds_read_b64 that
 //     yields the A operands of both the V (tap 1) and the U (tap 0) MFMA.
+// Vector-memory operations retire in issue order, so "the DMA has landed" is an s_waitcnt vmcnt(N) with N = the
+// number of operations issued after it (always counted conservatively: conditional stores are not counted).
 // ---------------------------------------------------------------------------------------------
 static constexpr int kCWaves = 4;
-static constexpr int kCWaveFloats = 4096;                       // xc tile, xo tile, patch A, patch B
+static constexpr int kCWaveFloats = 8192;                       // f, g, V, U tiles | xc, xo tiles | patch A, patch B
 static constexpr int kCWFloats = 2048 + 2048 + 1024;            // Wf, Wg, Wp
 static constexpr int kCLdsBytes = (kCWFloats + kCWaves * kCWaveFloats) * 4;
 static constexpr int kCMaxBlocks = 256;
 
-struct ChainPF { float4 f[4], g[4], z[4], v[4], u[4]; };
+#define WN_LDS_DMA16(src, dst) \
+    __builtin_amdgcn_global_load_lds((src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
 template <bool HAS_DO, bool HAS_U, bool HAS_DZ>
 __global__ __launch_bounds__(64 * kCWaves, 1) void k_layer_bwd_chain8(
@@ -368,30 +375,44 @@ __global__ __launch_bounds__(64 * kCWaves, 1) void k_layer_bwd_chain8(
     float* lWg = dyn + 2048;
     float* lWp = dyn + 4096;
     float* wbase = dyn + kCWFloats;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // wave-uniform: tile maths on the SALU
     const int j = lane & 31, h = lane >> 5;
-    float* xsc = wbase + wv * kCWaveFloats;
-    float* xso = xsc + 1024;
-    float* pa = xsc + 2048;
-    float* pb = xsc + 3072;
+    float* tf = wbase + wv * kCWaveFloats;
+    float* tg = tf + 1024;
+    float* tv = tf + 2048;
+    float* tu = tf + 3072;
+    float* xsc = tf + 4096;
+    float* xso = tf + 5120;
+    float* pa = tf + 6144;
+    float* pb = tf + 7168;
     const int wave = blockIdx.x * kCWaves + wv;
     const int nwaves = gridDim.x * kCWaves;
-    constexpr int kPFOps = 4 * (2 + (HAS_DZ ? 1 : 0) + (HAS_DO ? 1 : 0) + (HAS_U ? 1 : 0));
+    constexpr int kAOps = 4 * (2 + (HAS_DO ? 1 : 0) + (HAS_U ? 1 : 0));        // DMA pieces of one tile's f, g, V, U
+    constexpr int kZOps = HAS_DZ ? 4 : 0;
+    const int lr = lane >> 3, lp = lane & 7;                                    // DMA: row inside a piece, LDS position
 
-    // phase-A operands of a tile (time on lanes): unconditional loads from clamped rows, masked at use
-    auto load_a = [&](int tile, ChainPF& p) {
+    // f, g, V, U of a tile -> LDS (swizzled), dz -> registers (time on lanes only, nothing to transpose)
+    auto fetch_a = [&](int tile, float4 (&dz4)[4]) {
         const int b = tile / tiles_per_b;
-        const int t = (tile - b * tiles_per_b) * 32 + j;
-        const int tc = t < T ? t : T - 1;
-        const long long rowc = ((long long)b * T + tc) * 32 + 4 * h;
-        const long long rowu = ((long long)b * T + (tc + dU < T ? tc + dU : T - 1)) * 32 + 4 * h;
+        const int t0 = (tile - b * tiles_per_b) * 32;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            p.f[q] = *reinterpret_cast<const float4*>(f + rowc + 8 * q);
-            p.g[q] = *reinterpret_cast<const float4*>(g + rowc + 8 * q);
-            if (HAS_DZ) p.z[q] = *reinterpret_cast<const float4*>(dzs + rowc + 8 * q);
-            if (HAS_DO) p.v[q] = *reinterpret_cast<const float4*>(Vin + rowc + 8 * q);
-            if (HAS_U) p.u[q] = *reinterpret_cast<const float4*>(Uin + rowu + 8 * q);
+        for (int k = 0; k < 4; ++k) {
+            const int r = 8 * k + lr;
+            const int tt = t0 + r;
+            const int ttc = tt < T ? tt : T - 1;
+            const int ttu = ttc + dU < T ? ttc + dU : T - 1;
+            const long long o = ((long long)b * T + ttc) * 32 + ((lp ^ (r & 7)) << 2);
+            WN_LDS_DMA16(f + o, tf + k * 256);
+            WN_LDS_DMA16(g + o, tg + k * 256);
+            if (HAS_DO) WN_LDS_DMA16(Vin + o, tv + k * 256);
+            if (HAS_U) WN_LDS_DMA16(Uin + ((long long)b * T + ttu) * 32 + ((lp ^ (r & 7)) << 2), tu + k * 256);
+        }
+        if (HAS_DZ) {
+            const int t = t0 + j;
+            const long long rowc = ((long long)b * T + (t < T ? t : T - 1)) * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dz4[q] = *reinterpret_cast<const float4*>(dzs + rowc + 8 * q);
         }
     };
 
@@ -404,8 +425,8 @@ __global__ __launch_bounds__(64 * kCWaves, 1) void k_layer_bwd_chain8(
         s_wg[k] = reinterpret_cast<const float4*>(Wg)[threadIdx.x + k * kThreads];
     }
     const float4 s_wp = reinterpret_cast<const float4*>(Wp)[threadIdx.x & 255];
-    ChainPF cur;
-    if (wave < ntiles) load_a(wave, cur);
+    float4 dzc[4], dzn[4];
+    if (wave < ntiles) fetch_a(wave, dzc);
 #pragma unroll
     for (int k = 0; k < 512 / kThreads; ++k) {
         reinterpret_cast<float4*>(lWf)[threadIdx.x + k * kThreads] = s_wf[k];
@@ -424,31 +445,40 @@ __global__ __launch_bounds__(64 * kCWaves, 1) void k_layer_bwd_chain8(
         const int t = t0 + j;
         const bool valid = t < T;
         const bool more = tile + nwaves < ntiles;
-        // x[t] and x[t-d] of the tile -> LDS, row-major (lane L of piece k: row 8k + L/8, 16-byte chunk L%8)
+        // x[t] and x[t-d] of the tile -> LDS, row-major, not swizzled (only read channel-on-lanes)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int tt = t0 + 8 * k + (lane >> 3);
+            const int tt = t0 + 8 * k + lr;
             const int ttc = tt < T ? tt : T - 1;
             const int tto = ttc - d >= 0 ? ttc - d : 0;
-            const float* sc = x + ((long long)b * T + ttc) * 32 + (lane & 7) * 4;
-            const float* so = x + ((long long)b * T + tto) * 32 + (lane & 7) * 4;
-            __builtin_amdgcn_global_load_lds(sc, (__attribute__((address_space(3))) void*)(xsc + k * 256), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(so, (__attribute__((address_space(3))) void*)(xso + k * 256), 16, 0, 0);
+            WN_LDS_DMA16(x + ((long long)b * T + ttc) * 32 + lp * 4, xsc + k * 256);
+            WN_LDS_DMA16(x + ((long long)b * T + tto) * 32 + lp * 4, xso + k * 256);
         }
+        // this tile's f, g, V, U (and dz) were issued before the eight x pieces
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         const float mu = (HAS_U && valid && t + dU < T) ? 1.f : 0.f;
         f32x16 acc;
         float ff[16], gg[16], dob[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
             float4 z4 = make_float4(0, 0, 0, 0), o4 = z4;
-            if (HAS_DZ) z4 = cur.z[q];
-            if (HAS_DO) o4 = cur.v[q];
-            if (HAS_U) { o4.x += cur.u[q].x * mu; o4.y += cur.u[q].y * mu; o4.z += cur.u[q].z * mu; o4.w += cur.u[q].w * mu; }
+            const float4 f4 = *reinterpret_cast<const float4*>(tf + o);
+            const float4 g4 = *reinterpret_cast<const float4*>(tg + o);
+            if (HAS_DZ) z4 = dzc[q];
+            if (HAS_DO) o4 = *reinterpret_cast<const float4*>(tv + o);
+            if (HAS_U) {
+                const float4 u4 = *reinterpret_cast<const float4*>(tu + o);
+                o4.x += u4.x * mu; o4.y += u4.y * mu; o4.z += u4.z * mu; o4.w += u4.w * mu;
+            }
             acc[4 * q] = z4.x; acc[4 * q + 1] = z4.y; acc[4 * q + 2] = z4.z; acc[4 * q + 3] = z4.w;
-            ff[4 * q] = cur.f[q].x; ff[4 * q + 1] = cur.f[q].y; ff[4 * q + 2] = cur.f[q].z; ff[4 * q + 3] = cur.f[q].w;
-            gg[4 * q] = cur.g[q].x; gg[4 * q + 1] = cur.g[q].y; gg[4 * q + 2] = cur.g[q].z; gg[4 * q + 3] = cur.g[q].w;
+            ff[4 * q] = f4.x; ff[4 * q + 1] = f4.y; ff[4 * q + 2] = f4.z; ff[4 * q + 3] = f4.w;
+            gg[4 * q] = g4.x; gg[4 * q + 1] = g4.y; gg[4 * q + 2] = g4.z; gg[4 * q + 3] = g4.w;
             dob[4 * q] = o4.x; dob[4 * q + 1] = o4.y; dob[4 * q + 2] = o4.z; dob[4 * q + 3] = o4.w;
         }
+        // the tiles are in registers: the next tile's may overwrite them (issued before this tile's stores)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (more) fetch_a(tile + nwaves, dzn);
         if (HAS_DO || HAS_U) {
 #pragma unroll
             for (int s = 0; s < 16; ++s)
@@ -476,28 +506,37 @@ __global__ __launch_bounds__(64 * kCWaves, 1) void k_layer_bwd_chain8(
             v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.y, dg[s], v1, 0, 0, 0);
             u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.x, dg[s], u0, 0, 0, 0);
         }
-        // transposed patches of (da, dg): float4 column c of row j sits at column c ^ (j & 7)
+        // V, U leave through the patches as whole rows
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
+            *reinterpret_cast<float4*>(pa + o) = make_float4(v1[4 * q], v1[4 * q + 1], v1[4 * q + 2], v1[4 * q + 3]);
+            *reinterpret_cast<float4*>(pb + o) = make_float4(u0[4 * q], u0[4 * q + 1], u0[4 * q + 2], u0[4 * q + 3]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 8 * k + lr;
+            const float4 vv = *reinterpret_cast<const float4*>(pa + k * 256 + lane * 4);
+            const float4 uu = *reinterpret_cast<const float4*>(pb + k * 256 + lane * 4);
+            if (t0 + r < T) {
+                const long long o = ((long long)b * T + t0 + r) * 32 + ((lp ^ (r & 7)) << 2);
+                *reinterpret_cast<float4*>(Vout + o) = vv;
+                *reinterpret_cast<float4*>(Uout + o) = uu;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // transposed patches of (da, dg)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
             *reinterpret_cast<float4*>(pa + o) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
             *reinterpret_cast<float4*>(pb + o) = make_float4(dg[4 * q], dg[4 * q + 1], dg[4 * q + 2], dg[4 * q + 3]);
         }
-        // next tile's operands: issued BEFORE this tile's stores, so that waiting for them never waits for a store
-        ChainPF nxt;
-        if (more) load_a(tile + nwaves, nxt);
-        if (valid) {
-            const long long row = ((long long)b * T + t) * 32 + 4 * h;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                *reinterpret_cast<float4*>(Vout + row + 8 * q) = make_float4(v1[4 * q], v1[4 * q + 1], v1[4 * q + 2], v1[4 * q + 3]);
-                *reinterpret_cast<float4*>(Uout + row + 8 * q) = make_float4(u0[4 * q], u0[4 * q + 1], u0[4 * q + 2], u0[4 * q + 3]);
-            }
-        }
-        // the x tiles must have landed (vector-memory operations retire in order: everything issued after the
-        // eight DMA pieces may stay in flight)
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPFOps + 8) : "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // the x tiles must have landed: after them went the next tile's operands (if any) and the (uncounted) stores
+        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAOps + kZOps) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // weight gradients: contraction over the tile's 32 columns, step s covers columns 2s and 2s+1
@@ -516,10 +555,10 @@ __global__ __launch_bounds__(64 * kCWaves, 1) void k_layer_bwd_chain8(
         }
         if (HAS_DO || HAS_U) {                       // dWp += dout z^T through the same two patches
             __builtin_amdgcn_wave_barrier();
+            const float mvj = valid ? 1.f : 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
-                const float mvj = valid ? 1.f : 0.f;
                 *reinterpret_cast<float4*>(pa + o) = make_float4(dob[4 * q] * mvj, dob[4 * q + 1] * mvj, dob[4 * q + 2] * mvj, dob[4 * q + 3] * mvj);
                 *reinterpret_cast<float4*>(pb + o) = make_float4(zz[4 * q], zz[4 * q + 1], zz[4 * q + 2], zz[4 * q + 3]);
             }
@@ -533,10 +572,13 @@ __global__ __launch_bounds__(64 * kCWaves, 1) void k_layer_bwd_chain8(
             }
         }
         __builtin_amdgcn_wave_barrier();
-        if (more) cur = nxt;
+        if (HAS_DZ && more) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dzc[q] = dzn[q];
+        }
     }
 
-    // ---- sum the five accumulators over the eight waves (tree through the per-wave LDS space) -----
+    // ---- sum the five accumulators over the waves (tree through the per-wave LDS space) -----
     __syncthreads();
     for (int half = kCWaves / 2; half >= 1; half >>= 1) {
         if (wv >= half && wv < 2 * half) {

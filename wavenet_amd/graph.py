@@ -1,0 +1,93 @@
+"""A whole training step as a replayed HIP graph (new capability; the reference launches op by op).
+
+One step of train_audio/train.py:60-78 -- cleargrads, forward (causal -> residual stack -> softmax head), softmax
+cross-entropy, backward, the optimiser hooks and Adam -- is ~250 kernel launches of 5-70 us each.  Launched one by
+one from Python the GPU idles ~8 % of the step between them; captured once (``torch.cuda.graph`` = hipStreamBeginCapture
+on the stream our C-ABI calls are issued on) and replayed, the step is one graph launch.
+
+What changes from step to step lives in device memory, never in kernel arguments:
+  * the batch: copied into the graph's static input buffers;
+  * Adam's bias-corrected step size alpha_t: a device scalar written before each replay (``wn_adam_step_dev``).
+With data parallelism the gradient all-reduce stays OUTSIDE the graphs (forward+backward graph -> RCCL all-reduce ->
+optimiser graph), so nothing here depends on capturing a collective.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+def default_loss(net, x, tgt):
+    """train_audio/train.py:60-75: loss over the last ``tgt.shape[1]`` columns of the window."""
+    c = net.forward_causal_block(x)
+    _, s = net.forward_residual_block(c, t_off=x.shape[1] - tgt.shape[1])
+    logits = net.forward_softmax_block(s, apply_softmax=False)
+    return net.cross_entropy(logits, tgt)
+
+
+class TrainStepGraph(object):
+    """``g = TrainStepGraph(net, x, tgt); loss = g.step(x, tgt)`` -- same result as
+    ``net.backprop(default_loss(net, x, tgt))`` for batches of the captured shape."""
+
+    def __init__(self, net, x, tgt, loss_fn=default_loss, warmup: int = 2):
+        if not (net.gpu_enabled and x.is_cuda and tgt.is_cuda):
+            raise _lib.WaveNetHipError("TrainStepGraph needs the network and the batch on a HIP device")
+        self.net, self.loss_fn = net, loss_fn
+        self.x = x.clone()
+        self.tgt = tgt.clone()
+        opt = net.optimizer
+        self._lr = torch.zeros((1,), device=x.device, dtype=torch.float32)
+        dp = net._dp_group is not None
+        self._gmult = 1.0 / net._dp_group.world if dp else 1.0
+        # warm-up on the capture stream (per-stream scratch, function attributes, allocator pools), then put the
+        # training state back: the warm-up steps are not training steps
+        keep = (net._arena.clone(), opt.m.clone(), opt.v.clone(), opt.t)
+        self._stream = torch.cuda.Stream(device=x.device)
+        self._stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._stream):
+            for _ in range(max(1, warmup)):
+                self._fwd_bwd()
+                self._opt()
+        torch.cuda.current_stream().wait_stream(self._stream)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            net._arena.copy_(keep[0]); opt.m.copy_(keep[1]); opt.v.copy_(keep[2])
+        self._g1 = torch.cuda.CUDAGraph()
+        self._g2 = None
+        with torch.cuda.graph(self._g1, stream=self._stream):
+            self.loss = self._fwd_bwd()
+            if not dp:
+                self._opt()
+        if dp:
+            self._g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g2, stream=self._stream, pool=self._g1.pool()):
+                self._opt()
+        opt.t = keep[3]
+        net._weights_changed()
+
+    def _fwd_bwd(self):
+        self.net.zero_grads()
+        loss = self.loss_fn(self.net, self.x, self.tgt)
+        loss.backward()
+        return loss.detach()
+
+    def _opt(self):
+        self.net.optimizer.update(self._gmult, lr_dev=self._lr)
+
+    def step(self, x=None, tgt=None):
+        """One training step on (x, tgt) (default: the batch already in the static buffers).  Returns the loss
+        (a device scalar that the next step overwrites)."""
+        net, opt = self.net, self.net.optimizer
+        if x is not None:
+            self.x.copy_(x, non_blocking=True)
+        if tgt is not None:
+            self.tgt.copy_(tgt, non_blocking=True)
+        opt.t += 1                                   # update() is not called on replay: keep Adam's clock here
+        self._lr.fill_(opt.lr)
+        self._g1.replay()
+        if self._g2 is not None:
+            net._dp_group.all_reduce_grads(net._grad_arena)
+            self._g2.replay()
+        net._weights_changed()
+        return self.loss

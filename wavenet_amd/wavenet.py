@@ -755,7 +755,9 @@ class AdamState(object):
         fix2 = 1.0 - self.beta2 ** self.t
         return self.alpha * math.sqrt(fix2) / fix1
 
-    def update(self, grad_mult: float = 1.0):
+    def update(self, grad_mult: float = 1.0, lr_dev=None):
+        """One optimiser step.  ``lr_dev`` (1-element device tensor) makes the kernel read the bias-corrected
+        step size from device memory instead of taking ``self.lr`` by value (graph.TrainStepGraph)."""
         net = self.net
         _need_gpu(net._arena)
         self.t += 1
@@ -770,6 +772,11 @@ class AdamState(object):
             check(lib.wn_sqnorm(ptr(net._grad_arena), ptr(net._arena), n, grad_mult, wd, ptr(self._norm), st),
                   "wn_sqnorm")
             norm_ptr = ptr(self._norm)
+        if lr_dev is not None:
+            check(lib.wn_adam_step_dev(ptr(net._arena), ptr(net._grad_arena), ptr(self.m), ptr(self.v), n, ptr(lr_dev),
+                                       self.beta1, self.beta2, self.eps, wd, norm_ptr, clip, grad_mult, st),
+                  "wn_adam_step_dev")
+            return
         check(lib.wn_adam_step(ptr(net._arena), ptr(net._grad_arena), ptr(self.m), ptr(self.v), n, self.lr,
                                self.beta1, self.beta2, self.eps, wd, norm_ptr, clip, grad_mult, st), "wn_adam_step")
 
