@@ -2,6 +2,10 @@
 // any filter width, biases on or off).  One thread per output element, weights through L1/L2.
 // The shapes BASELINE.json names take the MFMA kernels in mfma_*.hip instead; these are the
 // fallback for everything else and the on-GPU cross-check of the fast kernels.
+#include <cstdlib>
+#include <map>
+#include <mutex>
+
 #include "wn_common.hpp"
 
 namespace wn {
@@ -32,43 +36,91 @@ __global__ void k_embed_fwd(const int32_t* __restrict__ idx, const float* __rest
 }
 
 // dW accumulated through an LDS table [Q*fw][C] per block, then flushed with global atomics.
+// The block's columns are one contiguous range of dout; a thread takes kEmbU elements per round and issues all of
+// their loads (values and tokens) before the first LDS atomic -- a loop of "load, then atomics on it" runs one
+// memory latency per element (this kernel took 0.24 ms per step that way; the data is 17 MB).
+static constexpr int kEmbU = 8;
+template <int FW>
 __global__ void k_embed_bwd_lds(const int32_t* __restrict__ idx, const float* __restrict__ dout,
-                                float* __restrict__ dW, float* __restrict__ dbias,
-                                int B, int T, int Q, int C, int fw, int cols_per_block) {
+                                float* __restrict__ ws, int has_bias,
+                                int B, int T, int Q, int C, int fw_rt, int cols_per_block) {
     extern __shared__ __attribute__((aligned(16))) float tab[];   // [(q*fw+k)][c], then [C] bias
+    const int fw = FW > 0 ? FW : fw_rt;
     const int ntab = Q * fw * C;
     float* btab = tab + ntab;
     for (int i = threadIdx.x; i < ntab + C; i += blockDim.x) tab[i] = 0.f;
     __syncthreads();
-    long long col0 = (long long)blockIdx.x * cols_per_block;
-    long long ncol = (long long)B * T;
-    long long work = (long long)cols_per_block * C;
-    for (long long w = threadIdx.x; w < work; w += blockDim.x) {
-        long long col = col0 + w / C;
-        if (col >= ncol) break;
-        int c = (int)(w % C);
-        int t = (int)(col % T);
-        int b = (int)(col / T);
-        float g = dout[col * C + c];
-        if (dbias) atomicAdd(&btab[c], g);
-        for (int k = 0; k < fw; ++k) {
-            int ts = t - (fw - 1 - k);
-            if (ts < 0) continue;
-            int q = idx[(long long)b * T + ts];
-            atomicAdd(&tab[(q * fw + k) * C + c], g);
+    const long long col0 = (long long)blockIdx.x * cols_per_block;
+    const long long ncol = (long long)B * T;
+    const int ncb = (int)(ncol - col0 < cols_per_block ? ncol - col0 : cols_per_block);
+    const int work = ncb * C;
+    const float* __restrict__ src = dout + col0 * C;
+    const int b0 = (int)(col0 / T), t00 = (int)(col0 - (long long)b0 * T);
+    for (int base = threadIdx.x; base < work; base += blockDim.x * kEmbU) {
+        float g[kEmbU];
+        int cc[kEmbU], qq[kEmbU][FW > 0 ? FW : 1];
+#pragma unroll
+        for (int u = 0; u < kEmbU; ++u) {
+            const int e = base + u * blockDim.x;
+            const int ec = e < work ? e : work - 1;                // clamped load, masked value
+            const int colr = ec / C;
+            cc[u] = ec - colr * C;
+            g[u] = e < work ? src[ec] : 0.f;
+            const int tt = t00 + colr;
+            const int b = b0 + tt / T, t = tt - (tt / T) * T;
+            if (FW > 0) {
+#pragma unroll
+                for (int k = 0; k < (FW > 0 ? FW : 1); ++k) {
+                    const int ts = t - (FW - 1 - k);
+                    qq[u][k] = ts >= 0 ? idx[(long long)b * T + ts] : -1;
+                }
+            } else {
+                qq[u][0] = b * T + t;                              // runtime filter width: tokens are read below
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kEmbU; ++u) {
+            if (base + u * blockDim.x >= work) break;
+            if (has_bias) atomicAdd(&btab[cc[u]], g[u]);
+            if (FW > 0) {
+#pragma unroll
+                for (int k = 0; k < (FW > 0 ? FW : 1); ++k)
+                    if (qq[u][k] >= 0) atomicAdd(&tab[(qq[u][k] * FW + k) * C + cc[u]], g[u]);
+            } else {
+                const int bt = qq[u][0], t = bt % T;
+                for (int k = 0; k < fw; ++k) {
+                    const int ts = t - (fw - 1 - k);
+                    if (ts >= 0) atomicAdd(&tab[(idx[bt - t + ts] * fw + k) * C + cc[u]], g[u]);
+                }
+            }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < ntab; i += blockDim.x) {
-        float v = tab[i];
-        if (v != 0.f) {
-            int c = i % C;
-            int qk = i / C;     // q*fw + k
-            atomicAdd(&dW[(long long)c * Q * fw + qk], v);
-        }
+    // the block's table leaves with plain coalesced stores; k_embed_bwd_reduce sums the tables (256 blocks adding
+    // 16k entries each into the same 64 KB with global atomics took 0.2 ms)
+    float* __restrict__ o = ws + (long long)blockIdx.x * (ntab + C);
+    for (int i = threadIdx.x; i < ntab + C; i += blockDim.x) o[i] = tab[i];
+}
+
+__global__ void k_embed_bwd_reduce(const float* __restrict__ ws, int nblk, int Q, int C, int fw,
+                                   float* __restrict__ dW, float* __restrict__ dbias) {
+    const int ntab = Q * fw * C;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntab + C) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 4 <= nblk; b += 4) {
+        a0 += ws[(long long)(b + 0) * (ntab + C) + i]; a1 += ws[(long long)(b + 1) * (ntab + C) + i];
+        a2 += ws[(long long)(b + 2) * (ntab + C) + i]; a3 += ws[(long long)(b + 3) * (ntab + C) + i];
     }
-    if (dbias)
-        for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(&dbias[c], btab[c]);
+    for (; b < nblk; ++b) a0 += ws[(long long)b * (ntab + C) + i];
+    const float v = (a0 + a1) + (a2 + a3);
+    if (i < ntab) {
+        const int c = i % C, qk = i / C;                   // qk = q*fw + k
+        dW[(long long)c * Q * fw + qk] += v;               // sole writer of this element
+    } else if (dbias) {
+        dbias[i - ntab] += v;
+    }
 }
 
 __global__ void k_embed_bwd_atomic(const int32_t* __restrict__ idx, const float* __restrict__ dout,
@@ -612,22 +664,54 @@ int generic_embed_fwd(const int32_t* idx, const float* W, const float* bias, flo
     return WN_OK;
 }
 
+// per-stream scratch for the per-block embedding-gradient tables (grown on first use, then reused)
+struct EmbScratch { void* buf = nullptr; size_t bytes = 0; };
+static std::mutex g_emb_mu;
+static std::map<hipStream_t, EmbScratch> g_emb_scratch;
+static void* embed_scratch_for(hipStream_t s, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_emb_mu);
+    EmbScratch& sc = g_emb_scratch[s];
+    if (sc.bytes < bytes) {
+        if (sc.buf) (void)hipFree(sc.buf);
+        sc.buf = nullptr;
+        sc.bytes = 0;
+        if (hipMalloc(&sc.buf, bytes) != hipSuccess) { sc.buf = nullptr; return nullptr; }
+        sc.bytes = bytes;
+    }
+    return sc.buf;
+}
+
 int generic_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* dbias, int B, int T,
                       int Q, int C, int fw, hipStream_t s) {
     size_t lds = ((size_t)Q * fw * C + C) * sizeof(float);
     long long ncol = (long long)B * T;
     if (lds <= 150 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_embed_bwd_lds),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr_set = true;
-        }
-        int nblk = (int)(ncol < 256 * 64 ? (ncol + 63) / 64 : 256);
-        int cpb = (int)((ncol + nblk - 1) / nblk);
-        nblk = (int)((ncol + cpb - 1) / cpb);
-        hipLaunchKernelGGL(k_embed_bwd_lds, dim3(nblk), dim3(kThreads), lds, s, idx, dout, dW, dbias, B, T,
-                           Q, C, fw, cpb);
+        long long nb = ncol < 256 * 64 ? (ncol + 63) / 64 : 256;
+        while ((ncol + nb - 1) / nb * C >= (1ll << 30)) nb *= 2;          // 32-bit element indices inside a block
+        int cpb = (int)((ncol + nb - 1) / nb);
+        int nblk = (int)((ncol + cpb - 1) / cpb);
+        const int nent = Q * fw * C + C;
+        float* ws = reinterpret_cast<float*>(embed_scratch_for(s, (size_t)nblk * nent * sizeof(float)));
+        if (!ws) { wn::set_error("embed_bwd: cannot allocate the per-block table scratch"); return WN_EHIP; }
+#define EMB_LAUNCH(FW)                                                                                        \
+    do {                                                                                                      \
+        static bool attr_set = false;                                                                         \
+        if (!attr_set) {                                                                                      \
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_embed_bwd_lds<FW>),                    \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));              \
+            attr_set = true;                                                                                  \
+        }                                                                                                     \
+        hipLaunchKernelGGL(k_embed_bwd_lds<FW>, dim3(nblk), dim3(kThreads), lds, s, idx, dout, ws, dbias ? 1 : 0, B, T, \
+                           Q, C, fw, cpb);                                                                    \
+    } while (0)
+        if (fw == 1) EMB_LAUNCH(1);
+        else if (fw == 2) EMB_LAUNCH(2);
+        else if (fw == 3) EMB_LAUNCH(3);
+        else EMB_LAUNCH(0);
+#undef EMB_LAUNCH
+        WN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_embed_bwd_reduce, dim3(cdiv(nent, kThreads)), dim3(kThreads), 0, s, ws, nblk, Q, C, fw, dW,
+                           dbias);
     } else {
         long long total = ncol * C;
         hipLaunchKernelGGL(k_embed_bwd_atomic, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, s, idx, dout,
