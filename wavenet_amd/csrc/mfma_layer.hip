@@ -38,8 +38,22 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
     const int lane = threadIdx.x & 63;
     const int j = lane & 31;      // time column inside the tile (B/D operand), weight row (A operand)
     const int h = lane >> 5;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Tile order: workgroups are dealt to the 8 XCDs round-robin, so XCD k = blockIdx % 8 is given the k-th contiguous
+    // eighth of the tiles: x[t-d] of a tile is then a row range that a neighbouring CU of the SAME XCD fetches as its
+    // x[t] in the same round -- an L2 hit instead of a second trip to HBM.
+    int first, stride, last;                        // this wave's tiles: first, first + stride, ... < last
+    if ((gridDim.x & 7) == 0) {
+        const int per_xcd = (ntiles + 7) >> 3;
+        const int xcd = blockIdx.x & 7;
+        stride = (gridDim.x >> 3) * 4;
+        first = xcd * per_xcd + (blockIdx.x >> 3) * 4 + wv;
+        last = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
+    } else {
+        stride = gridDim.x * 4;
+        first = blockIdx.x * 4 + wv;
+        last = ntiles;
+    }
 
     // ---- A operands: lane (i=j, h), step s holds W[i][ch(s,h)] ------------------------------
     // The workgroup stages the layer's weights in LDS with coalesced 16-byte loads (rows padded to 66 / 33 floats) and
@@ -77,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
     };
 
     float xc[16], xo[16], xcn[16], xon[16];
-    if (wave < ntiles) load_tile(wave, xc, xo);          // in flight while the weights settle in LDS
+    if (first < last) load_tile(first, xc, xo);          // in flight while the weights settle in LDS
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int e = (threadIdx.x + 256 * k) * 4;
@@ -109,14 +123,14 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
             wp[4 * q + m] = wlds[2 * 32 * kWRow + j * kPRow + 8 * q + 4 * h + m];
         }
     }
-    for (int tile = wave; tile < ntiles; tile += nwaves) {
+    for (int tile = first; tile < last; tile += stride) {
         const int b = tile / tiles_per_b;
         const int t = (tile - b * tiles_per_b) * 32 + j;
         const bool valid = t < T;
         const long long row = ((long long)b * T + t) * 32 + 4 * h;
         // the next tile's columns are fetched while this tile computes
-        const bool more = tile + nwaves < ntiles;
-        if (more) load_tile(tile + nwaves, xcn, xon);
+        const bool more = tile + stride < last;
+        if (more) load_tile(tile + stride, xcn, xon);
         f32x16 aa, ag;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

@@ -386,8 +386,21 @@ __global__ __launch_bounds__(64 * kCWaves, 1) void k_layer_bwd_chain8(
     float* xso = tf + 5120;
     float* pa = tf + 6144;
     float* pb = tf + 7168;
-    const int wave = blockIdx.x * kCWaves + wv;
-    const int nwaves = gridDim.x * kCWaves;
+    // Tile order: workgroups are dealt to the 8 XCDs round-robin, so XCD k = blockIdx % 8 is given the k-th contiguous
+    // eighth of the tiles.  x[t-d] (and the layer above's U[t+dU]) of a tile are then rows that a neighbouring CU of
+    // the SAME XCD fetches in the same round: the second fetch is an L2 hit instead of another trip to HBM.
+    int first, stride, last;                        // this wave's tiles: first, first + stride, ... < last
+    if ((gridDim.x & 7) == 0) {
+        const int per_xcd = (ntiles + 7) >> 3;
+        const int xcd = blockIdx.x & 7;
+        stride = (gridDim.x >> 3) * kCWaves;
+        first = xcd * per_xcd + (blockIdx.x >> 3) * kCWaves + wv;
+        last = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
+    } else {
+        stride = gridDim.x * kCWaves;
+        first = blockIdx.x * kCWaves + wv;
+        last = ntiles;
+    }
     constexpr int kAOps = 4 * (2 + (HAS_DO ? 1 : 0) + (HAS_U ? 1 : 0));        // DMA pieces of one tile's f, g, V, U
     constexpr int kZOps = HAS_DZ ? 4 : 0;
     const int lr = lane >> 3, lp = lane & 7;                                    // DMA: row inside a piece, LDS position
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(64 * kCWaves, 1) void k_layer_bwd_chain8(
     }
     const float4 s_wp = reinterpret_cast<const float4*>(Wp)[threadIdx.x & 255];
     float4 dzc[4], dzn[4];
-    if (wave < ntiles) fetch_a(wave, dzc);
+    if (first < last) fetch_a(first, dzc);
 #pragma unroll
     for (int k = 0; k < 512 / kThreads; ++k) {
         reinterpret_cast<float4*>(lWf)[threadIdx.x + k * kThreads] = s_wf[k];
@@ -439,12 +452,12 @@ __global__ __launch_bounds__(64 * kCWaves, 1) void k_layer_bwd_chain8(
 #pragma unroll
     for (int r = 0; r < 16; ++r) { aWf0[r] = 0.f; aWf1[r] = 0.f; aWg0[r] = 0.f; aWg1[r] = 0.f; aWp[r] = 0.f; }
 
-    for (int tile = wave; tile < ntiles; tile += nwaves) {
+    for (int tile = first; tile < last; tile += stride) {
         const int b = tile / tiles_per_b;
         const int t0 = (tile - b * tiles_per_b) * 32;
         const int t = t0 + j;
         const bool valid = t < T;
-        const bool more = tile + nwaves < ntiles;
+        const bool more = tile + stride < last;
         // x[t] and x[t-d] of the tile -> LDS, row-major, not swizzled (only read channel-on-lanes)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -478,7 +491,7 @@ __global__ __launch_bounds__(64 * kCWaves, 1) void k_layer_bwd_chain8(
         }
         // the tiles are in registers: the next tile's may overwrite them (issued before this tile's stores)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (more) fetch_a(tile + nwaves, dzn);
+        if (more) fetch_a(tile + stride, dzn);
         if (HAS_DO || HAS_U) {
 #pragma unroll
             for (int s = 0; s < 16; ++s)
@@ -603,6 +616,298 @@ __global__ __launch_bounds__(64 * kCWaves, 1) void k_layer_bwd_chain8(
         __syncthreads();
     }
     if (wv == 0) {
+        float* __restrict__ o = part + (long long)blockIdx.x * kPartFloats + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o[(0 * 16 + r) * 64] = aWf0[r]; o[(1 * 16 + r) * 64] = aWf1[r];
+            o[(2 * 16 + r) * 64] = aWg0[r]; o[(3 * 16 + r) * 64] = aWg1[r];
+            o[(4 * 16 + r) * 64] = aWp[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Third structure: producer / consumer wave pairs.  With one wave per SIMD (k_layer_bwd_chain8) the 160 MFMAs of a tile
+// (10,240 cycles) run strictly between that wave's own DMA waits, LDS traffic, gate arithmetic and stores: ~21,000
+// cycles per tile, the matrix pipe idle half of the time and HBM at 2.8 TB/s.  Here a workgroup is 8 waves = 4 pairs
+// that share a SIMD each (waves w and w+4):
+//   producer (w < 4):  f, g, V, U tiles (LDS-DMA, swizzled) -> dz = Wp^T dout + dz_skip -> gate -> da, dg -> V, U
+//                      (80 MFMAs); stores V/U as whole rows; leaves da, dg, dout, z = f g as swizzled patches IN THE
+//                      SLOTS ITS INPUT TILES CAME IN (they are consumed by then);
+//   consumer (w >= 4): takes the four patches into registers (channel on lanes), reads x[t], x[t-d] straight from
+//                      memory in that layout (a half wave = one 128-byte row), prefetched one tile ahead in registers,
+//                      and runs the 80 weight-gradient MFMAs into the five accumulators it alone holds.
+// A pair owns two groups of four 4 KB slots; tile n lives in group n % 2, so the producer issues the DMA of tile n+1
+// (into the other group, whose patches the consumer took at the previous hand-over) before it starts on tile n: every
+// fetch has a whole tile of time to land.  Two LDS-only workgroup barriers per tile hand the patches over (ready /
+// taken); they wait for LDS traffic only, not for outstanding stores or DMA.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_only_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <bool HAS_DO, bool HAS_U, bool HAS_DZ>
+__global__ __launch_bounds__(512, 1) void k_layer_bwd_chainpc(
+    const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
+    const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
+    const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, const float* __restrict__ dzs,
+    float* __restrict__ Vout, float* __restrict__ Uout, float* __restrict__ part, int B, int T, int d, int Z,
+    int tiles_per_b, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float* lWf = dyn;
+    float* lWg = dyn + 2048;
+    float* lWp = dyn + 4096;
+    float* wbase = dyn + kCWFloats;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wv & 3;
+    const bool producer = wv < 4;
+    const int j = lane & 31, h = lane >> 5;
+    float* pbase = wbase + pair * kCWaveFloats;      // group k: pbase + 4096 k = {f | dout, g | z, V | da, U | dg}
+    int first0, stride, last;                        // pair p walks first0 + p, + stride, ... < last (XCD-aware, see above)
+    if ((gridDim.x & 7) == 0) {
+        const int per_xcd = (ntiles + 7) >> 3;
+        const int xcd = blockIdx.x & 7;
+        stride = (gridDim.x >> 3) * 4;
+        first0 = xcd * per_xcd + (blockIdx.x >> 3) * 4;
+        last = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
+    } else {
+        stride = gridDim.x * 4;
+        first0 = blockIdx.x * 4;
+        last = ntiles;
+    }
+    const int first = first0 + pair;
+    const int iters = first0 < last ? (last - first0 + stride - 1) / stride : 0;    // same for the whole workgroup
+    const int lr = lane >> 3, lp = lane & 7;                                    // DMA: row inside a piece, LDS position
+    constexpr int kFetchOps = 4 * (2 + (HAS_DO ? 1 : 0) + (HAS_U ? 1 : 0) + (HAS_DZ ? 1 : 0));
+
+    auto fetch_a = [&](int tile, float* grp, float4 (&dz4)[4]) {
+        const int b = tile / tiles_per_b;
+        const int t0 = (tile - b * tiles_per_b) * 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = 8 * k + lr;
+            const int tt = t0 + r;
+            const int ttc = tt < T ? tt : T - 1;
+            const int ttu = ttc + dU < T ? ttc + dU : T - 1;
+            const long long o = ((long long)b * T + ttc) * 32 + ((lp ^ (r & 7)) << 2);
+            WN_LDS_DMA16(f + o, grp + k * 256);
+            WN_LDS_DMA16(g + o, grp + 1024 + k * 256);
+            if (HAS_DO) WN_LDS_DMA16(Vin + o, grp + 2048 + k * 256);
+            if (HAS_U) WN_LDS_DMA16(Uin + ((long long)b * T + ttu) * 32 + ((lp ^ (r & 7)) << 2), grp + 3072 + k * 256);
+        }
+        if (HAS_DZ) {
+            const int t = t0 + j;
+            const long long rowc = ((long long)b * T + (t < T ? t : T - 1)) * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dz4[q] = *reinterpret_cast<const float4*>(dzs + rowc + 8 * q);
+        }
+    };
+    // x[t], x[t-d] of a tile as B operands of the weight-gradient MFMAs: lane (j,h), step s: row 2s+h, channel j
+    auto fetch_x = [&](int tile, float (&xc)[16], float (&xo)[16]) {
+        const int b = tile / tiles_per_b;
+        const int t0 = (tile - b * tiles_per_b) * 32;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int tt = t0 + 2 * s + h;
+            const int ttc = tt < T ? tt : T - 1;
+            const int tto = ttc - d >= 0 ? ttc - d : 0;
+            xc[s] = x[((long long)b * T + ttc) * 32 + j];
+            xo[s] = x[((long long)b * T + tto) * 32 + j];
+        }
+    };
+
+    // ---- weights -> LDS (coalesced), first tile's operands in flight meanwhile -------------------
+    const float4 s_wf = reinterpret_cast<const float4*>(Wf)[threadIdx.x];
+    const float4 s_wg = reinterpret_cast<const float4*>(Wg)[threadIdx.x];
+    const float4 s_wp = reinterpret_cast<const float4*>(Wp)[threadIdx.x & 255];
+    float4 dzc[4], dzn[4];
+    float xcn[16], xon[16];
+    if (first < last) {
+        if (producer) fetch_a(first, pbase, dzc);
+        else fetch_x(first, xcn, xon);
+    }
+    reinterpret_cast<float4*>(lWf)[threadIdx.x] = s_wf;
+    reinterpret_cast<float4*>(lWg)[threadIdx.x] = s_wg;
+    if (threadIdx.x < 256) reinterpret_cast<float4*>(lWp)[threadIdx.x] = s_wp;
+    __syncthreads();
+
+    f32x16 aWf0, aWf1, aWg0, aWg1, aWp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aWf0[r] = 0.f; aWf1[r] = 0.f; aWg0[r] = 0.f; aWg1[r] = 0.f; aWp[r] = 0.f; }
+
+    if (producer) {
+        for (int it = 0; it < iters; ++it) {
+            const int tile = first + it * stride;
+            float* grp = pbase + (it & 1) * 4096;
+            float* tf = grp;
+            float* tg = grp + 1024;
+            float* tv = grp + 2048;
+            float* tu = grp + 3072;
+            const bool more = tile + stride < last;
+            // the next tile's operands go to the other group (its patches were taken at the last hand-over)
+            if (more) fetch_a(tile + stride, pbase + ((it + 1) & 1) * 4096, dzn);
+            if (tile < last) {
+                const int b = tile / tiles_per_b;
+                const int t0 = (tile - b * tiles_per_b) * 32;
+                const int t = t0 + j;
+                const bool valid = t < T;
+                // this tile's f, g, V, U have landed (issued before the next tile's; stores are not counted)
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFetchOps) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const float mu = (HAS_U && valid && t + dU < T) ? 1.f : 0.f;
+                f32x16 acc;
+                float ff[16], gg[16], dob[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
+                    float4 z4 = make_float4(0, 0, 0, 0), o4 = z4;
+                    const float4 f4 = *reinterpret_cast<const float4*>(tf + o);
+                    const float4 g4 = *reinterpret_cast<const float4*>(tg + o);
+                    if (HAS_DZ) z4 = dzc[q];
+                    if (HAS_DO) o4 = *reinterpret_cast<const float4*>(tv + o);
+                    if (HAS_U) {
+                        const float4 u4 = *reinterpret_cast<const float4*>(tu + o);
+                        o4.x += u4.x * mu; o4.y += u4.y * mu; o4.z += u4.z * mu; o4.w += u4.w * mu;
+                    }
+                    acc[4 * q] = z4.x; acc[4 * q + 1] = z4.y; acc[4 * q + 2] = z4.z; acc[4 * q + 3] = z4.w;
+                    ff[4 * q] = f4.x; ff[4 * q + 1] = f4.y; ff[4 * q + 2] = f4.z; ff[4 * q + 3] = f4.w;
+                    gg[4 * q] = g4.x; gg[4 * q + 1] = g4.y; gg[4 * q + 2] = g4.z; gg[4 * q + 3] = g4.w;
+                    dob[4 * q] = o4.x; dob[4 * q + 1] = o4.y; dob[4 * q + 2] = o4.z; dob[4 * q + 3] = o4.w;
+                }
+                if (HAS_DO || HAS_U) {
+#pragma unroll
+                    for (int s = 0; s < 16; ++s)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lWp[bch(s, h) * 32 + j], dob[s], acc, 0, 0, 0);
+                }
+                const bool live = valid && t >= Z;
+                float da[16], dg[16], zz[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dz = live ? acc[r] : 0.f;
+                    da[r] = dz * gg[r] * (1.f - ff[r] * ff[r]);
+                    dg[r] = dz * ff[r] * gg[r] * (1.f - gg[r]);
+                    zz[r] = ff[r] * gg[r];
+                }
+                f32x16 v1, u0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { v1[r] = dob[r]; u0[r] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float2 wf = *reinterpret_cast<const float2*>(lWf + (bch(s, h) * 32 + j) * 2);
+                    const float2 wg = *reinterpret_cast<const float2*>(lWg + (bch(s, h) * 32 + j) * 2);
+                    v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, da[s], v1, 0, 0, 0);
+                    u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, da[s], u0, 0, 0, 0);
+                    v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.y, dg[s], v1, 0, 0, 0);
+                    u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.x, dg[s], u0, 0, 0, 0);
+                }
+                // V, U leave as whole rows through the (consumed) V/U input slots
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
+                    *reinterpret_cast<float4*>(tv + o) = make_float4(v1[4 * q], v1[4 * q + 1], v1[4 * q + 2], v1[4 * q + 3]);
+                    *reinterpret_cast<float4*>(tu + o) = make_float4(u0[4 * q], u0[4 * q + 1], u0[4 * q + 2], u0[4 * q + 3]);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = 8 * k + lr;
+                    const float4 vv = *reinterpret_cast<const float4*>(tv + k * 256 + lane * 4);
+                    const float4 uu = *reinterpret_cast<const float4*>(tu + k * 256 + lane * 4);
+                    if (t0 + r < T) {
+                        const long long o = ((long long)b * T + t0 + r) * 32 + ((lp ^ (r & 7)) << 2);
+                        *reinterpret_cast<float4*>(Vout + o) = vv;
+                        *reinterpret_cast<float4*>(Uout + o) = uu;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                // the four patches for the consumer: dout (0 beyond T), z, da, dg
+                const float mvj = valid ? 1.f : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
+                    *reinterpret_cast<float4*>(tf + o) = make_float4(dob[4 * q] * mvj, dob[4 * q + 1] * mvj, dob[4 * q + 2] * mvj, dob[4 * q + 3] * mvj);
+                    *reinterpret_cast<float4*>(tg + o) = make_float4(zz[4 * q], zz[4 * q + 1], zz[4 * q + 2], zz[4 * q + 3]);
+                    *reinterpret_cast<float4*>(tv + o) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
+                    *reinterpret_cast<float4*>(tu + o) = make_float4(dg[4 * q], dg[4 * q + 1], dg[4 * q + 2], dg[4 * q + 3]);
+                }
+            }
+            lds_only_barrier();                       // patches ready
+            lds_only_barrier();                       // patches taken
+            if (HAS_DZ && more) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dzc[q] = dzn[q];
+            }
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+            const int tile = first + it * stride;
+            const bool active = tile < last;
+            const float* grp = pbase + (it & 1) * 4096;
+            float a_da[16], a_dg[16], a_do[16], b_z[16], b_xc[16], b_xo[16];
+            if (active) {
+                const int b = tile / tiles_per_b;
+                const int t0 = (tile - b * tiles_per_b) * 32;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int tt = t0 + 2 * s + h;
+                    b_xc[s] = xcn[s] * (tt < T ? 1.f : 0.f);
+                    b_xo[s] = xon[s] * ((tt < T && tt - d >= 0) ? 1.f : 0.f);
+                }
+            }
+            lds_only_barrier();                       // patches ready
+            if (active) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int r = 2 * s + h;
+                    const int po = r * 32 + ((((j >> 2) ^ (r & 7)) << 2) | (j & 3));
+                    a_do[s] = grp[po]; b_z[s] = grp[1024 + po]; a_da[s] = grp[2048 + po]; a_dg[s] = grp[3072 + po];
+                }
+            }
+            lds_only_barrier();                       // patches taken
+            if (tile + stride < last) fetch_x(tile + stride, xcn, xon);
+            if (active) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    aWf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da[s], b_xc[s], aWf1, 0, 0, 0);
+                    aWf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da[s], b_xo[s], aWf0, 0, 0, 0);
+                    aWg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg[s], b_xc[s], aWg1, 0, 0, 0);
+                    aWg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg[s], b_xo[s], aWg0, 0, 0, 0);
+                    if (HAS_DO || HAS_U) aWp = __builtin_amdgcn_mfma_f32_32x32x2f32(a_do[s], b_z[s], aWp, 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- sum the five accumulators over the four consumer waves (tree through the slot groups) -----
+    __syncthreads();
+    for (int half = 2; half >= 1; half >>= 1) {
+        if (!producer && pair >= half && pair < 2 * half) {
+            float* red = wbase + (pair - half) * kPartFloats;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                red[(0 * 16 + r) * 64 + lane] = aWf0[r]; red[(1 * 16 + r) * 64 + lane] = aWf1[r];
+                red[(2 * 16 + r) * 64 + lane] = aWg0[r]; red[(3 * 16 + r) * 64 + lane] = aWg1[r];
+                red[(4 * 16 + r) * 64 + lane] = aWp[r];
+            }
+        }
+        __syncthreads();
+        if (!producer && pair < half) {
+            const float* red = wbase + pair * kPartFloats;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                aWf0[r] += red[(0 * 16 + r) * 64 + lane]; aWf1[r] += red[(1 * 16 + r) * 64 + lane];
+                aWg0[r] += red[(2 * 16 + r) * 64 + lane]; aWg1[r] += red[(3 * 16 + r) * 64 + lane];
+                aWp[r] += red[(4 * 16 + r) * 64 + lane];
+            }
+        }
+        __syncthreads();
+    }
+    if (!producer && pair == 0) {
         float* __restrict__ o = part + (long long)blockIdx.x * kPartFloats + lane;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -753,23 +1058,32 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
     WN_CHECK_SHAPE(nt < (1ll << 31), "mfma_layer_bwd_chain: too many tiles");
     WN_CHECK_ARG(Vin || Uin || dzs, "mfma_layer_bwd_chain: no incoming gradient");
     const int ntiles = (int)nt;
-    static const bool old_kernel = [] { const char* e = getenv("WAVENET_HIP_CHAIN"); return e && !strcmp(e, "old"); }();
-    int blocks = old_kernel ? (ntiles + 3) / 4 : (ntiles + kCWaves - 1) / kCWaves;
-    const int maxb = old_kernel ? kMaxBlocks : kCMaxBlocks;
+    static const int variant = [] {                      // 0: producer/consumer pairs (default), 1: chain8, 2: first chained kernel
+        const char* e = getenv("WAVENET_HIP_CHAIN");
+        return !e ? 0 : !strcmp(e, "v2") ? 1 : !strcmp(e, "old") ? 2 : 0;
+    }();
+    int blocks = variant == 2 ? (ntiles + 3) / 4 : (ntiles + kCWaves - 1) / kCWaves;
+    const int maxb = variant == 2 ? kMaxBlocks : kCMaxBlocks;
     if (blocks > maxb) blocks = maxb;
-#define CH_LAUNCH(DO, UU, DZ)                                                                                      \
-    if (old_kernel) {                                                                                              \
-        hipLaunchKernelGGL((k_layer_bwd_chain<DO, UU, DZ>), dim3(blocks), dim3(256), 0, s, x, f, g, Wp, Wf, Wg, Vin, Uin, \
-                           dU, dzs, Vout, Uout, part, B, T, d, Z, tiles_per_b, ntiles);                            \
-    } else {                                                                                                       \
+#define CH_LAUNCH_LDS(KERNEL, THREADS)                                                                             \
+    do {                                                                                                           \
         static bool attr_set = false;                                                                              \
         if (!attr_set) {                                                                                           \
-            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chain8<DO, UU, DZ>),              \
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL),                                      \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kCLdsBytes));                   \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL((k_layer_bwd_chain8<DO, UU, DZ>), dim3(blocks), dim3(64 * kCWaves), kCLdsBytes, s, x, f, g, Wp, \
-                           Wf, Wg, Vin, Uin, dU, dzs, Vout, Uout, part, B, T, d, Z, tiles_per_b, ntiles);          \
+        hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(THREADS), kCLdsBytes, s, x, f, g, Wp, Wf, Wg, Vin, Uin, dU, dzs, \
+                           Vout, Uout, part, B, T, d, Z, tiles_per_b, ntiles);                                     \
+    } while (0)
+#define CH_LAUNCH(DO, UU, DZ)                                                                                      \
+    if (variant == 2) {                                                                                            \
+        hipLaunchKernelGGL((k_layer_bwd_chain<DO, UU, DZ>), dim3(blocks), dim3(256), 0, s, x, f, g, Wp, Wf, Wg, Vin, Uin, \
+                           dU, dzs, Vout, Uout, part, B, T, d, Z, tiles_per_b, ntiles);                            \
+    } else if (variant == 1) {                                                                                     \
+        CH_LAUNCH_LDS((k_layer_bwd_chain8<DO, UU, DZ>), 64 * kCWaves);                                             \
+    } else {                                                                                                       \
+        CH_LAUNCH_LDS((k_layer_bwd_chainpc<DO, UU, DZ>), 512);                                                     \
     }
     const int key = (Vin ? 4 : 0) | (Uin ? 2 : 0) | (dzs ? 1 : 0);
     switch (key) {
@@ -782,6 +1096,7 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
         default: CH_LAUNCH(false, false, true); break;
     }
 #undef CH_LAUNCH
+#undef CH_LAUNCH_LDS
     WN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_layer_bwd_reduce, dim3(kPartFloats / 256, kRedParts), dim3(256), 0, s, part, blocks, dWf, dWg,
                        (Vin || Uin) ? dWp : (float*)nullptr);
