@@ -918,6 +918,329 @@ __global__ __launch_bounds__(512, 1) void k_layer_bwd_chainpc(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fourth structure: ONE wave per SIMD again (4 waves per workgroup, 512 registers), software-pipelined: the loop
+// body holds the 80 weight-gradient MFMAs of tile n (operands already in registers) AND the whole first half of tile
+// n+1 (LDS reads, dz chain, gate, V/U MFMAs, patch writes) in one basic block, so the compiler's scheduler interleaves
+// the VALU / LDS work of one tile between the MFMAs of the other.  (Two waves per SIMD do not achieve that: a wave
+// that streams MFMAs starves its sibling's VALU issue -- the producer/consumer kernel above measured 11,000 cycles for
+// 300 VALU instructions next to the consumer's MFMA stream.)  LDS use and data movement are those of the
+// producer/consumer kernel: two groups of four slots per wave, x through registers.
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_DO, bool HAS_U, bool HAS_DZ>
+__global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
+    const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
+    const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
+    const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, const float* __restrict__ dzs,
+    float* __restrict__ Vout, float* __restrict__ Uout, float* __restrict__ part, int B, int T, int d, int Z,
+    int tiles_per_b, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float dyn[];
+    float* lWf = dyn;
+    float* lWg = dyn + 2048;
+    float* lWp = dyn + 4096;
+    float* wbase = dyn + kCWFloats;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    float* pbase = wbase + wv * kCWaveFloats;        // group k: pbase + 4096 k = {f | dout, g | z, V | da, U | dg}
+    int first, stride, last;
+    if ((gridDim.x & 7) == 0) {
+        const int per_xcd = (ntiles + 7) >> 3;
+        const int xcd = blockIdx.x & 7;
+        stride = (gridDim.x >> 3) * 4;
+        first = xcd * per_xcd + (blockIdx.x >> 3) * 4 + wv;
+        last = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
+    } else {
+        stride = gridDim.x * 4;
+        first = blockIdx.x * 4 + wv;
+        last = ntiles;
+    }
+    const int lr = lane >> 3, lp = lane & 7;
+
+    auto fetch_a = [&](int tile, float* grp, float4 (&dz4)[4]) {
+        const int b = tile / tiles_per_b;
+        const int t0 = (tile - b * tiles_per_b) * 32;
+        if (t0 + 32 + (HAS_U ? dU : 0) <= T) {
+            // interior tile (wave-uniform test): one base address per tensor, the four pieces are 1 KB apart
+            const long long o = ((long long)b * T + t0 + lr) * 32 + ((lp ^ lr) << 2);
+            const float* pf = f + o;
+            const float* pg = g + o;
+            const float* pv = Vin + o;
+            const float* pu = Uin + o + (long long)dU * 32;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                WN_LDS_DMA16(pf + k * 256, grp + k * 256);
+                WN_LDS_DMA16(pg + k * 256, grp + 1024 + k * 256);
+                if (HAS_DO) WN_LDS_DMA16(pv + k * 256, grp + 2048 + k * 256);
+                if (HAS_U) WN_LDS_DMA16(pu + k * 256, grp + 3072 + k * 256);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 8 * k + lr;
+                const int tt = t0 + r;
+                const int ttc = tt < T ? tt : T - 1;
+                const int ttu = ttc + dU < T ? ttc + dU : T - 1;
+                const long long o = ((long long)b * T + ttc) * 32 + ((lp ^ (r & 7)) << 2);
+                WN_LDS_DMA16(f + o, grp + k * 256);
+                WN_LDS_DMA16(g + o, grp + 1024 + k * 256);
+                if (HAS_DO) WN_LDS_DMA16(Vin + o, grp + 2048 + k * 256);
+                if (HAS_U) WN_LDS_DMA16(Uin + ((long long)b * T + ttu) * 32 + ((lp ^ (r & 7)) << 2), grp + 3072 + k * 256);
+            }
+        }
+        if (HAS_DZ) {
+            const int t = t0 + j;
+            const long long rowc = ((long long)b * T + (t < T ? t : T - 1)) * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dz4[q] = *reinterpret_cast<const float4*>(dzs + rowc + 8 * q);
+        }
+    };
+    auto fetch_x = [&](int tile, float (&xc)[16], float (&xo)[16]) {
+        const int b = tile / tiles_per_b;
+        const int t0 = (tile - b * tiles_per_b) * 32;
+        if (t0 - d >= 0 && t0 + 32 <= T) {               // interior tile: rows 2s+h are 256 B apart from one base
+            const float* pc = x + ((long long)b * T + t0 + h) * 32 + j;
+            const float* po = pc - (long long)d * 32;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { xc[s] = pc[s * 64]; xo[s] = po[s * 64]; }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int tt = t0 + 2 * s + h;
+                const int ttc = tt < T ? tt : T - 1;
+                const int tto = ttc - d >= 0 ? ttc - d : 0;
+                xc[s] = x[((long long)b * T + ttc) * 32 + j];
+                xo[s] = x[((long long)b * T + tto) * 32 + j];
+            }
+        }
+    };
+
+    f32x16 aWf0, aWf1, aWg0, aWg1, aWp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aWf0[r] = 0.f; aWf1[r] = 0.f; aWg0[r] = 0.f; aWg1[r] = 0.f; aWp[r] = 0.f; }
+
+    // first half of a tile: everything up to the patches in its slot group; the V/U rows come back in registers
+    // (vv, uu) and are stored by the caller.  `grp` holds the tile's f, g, V, U (landed).
+    float vv[16], uu[16];
+    auto phase_a = [&](int tile, float* grp, const float4 (&dz4)[4]) {
+        float* tf = grp;
+        float* tg = grp + 1024;
+        float* tv = grp + 2048;
+        float* tu = grp + 3072;
+        const int b = tile / tiles_per_b;
+        const int t0 = (tile - b * tiles_per_b) * 32;
+        const int t = t0 + j;
+        const bool valid = t < T;
+        const float mu = (HAS_U && valid && t + dU < T) ? 1.f : 0.f;
+        f32x16 acc;
+        float ff[16], gg[16], dob[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
+            float4 z4 = make_float4(0, 0, 0, 0), o4 = z4;
+            const float4 f4 = *reinterpret_cast<const float4*>(tf + o);
+            const float4 g4 = *reinterpret_cast<const float4*>(tg + o);
+            if (HAS_DZ) z4 = dz4[q];
+            if (HAS_DO) o4 = *reinterpret_cast<const float4*>(tv + o);
+            if (HAS_U) {
+                const float4 u4 = *reinterpret_cast<const float4*>(tu + o);
+                o4.x += u4.x * mu; o4.y += u4.y * mu; o4.z += u4.z * mu; o4.w += u4.w * mu;
+            }
+            acc[4 * q] = z4.x; acc[4 * q + 1] = z4.y; acc[4 * q + 2] = z4.z; acc[4 * q + 3] = z4.w;
+            ff[4 * q] = f4.x; ff[4 * q + 1] = f4.y; ff[4 * q + 2] = f4.z; ff[4 * q + 3] = f4.w;
+            gg[4 * q] = g4.x; gg[4 * q + 1] = g4.y; gg[4 * q + 2] = g4.z; gg[4 * q + 3] = g4.w;
+            dob[4 * q] = o4.x; dob[4 * q + 1] = o4.y; dob[4 * q + 2] = o4.z; dob[4 * q + 3] = o4.w;
+        }
+        if (HAS_DO || HAS_U) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lWp[bch(s, h) * 32 + j], dob[s], acc, 0, 0, 0);
+        }
+        const bool live = valid && t >= Z;
+        float da[16], dg[16], zz[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float dz = live ? acc[r] : 0.f;
+            da[r] = dz * gg[r] * (1.f - ff[r] * ff[r]);
+            dg[r] = dz * ff[r] * gg[r] * (1.f - gg[r]);
+            zz[r] = ff[r] * gg[r];
+        }
+        f32x16 v1, u0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { v1[r] = dob[r]; u0[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float2 wf = *reinterpret_cast<const float2*>(lWf + (bch(s, h) * 32 + j) * 2);
+            const float2 wg = *reinterpret_cast<const float2*>(lWg + (bch(s, h) * 32 + j) * 2);
+            v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, da[s], v1, 0, 0, 0);
+            u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, da[s], u0, 0, 0, 0);
+            v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.y, dg[s], v1, 0, 0, 0);
+            u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.x, dg[s], u0, 0, 0, 0);
+        }
+        // V, U through the (consumed) V/U slots into row order
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
+            *reinterpret_cast<float4*>(tv + o) = make_float4(v1[4 * q], v1[4 * q + 1], v1[4 * q + 2], v1[4 * q + 3]);
+            *reinterpret_cast<float4*>(tu + o) = make_float4(u0[4 * q], u0[4 * q + 1], u0[4 * q + 2], u0[4 * q + 3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(tv + k * 256 + lane * 4);
+            const float4 c = *reinterpret_cast<const float4*>(tu + k * 256 + lane * 4);
+            vv[4 * k] = a.x; vv[4 * k + 1] = a.y; vv[4 * k + 2] = a.z; vv[4 * k + 3] = a.w;
+            uu[4 * k] = c.x; uu[4 * k + 1] = c.y; uu[4 * k + 2] = c.z; uu[4 * k + 3] = c.w;
+        }
+        // the four patches: dout (0 beyond T), z, da, dg
+        const float mvj = valid ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
+            *reinterpret_cast<float4*>(tf + o) = make_float4(dob[4 * q] * mvj, dob[4 * q + 1] * mvj, dob[4 * q + 2] * mvj, dob[4 * q + 3] * mvj);
+            *reinterpret_cast<float4*>(tg + o) = make_float4(zz[4 * q], zz[4 * q + 1], zz[4 * q + 2], zz[4 * q + 3]);
+            *reinterpret_cast<float4*>(tv + o) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
+            *reinterpret_cast<float4*>(tu + o) = make_float4(dg[4 * q], dg[4 * q + 1], dg[4 * q + 2], dg[4 * q + 3]);
+        }
+    };
+    // returns true when the tile is complete and the eight stores were issued unconditionally (they can then be left in
+    // flight across the next s_waitcnt vmcnt)
+    auto store_vu = [&](int tile) -> bool {
+        const int b = tile / tiles_per_b;
+        const int t0 = (tile - b * tiles_per_b) * 32;
+        const bool full = t0 + 32 <= T;
+        if (full) {
+            float* pv = Vout + ((long long)b * T + t0 + lr) * 32 + ((lp ^ lr) << 2);
+            float* pu = Uout + ((long long)b * T + t0 + lr) * 32 + ((lp ^ lr) << 2);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                *reinterpret_cast<float4*>(pv + k * 256) = make_float4(vv[4 * k], vv[4 * k + 1], vv[4 * k + 2], vv[4 * k + 3]);
+                *reinterpret_cast<float4*>(pu + k * 256) = make_float4(uu[4 * k], uu[4 * k + 1], uu[4 * k + 2], uu[4 * k + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 8 * k + lr;
+                if (t0 + r < T) {
+                    const long long o = ((long long)b * T + t0 + r) * 32 + ((lp ^ (r & 7)) << 2);
+                    *reinterpret_cast<float4*>(Vout + o) = make_float4(vv[4 * k], vv[4 * k + 1], vv[4 * k + 2], vv[4 * k + 3]);
+                    *reinterpret_cast<float4*>(Uout + o) = make_float4(uu[4 * k], uu[4 * k + 1], uu[4 * k + 2], uu[4 * k + 3]);
+                }
+            }
+        }
+        return full;
+    };
+    struct WOps { float a_da[16], a_dg[16], a_do[16], b_z[16], b_xc[16], b_xo[16]; };
+    auto take = [&](int tile, const float* grp, const float (&xc)[16], const float (&xo)[16], WOps& w) {
+        const int b = tile / tiles_per_b;
+        const int t0 = (tile - b * tiles_per_b) * 32;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int r = 2 * s + h;
+            const int tt = t0 + r;
+            const int po = r * 32 + ((((j >> 2) ^ (r & 7)) << 2) | (j & 3));
+            w.a_do[s] = grp[po]; w.b_z[s] = grp[1024 + po]; w.a_da[s] = grp[2048 + po]; w.a_dg[s] = grp[3072 + po];
+            w.b_xc[s] = xc[s] * (tt < T ? 1.f : 0.f);
+            w.b_xo[s] = xo[s] * ((tt < T && tt - d >= 0) ? 1.f : 0.f);
+        }
+    };
+    auto wgrad = [&](const WOps& w) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            aWf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w.a_da[s], w.b_xc[s], aWf1, 0, 0, 0);
+            aWf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w.a_da[s], w.b_xo[s], aWf0, 0, 0, 0);
+            aWg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w.a_dg[s], w.b_xc[s], aWg1, 0, 0, 0);
+            aWg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w.a_dg[s], w.b_xo[s], aWg0, 0, 0, 0);
+            if (HAS_DO || HAS_U) aWp = __builtin_amdgcn_mfma_f32_32x32x2f32(w.a_do[s], w.b_z[s], aWp, 0, 0, 0);
+        }
+    };
+
+    // ---- prologue: weights -> LDS, first tile's operands, its first half -----------------------------------
+    constexpr int kThreads = 256;
+    float4 s_wf[2], s_wg[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        s_wf[k] = reinterpret_cast<const float4*>(Wf)[threadIdx.x + k * kThreads];
+        s_wg[k] = reinterpret_cast<const float4*>(Wg)[threadIdx.x + k * kThreads];
+    }
+    const float4 s_wp = reinterpret_cast<const float4*>(Wp)[threadIdx.x];
+    float4 dza[4], dzb[4];
+    float xc[16], xo[16];
+    const bool any = first < last;
+    bool stores_in_flight = false;                     // the last eight vector-memory operations are unconditional V/U stores
+    if (any) { fetch_a(first, pbase, dza); fetch_x(first, xc, xo); }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        reinterpret_cast<float4*>(lWf)[threadIdx.x + k * kThreads] = s_wf[k];
+        reinterpret_cast<float4*>(lWg)[threadIdx.x + k * kThreads] = s_wg[k];
+    }
+    reinterpret_cast<float4*>(lWp)[threadIdx.x] = s_wp;
+    __syncthreads();                                   // (also drains vmcnt: the first tile has landed)
+    if (any) {
+        if (first + stride < last) fetch_a(first + stride, pbase + 4096, dzb);
+        phase_a(first, pbase, dza);
+        stores_in_flight = store_vu(first);
+    }
+    int it = 0;
+    for (int tile = first; tile < last; tile += stride, ++it) {
+        float* grp = pbase + (it & 1) * 4096;          // patches of `tile`
+        float* ngrp = pbase + ((it + 1) & 1) * 4096;   // f, g, V, U of tile + stride
+        const bool next = tile + stride < last;
+        // what the previous body fetched (this tile's x, the next tile's f, g, V, U, dz) has had a whole body to land;
+        // its V/U stores were issued last and may stay in flight
+        if (stores_in_flight) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WOps w;
+        take(tile, grp, xc, xo, w);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the patches are in registers: their slots are free
+        if (next) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dza[q] = dzb[q];
+            fetch_x(tile + stride, xc, xo);
+            if (tile + 2 * stride < last) fetch_a(tile + 2 * stride, grp, dzb);
+            // one basic block: 80 weight-gradient MFMAs of `tile` and the first half of the next tile
+            wgrad(w);
+            phase_a(tile + stride, ngrp, dza);
+            stores_in_flight = store_vu(tile + stride);
+        } else {
+            wgrad(w);
+        }
+    }
+
+    // ---- sum the five accumulators over the waves (tree through the slot groups) -----
+    __syncthreads();
+    for (int half = 2; half >= 1; half >>= 1) {
+        if (wv >= half && wv < 2 * half) {
+            float* red = wbase + (wv - half) * kPartFloats;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                red[(0 * 16 + r) * 64 + lane] = aWf0[r]; red[(1 * 16 + r) * 64 + lane] = aWf1[r];
+                red[(2 * 16 + r) * 64 + lane] = aWg0[r]; red[(3 * 16 + r) * 64 + lane] = aWg1[r];
+                red[(4 * 16 + r) * 64 + lane] = aWp[r];
+            }
+        }
+        __syncthreads();
+        if (wv < half) {
+            const float* red = wbase + wv * kPartFloats;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                aWf0[r] += red[(0 * 16 + r) * 64 + lane]; aWf1[r] += red[(1 * 16 + r) * 64 + lane];
+                aWg0[r] += red[(2 * 16 + r) * 64 + lane]; aWg1[r] += red[(3 * 16 + r) * 64 + lane];
+                aWp[r] += red[(4 * 16 + r) * 64 + lane];
+            }
+        }
+        __syncthreads();
+    }
+    if (wv == 0) {
+        float* __restrict__ o = part + (long long)blockIdx.x * kPartFloats + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o[(0 * 16 + r) * 64] = aWf0[r]; o[(1 * 16 + r) * 64] = aWf1[r];
+            o[(2 * 16 + r) * 64] = aWg0[r]; o[(3 * 16 + r) * 64] = aWg1[r];
+            o[(4 * 16 + r) * 64] = aWp[r];
+        }
+    }
+}
+
 // dx[t] = V[t] + U[t + dU]   (the split gradient of the stack input, materialised once at the bottom)
 __global__ void k_chain_combine(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ dx,
                                 int B, int T, int dU) {
@@ -954,6 +1277,31 @@ __global__ void k_layer_bwd_reduce(const float* __restrict__ part, int nwg, floa
         if (dW) atomicAdd(dW + (i * 32 + j) * 2 + (tile & 1), acc);
     } else if (dWp) {
         atomicAdd(dWp + i * 32 + j, acc);                     // dWp[cr=i][cd=j]
+    }
+}
+
+// The same sum for up to kRedAllMax layers in one launch (blockIdx.z = layer): the stack's chained backward keeps
+// every layer's partial tiles and reduces them all at the end, instead of 40 small launches between the layer kernels.
+static constexpr int kRedAllMax = 64;
+struct RedAllArgs { float* dWf[kRedAllMax]; float* dWg[kRedAllMax]; float* dWp[kRedAllMax]; };
+__global__ void k_layer_bwd_reduce_all(const float* __restrict__ part, long long layer_stride, int nwg, RedAllArgs a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kPartFloats) return;
+    const int l = blockIdx.z;
+    const float* __restrict__ p = part + (long long)l * layer_stride;
+    const int per = (nwg + kRedParts - 1) / kRedParts;
+    const int w0 = blockIdx.y * per, w1 = min(nwg, w0 + per);
+    if (w1 <= w0) return;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int w = w0; w < w1; ++w) acc += p[(long long)w * kPartFloats + e];
+    const int tile = e >> 10, r = (e >> 6) & 15, lane = e & 63;
+    const int j = lane & 31, i = bch(r, lane >> 5);
+    if (tile < 4) {
+        float* dW = tile < 2 ? a.dWf[l] : a.dWg[l];
+        if (dW) atomicAdd(dW + (i * 32 + j) * 2 + (tile & 1), acc);
+    } else if (a.dWp[l]) {
+        atomicAdd(a.dWp[l] + i * 32 + j, acc);
     }
 }
 
@@ -1052,15 +1400,15 @@ size_t mfma_layer_bwd_extra_ws_floats() { return (size_t)kMaxBlocks * kPartFloat
 int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
                          const float* Wp, const float* Vin, const float* Uin, int dU, const float* dzs, float* Vout,
                          float* Uout, float* dWf, float* dWg, float* dWp, float* part, int B, int T, int d, int Z,
-                         hipStream_t s) {
+                         bool defer_reduce, hipStream_t s) {
     const int tiles_per_b = (T + 31) / 32;
     const long long nt = (long long)B * tiles_per_b;
     WN_CHECK_SHAPE(nt < (1ll << 31), "mfma_layer_bwd_chain: too many tiles");
     WN_CHECK_ARG(Vin || Uin || dzs, "mfma_layer_bwd_chain: no incoming gradient");
     const int ntiles = (int)nt;
-    static const int variant = [] {                      // 0: producer/consumer pairs (default), 1: chain8, 2: first chained kernel
+    static const int variant = [] {      // 0: producer/consumer pairs, 1: chain8, 2: first chained kernel, 3: software-pipelined
         const char* e = getenv("WAVENET_HIP_CHAIN");
-        return !e ? 0 : !strcmp(e, "v2") ? 1 : !strcmp(e, "old") ? 2 : 0;
+        return !e ? 3 : !strcmp(e, "pc") ? 0 : !strcmp(e, "v2") ? 1 : !strcmp(e, "old") ? 2 : 3;
     }();
     int blocks = variant == 2 ? (ntiles + 3) / 4 : (ntiles + kCWaves - 1) / kCWaves;
     const int maxb = variant == 2 ? kMaxBlocks : kCMaxBlocks;
@@ -1082,6 +1430,8 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
                            dU, dzs, Vout, Uout, part, B, T, d, Z, tiles_per_b, ntiles);                            \
     } else if (variant == 1) {                                                                                     \
         CH_LAUNCH_LDS((k_layer_bwd_chain8<DO, UU, DZ>), 64 * kCWaves);                                             \
+    } else if (variant == 3) {                                                                                     \
+        CH_LAUNCH_LDS((k_layer_bwd_chainsp<DO, UU, DZ>), 256);                                                     \
     } else {                                                                                                       \
         CH_LAUNCH_LDS((k_layer_bwd_chainpc<DO, UU, DZ>), 512);                                                     \
     }
@@ -1098,9 +1448,33 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
 #undef CH_LAUNCH
 #undef CH_LAUNCH_LDS
     WN_LAUNCH_CHECK();
+    if (defer_reduce) return WN_OK;                  // the caller sums all layers' partial tiles with mfma_chain_reduce_all
     hipLaunchKernelGGL(k_layer_bwd_reduce, dim3(kPartFloats / 256, kRedParts), dim3(256), 0, s, part, blocks, dWf, dWg,
                        (Vin || Uin) ? dWp : (float*)nullptr);
     WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+size_t mfma_chain_part_floats() { return (size_t)kMaxBlocks * kPartFloats; }
+
+// Sum the partial tiles of L layers (layer l at part + l * mfma_chain_part_floats()) into their weight gradients.
+// dWp[l] == NULL: that layer had no gradient through its output (the top layer of the stack).
+int mfma_chain_reduce_all(const float* part, int L, int B, int T, float* const* dWf, float* const* dWg,
+                          float* const* dWp, hipStream_t s) {
+    const int tiles_per_b = (T + 31) / 32;
+    const long long nt = (long long)B * tiles_per_b;
+    static const bool old_kernel = [] { const char* e = getenv("WAVENET_HIP_CHAIN"); return e && !strcmp(e, "old"); }();
+    int blocks = old_kernel ? (int)((nt + 3) / 4) : (int)((nt + kCWaves - 1) / kCWaves);     // as mfma_layer_bwd_chain
+    const int maxb = old_kernel ? kMaxBlocks : kCMaxBlocks;
+    if (blocks > maxb) blocks = maxb;
+    for (int l0 = 0; l0 < L; l0 += kRedAllMax) {
+        const int n = L - l0 < kRedAllMax ? L - l0 : kRedAllMax;
+        RedAllArgs a{};
+        for (int l = 0; l < n; ++l) { a.dWf[l] = dWf[l0 + l]; a.dWg[l] = dWg[l0 + l]; a.dWp[l] = dWp[l0 + l]; }
+        hipLaunchKernelGGL(k_layer_bwd_reduce_all, dim3(kPartFloats / 256, kRedParts, n), dim3(256), 0, s,
+                           part + (size_t)l0 * mfma_chain_part_floats(), (long long)mfma_chain_part_floats(), blocks, a);
+        WN_LAUNCH_CHECK();
+    }
     return WN_OK;
 }
 

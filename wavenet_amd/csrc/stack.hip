@@ -40,6 +40,9 @@ size_t wn_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T) {
     if (lw < n * 2 * maxcd) lw = n * 2 * maxcd;
     tot += lw;
     tot += 2 * n * d->Cr;           // ping-pong gradient of the residual stream
+    bool fast = true;               // chained MFMA path: every layer keeps its partial weight-gradient tiles until the end
+    for (int l = 0; l < d->n_layers && fast; ++l) fast = wn_layer_fast_path(d->Cr, d->cd[l], d->fw) != 0;
+    if (fast) tot += (size_t)d->n_layers * mfma_chain_part_floats();
     return tot * sizeof(float);
 }
 
@@ -112,8 +115,9 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
     if (chain) {
         // the (da,dg) scratch is not needed: its room holds the partial weight-gradient tiles and, together with the
         // two ping-pong buffers, the split gradient (V, U) of two consecutive layers
-        float* part = dab;
+        float* parts = gbuf[1] + n * d->Cr;          // L x mfma_chain_part_floats(): summed once, after the last layer
         float* vu = dab + mfma_layer_bwd_extra_ws_floats();
+        std::vector<float*> dWp_eff(L);
         float* Vb[2] = {vu, vu + n * d->Cr};
         float* Ub[2] = {vu + 2 * n * d->Cr, vu + 3 * n * d->Cr};
         const float* Vin = dout;
@@ -124,10 +128,17 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
             const float* in = l == 0 ? x : xs + (size_t)(l - 1) * n * d->Cr;
             int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
             rc = mfma_layer_bwd_chain(in, f + off[l], g + off[l], d->Wf[l], d->Wg[l], d->Wp[l], Vin, Uin, dU,
-                                      dskip ? dzp[l] : nullptr, Vb[l & 1], Ub[l & 1], dWf[l], dWg[l], dWp[l], part, B, T,
-                                      d->dilation[l], Z, as_stream(stream));
+                                      dskip ? dzp[l] : nullptr, Vb[l & 1], Ub[l & 1], dWf[l], dWg[l], dWp[l],
+                                      parts + (size_t)l * mfma_chain_part_floats(), B, T, d->dilation[l], Z, true,
+                                      as_stream(stream));
             if (rc) return rc;
+            dWp_eff[l] = (Vin || Uin) ? dWp[l] : nullptr;
             Vin = Vb[l & 1]; Uin = Ub[l & 1]; dU = d->dilation[l];
+        }
+        {
+            wn::ProfScope prof__("wn_layer_bwd", stream);
+            rc = mfma_chain_reduce_all(parts, L, B, T, dWf, dWg, dWp_eff.data(), as_stream(stream));
+            if (rc) return rc;
         }
         if (dx) return mfma_chain_combine(Vin, Uin, dx, B, T, dU, as_stream(stream));
         return WN_OK;

@@ -53,7 +53,10 @@ size_t mfma_layer_bwd_extra_ws_floats();
 int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
                          const float* Wp, const float* Vin, const float* Uin, int dU, const float* dzs, float* Vout,
                          float* Uout, float* dWf, float* dWg, float* dWp, float* part, int B, int T, int d, int Z,
-                         hipStream_t s);
+                         bool defer_reduce, hipStream_t s);
+size_t mfma_chain_part_floats();
+int mfma_chain_reduce_all(const float* part, int L, int B, int T, float* const* dWf, float* const* dWg,
+                          float* const* dWp, hipStream_t s);
 int mfma_chain_combine(const float* V, const float* U, float* dx, int B, int T, int dU, hipStream_t s);
 int generic_layer_bwd_biases(const float* dab, const float* dout, float* dbf, float* dbg, float* dbp, int B,
                              int T, int Cr, int Cd, int Z, hipStream_t s);
