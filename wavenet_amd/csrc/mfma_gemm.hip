@@ -373,6 +373,7 @@ int launch_wgrad(WGArgs& a, int M, hipStream_t s) {
     a.rows_per_wg = rows;
     a.wgs_per_b = cdiv(a.rows_A_per_b, rows);
     dim3 grid(a.nB * a.wgs_per_b, cdiv(a.nprob, 4), M / (mt * 32));
+    if (gemm_b3_enabled() && M == 256 && a.nprob >= 8) return launch_wgrad_b3w(a, s);
     if (gemm_b3_enabled()) {          // bf16x3: at most 4 row tiles per workgroup (register budget), more groups in z
         const int mt3 = mt > 4 ? 4 : mt;
         grid.z = M / (mt3 * 32);

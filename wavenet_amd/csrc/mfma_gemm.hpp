@@ -44,6 +44,8 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s);
 
 // dW_p[m*ldo + k*osk] += sum_n A[n][m] * act(B_p[row(n)][k]) (* B2_p);  M rows; picks bf16x3 or exact fp32
 int launch_wgrad(WGArgs& a, int M, hipStream_t s);
+// wide bf16x3 block (M == 256, nprob >= 8)
+int launch_wgrad_b3w(WGArgs a, hipStream_t s);
 // one channel GEMM launch (multi-source form); picks bf16x3 or exact fp32
 int launch_colgemm_multi(CGArgs& a, hipStream_t s);
 // bf16x3 form of k_wgrad_mfma (same grid / arguments)

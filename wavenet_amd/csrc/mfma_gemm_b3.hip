@@ -406,6 +406,174 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
             atomicAdd(o + (long long)(m0 + mt * 32 + b3_ch(r, h)) * a.ldo + (long long)j * (a.osk ? a.osk : 1), acc[mt][r]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide weight-gradient block: 8 waves, all 256 rows of A (8 m-tiles) x 8 problems of 32 columns per workgroup.
+// k_wgrad_b3<4> (4 waves, 128 x 128) spends 75 % of its wave-cycles waiting (PMC: SQ_WAIT_ANY; the matrix pipe is 17 %
+// busy): two barriers per 32-row chunk and ~260 split/pack VALU instructions per wave against 48 MFMAs.  Here a chunk
+// of A is split ONCE per 256 x 256 block (16 values per thread), the image is double buffered in LDS (96 KB, one
+// barrier per chunk), and every wave runs 96 MFMAs per chunk on its own problem's B values.
+// Grid: x = batch * row slabs, y = ceil(nprob / 8); M == 256.
+// ---------------------------------------------------------------------------------------------
+template <bool HAS_B2>
+__global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
+    constexpr int MT = 8;
+    extern __shared__ __attribute__((aligned(16))) char ldsw[];               // 2 x MT x 6 KB
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int p = blockIdx.y * 8 + wv;
+    const bool active = p < a.nprob;
+    const int b = blockIdx.x / a.wgs_per_b;
+    const int r_begin = (blockIdx.x - b * a.wgs_per_b) * a.rows_per_wg;
+    const int r_end = min(a.rows_A_per_b, r_begin + a.rows_per_wg);
+    const float* __restrict__ Ab = a.A + ((long long)b * a.rows_A_per_b) * a.lda;
+    const float* __restrict__ Bb = a.Bp[active ? p : 0] + ((long long)b * a.rows_B_per_b + a.off) * a.ldb + j;
+    const float* __restrict__ B2b = a.B2p[active ? p : 0] ? a.B2p[active ? p : 0] + ((long long)b * a.rows_B_per_b + a.off) * a.ldb + j : nullptr;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    // A fragments of this thread: channel fm, row groups g = 2*ks + hh for (ks, hh) = (it, tid >> 8)
+    const int fm = tid & 255;
+    const int fhh = tid >> 8;
+    // Loads only -- no activation, no masks, no runtime-conditional loads: a uniform `if` around a load (the optional
+    // B2 factor, `active ? load : 0`, the activation switch) makes hipcc branch and drain vmcnt PER ELEMENT, which
+    // serialised the sixteen B loads of every chunk (0.44 ms of this kernel's 0.76 ms at config 2).  Rows are clamped
+    // in the edge chunk; everything else happens at split time on registers.
+    float ar[2][8], br[2][8], b2r[2][8];
+    const float* __restrict__ B2s = HAS_B2 ? B2b : Bb;
+    auto issue = [&](int r0) {
+        const bool full = r0 + 32 <= r_end && r0 + a.off >= 0 && r0 + 31 + a.off < a.rows_B_per_b;
+        if (full) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const float* ap = Ab + (long long)(r0 + 16 * ks + 8 * fhh) * a.lda + fm;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) ar[ks][jj] = ap[(long long)jj * a.lda];
+            }
+            const float* bp = Bb + (long long)(r0 + 8 * h) * a.ldb;
+            const float* b2p = B2s + (long long)(r0 + 8 * h) * a.ldb;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    br[ks][jj] = bp[(long long)(16 * ks + jj) * a.ldb];
+                    if (HAS_B2) b2r[ks][jj] = b2p[(long long)(16 * ks + jj) * a.ldb];
+                }
+            return;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int r = r0 + 16 * ks + 8 * fhh + jj;
+                const int rc = r < r_end ? r : r_end - 1;
+                ar[ks][jj] = Ab[(long long)rc * a.lda + fm];
+            }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int r = r0 + 16 * ks + 8 * h + jj;
+                int rc = r < r_end ? r : r_end - 1;
+                if (rc + a.off < 0) rc = -a.off;
+                if (rc + a.off >= a.rows_B_per_b) rc = a.rows_B_per_b - 1 - a.off;
+                br[ks][jj] = Bb[(long long)rc * a.ldb];
+                if (HAS_B2) b2r[ks][jj] = B2s[(long long)rc * a.ldb];
+            }
+    };
+    const float amask = active ? 1.f : 0.f;
+    if (r_begin < r_end) issue(r_begin);
+    int c = 0;
+    for (int r0 = r_begin; r0 < r_end; r0 += 32, ++c) {
+        char* buf = ldsw + (c & 1) * (MT * kTileBytes);
+        bf16x8 bh[2], bm[2], bl[2];
+        const bool edge = !(r0 + 32 <= r_end && r0 + a.off >= 0 && r0 + 31 + a.off < a.rows_B_per_b);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 ah, am, al;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float av = ar[ks][e];
+                float bv = act_apply(br[ks][e], a.act) * amask;
+                if (HAS_B2) bv *= b2r[ks][e];
+                if (edge) {                              // rows beyond the slab / outside B's clip contribute nothing
+                    const int ra = r0 + 16 * ks + 8 * fhh + e;
+                    const int rb = r0 + 16 * ks + 8 * h + e;
+                    av *= ra < r_end ? 1.f : 0.f;
+                    bv *= (rb < r_end && rb + a.off >= 0 && rb + a.off < a.rows_B_per_b) ? 1.f : 0.f;
+                }
+                __bf16 x0, x1, x2;
+                split3(av, x0, x1, x2);
+                ah[e] = x0; am[e] = x1; al[e] = x2;
+                split3(bv, x0, x1, x2);
+                bh[ks][e] = x0; bm[ks][e] = x1; bl[ks][e] = x2;
+            }
+            // image: tile fm>>5, [ks][comp][lane = (fm & 31) + 32*fhh][8]
+            char* d = buf + (fm >> 5) * kTileBytes + (ks * 3) * 1024 + ((fm & 31) + 32 * fhh) * 16;
+            *reinterpret_cast<bf16x8*>(d) = ah;
+            *reinterpret_cast<bf16x8*>(d + 1024) = am;
+            *reinterpret_cast<bf16x8*>(d + 2048) = al;
+        }
+        __syncthreads();                 // the image of this chunk is complete (the buffer written next was read two chunks ago)
+        if (r0 + 32 < r_end) issue(r0 + 32);                 // in flight during the MFMAs below
+        const char* Al = buf + lane * 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const char* q = Al + mt * kTileBytes + ks * 3 * 1024;
+                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(q);
+                const bf16x8 xm = *reinterpret_cast<const bf16x8*>(q + 1024);
+                const bf16x8 xl = *reinterpret_cast<const bf16x8*>(q + 2048);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm[ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh[ks], acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    if (!active) return;
+    float* __restrict__ o = a.out[p];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            atomicAdd(o + (long long)(mt * 32 + b3_ch(r, h)) * a.ldo + (long long)j * (a.osk ? a.osk : 1), acc[mt][r]);
+}
+
+// M == 256 and at least 8 problems: the wide block.  Picks its own row slabs (one workgroup per CU).
+int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_b3w<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * kTileBytes));
+        WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_b3w<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * kTileBytes));
+        attr_set = true;
+    }
+    const int gy = (a.nprob + 7) / 8;
+    int slabs = 256 / gy;                                    // workgroups in flight: one per CU
+    if (slabs < 1) slabs = 1;
+    int per_b = slabs / a.nB;                                // never more workgroups than CUs: a second round doubles the time
+    if (per_b < 1) per_b = 1;
+    int rows = (a.rows_A_per_b + per_b - 1) / per_b;
+    rows = ((rows + 31) / 32) * 32;
+    if (rows < 256) rows = 256;
+    a.rows_per_wg = rows;
+    a.wgs_per_b = (a.rows_A_per_b + rows - 1) / rows;
+    bool any_b2 = false, all_b2 = true;
+    for (int q = 0; q < a.nprob; ++q) { any_b2 |= a.B2p[q] != nullptr; all_b2 &= a.B2p[q] != nullptr; }
+    if (any_b2 != all_b2) { wn::set_error("wgrad_b3w: the B2 factor must be given for all problems or for none"); return WN_EARG; }
+    if (any_b2) hipLaunchKernelGGL(k_wgrad_b3w<true>, dim3(a.nB * a.wgs_per_b, gy), dim3(512), 2 * 8 * kTileBytes, s, a);
+    else hipLaunchKernelGGL(k_wgrad_b3w<false>, dim3(a.nB * a.wgs_per_b, gy), dim3(512), 2 * 8 * kTileBytes, s, a);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
 int launch_wgrad_b3(const WGArgs& a, int mt, dim3 grid, hipStream_t s) {
     switch (mt) {
         case 8: hipLaunchKernelGGL(k_wgrad_b3<8>, grid, dim3(256), 0, s, a); break;
