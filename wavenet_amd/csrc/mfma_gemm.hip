@@ -279,7 +279,7 @@ int mfma_pointwise_bwd_dx(const float* x, const float* W, const float* dout, flo
 namespace wn {
 
 
-template <int MT>
+template <int MT, bool HAS_B2>
 __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WGArgs a) {
     __shared__ __attribute__((aligned(16))) float Alds[32 * MT * 32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -291,8 +291,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WGArgs a) {
     const int r_begin = (blockIdx.x - b * a.wgs_per_b) * a.rows_per_wg;
     const int r_end = min(a.rows_A_per_b, r_begin + a.rows_per_wg);
     const float* __restrict__ Ab = a.A + ((long long)b * a.rows_A_per_b) * a.lda + m0;
-    const float* __restrict__ Bb = active ? a.Bp[p] + ((long long)b * a.rows_B_per_b + a.off) * a.ldb + j : nullptr;
-    const float* __restrict__ B2b = (active && a.B2p[p]) ? a.B2p[p] + ((long long)b * a.rows_B_per_b + a.off) * a.ldb + j : nullptr;
+    // inactive waves read problem 0 (masked): every load below is unconditional -- a runtime condition around a load
+    // makes hipcc branch and drain vmcnt per element (see k_wgrad_b3w in mfma_gemm_b3.hip)
+    const float* __restrict__ Bb = a.Bp[active ? p : 0] + ((long long)b * a.rows_B_per_b + a.off) * a.ldb + j;
+    const float* __restrict__ B2b = HAS_B2 ? a.B2p[active ? p : 0] + ((long long)b * a.rows_B_per_b + a.off) * a.ldb + j : Bb;
     f32x16 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -313,16 +315,23 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WGArgs a) {
             v.x *= m; v.y *= m; v.z *= m; v.w *= m;
             ar[it] = v;
         }
+        float raw[16], raw2[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int r = r0 + 2 * s + h;
+            int rc = r < r_end ? r : r_end - 1;                              // clamped row, masked value
+            if (rc + a.off < 0) rc = -a.off;
+            if (rc + a.off >= a.rows_B_per_b) rc = a.rows_B_per_b - 1 - a.off;
+            raw[s] = Bb[(long long)rc * a.ldb];
+            if (HAS_B2) raw2[s] = B2b[(long long)rc * a.ldb];
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int r = r0 + 2 * s + h;
             const int rb = r + a.off;
             const bool ok = active && r < r_end && rb >= 0 && rb < a.rows_B_per_b;
-            int rc = r < r_end ? r : r_end - 1;                              // clamped row, masked value
-            if (rc + a.off < 0) rc = -a.off;
-            if (rc + a.off >= a.rows_B_per_b) rc = a.rows_B_per_b - 1 - a.off;
-            float v = active ? act_apply(Bb[(long long)rc * a.ldb], a.act) : 0.f;
-            if (B2b) v *= B2b[(long long)rc * a.ldb];
+            float v = act_apply(raw[s], a.act);
+            if (HAS_B2) v *= raw2[s];
             br[s] = ok ? v : 0.f;
         }
     };
@@ -379,12 +388,21 @@ int launch_wgrad(WGArgs& a, int M, hipStream_t s) {
         grid.z = M / (mt3 * 32);
         return launch_wgrad_b3(a, mt3, grid, s);
     }
+    bool any_b2 = false, all_b2 = true;
+    for (int q = 0; q < a.nprob; ++q) { any_b2 |= a.B2p[q] != nullptr; all_b2 &= a.B2p[q] != nullptr; }
+    if (any_b2 != all_b2) { wn::set_error("wgrad: the B2 factor must be given for all problems or for none"); return WN_EARG; }
+#define WG_LAUNCH(MT_)                                                                               \
+    do {                                                                                             \
+        if (any_b2) hipLaunchKernelGGL((k_wgrad_mfma<MT_, true>), grid, dim3(256), 0, s, a);         \
+        else hipLaunchKernelGGL((k_wgrad_mfma<MT_, false>), grid, dim3(256), 0, s, a);               \
+    } while (0)
     switch (mt) {
-        case 8: hipLaunchKernelGGL(k_wgrad_mfma<8>, grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(k_wgrad_mfma<4>, grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(k_wgrad_mfma<2>, grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(k_wgrad_mfma<1>, grid, dim3(256), 0, s, a); break;
+        case 8: WG_LAUNCH(8); break;
+        case 4: WG_LAUNCH(4); break;
+        case 2: WG_LAUNCH(2); break;
+        default: WG_LAUNCH(1); break;
     }
+#undef WG_LAUNCH
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

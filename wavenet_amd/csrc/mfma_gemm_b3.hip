@@ -268,7 +268,7 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
 //     A-operand image layout as above; raw loads of chunk c+1 are in flight during the MFMAs of chunk c;
 //   * B (one 32-channel tile per wave): eight dword loads per lane per k-step, split in registers.
 // =============================================================================================
-template <int MT>
+template <int MT, bool HAS_B2>
 __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[MT * kTileBytes];          // one 32-row chunk of A, split
     constexpr int NF = MT / 2 > 0 ? MT / 2 : 1;             // A fragments per thread per chunk (MT*128 / 256)
@@ -289,7 +289,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-    float ar[NF][8], br[2][8];
+    // loads only, never under a runtime condition (see k_wgrad_b3w): activation, the B2 factor and the edge masks are
+    // applied at split time on registers
+    float ar[NF][8], br[2][8], b2r[2][8];
+    const float* __restrict__ B2s = HAS_B2 ? B2b : Bb;
+    const float amask = active ? 1.f : 0.f;
     // per-thread fragment coordinates are chunk-invariant
     int fm[NF], fg[NF];
 #pragma unroll
@@ -299,7 +303,6 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
         fg[it] = f / (MT * 32);
     }
     auto issue = [&](int r0) {
-        // whole chunk inside the slab and inside B's rows (every chunk but possibly the last): no clamps, no masks
         const bool full = r0 + 32 <= r_end && r0 + a.off >= 0 && r0 + 31 + a.off < a.rows_B_per_b;
         if (full) {
 #pragma unroll
@@ -309,60 +312,63 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
                 for (int jj = 0; jj < 8; ++jj) ar[it][jj] = ap[(long long)jj * a.lda];
             }
             const float* bp = Bb + (long long)(r0 + 8 * h) * a.ldb;
+            const float* b2p = B2s + (long long)(r0 + 8 * h) * a.ldb;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
-                    float v = active ? act_apply(bp[(long long)(16 * ks + jj) * a.ldb], a.act) : 0.f;
-                    if (B2b) v *= B2b[(long long)(r0 + 8 * h + 16 * ks + jj) * a.ldb];
-                    br[ks][jj] = v;
+                    br[ks][jj] = bp[(long long)(16 * ks + jj) * a.ldb];
+                    if (HAS_B2) b2r[ks][jj] = b2p[(long long)(16 * ks + jj) * a.ldb];
                 }
             return;
         }
 #pragma unroll
-        for (int it = 0; it < NF; ++it) {
-            const int m = fm[it], g = fg[it];
-            const bool fv = MT >= 2 || g < 4;                // MT == 1: only 128 fragments exist
+        for (int it = 0; it < NF; ++it)
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
-                const int r = r0 + 8 * (fv ? g : 0) + jj;
-                const int rc = r < r_end ? r : r_end - 1;    // clamped row, masked value
-                ar[it][jj] = Ab[(long long)rc * a.lda + m] * ((fv && r < r_end) ? 1.f : 0.f);
+                const int r = r0 + 8 * (fg[it] & 3) + jj;
+                const int rc = r < r_end ? r : r_end - 1;    // clamped row, masked at split time
+                ar[it][jj] = Ab[(long long)rc * a.lda + fm[it]];
             }
-        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
                 const int r = r0 + 16 * ks + 8 * h + jj;
-                const int rb = r + a.off;
-                const bool ok = active && r < r_end && rb >= 0 && rb < a.rows_B_per_b;
                 int rc = r < r_end ? r : r_end - 1;
                 if (rc + a.off < 0) rc = -a.off;
                 if (rc + a.off >= a.rows_B_per_b) rc = a.rows_B_per_b - 1 - a.off;
-                float v = ok ? act_apply(Bb[(long long)rc * a.ldb], a.act) : 0.f;
-                if (B2b) v *= B2b[(long long)rc * a.ldb];
-                br[ks][jj] = v;
+                br[ks][jj] = Bb[(long long)rc * a.ldb];
+                if (HAS_B2) b2r[ks][jj] = B2s[(long long)rc * a.ldb];
             }
     };
     if (r_begin < r_end) issue(r_begin);
     for (int r0 = r_begin; r0 < r_end; r0 += 32) {
         // split this chunk's operands (loads were issued one iteration ago)
         bf16x8 ah[NF], am[NF], al[NF], bh[2], bm[2], bl[2];
+        const bool edge = !(r0 + 32 <= r_end && r0 + a.off >= 0 && r0 + 31 + a.off < a.rows_B_per_b);
 #pragma unroll
         for (int it = 0; it < NF; ++it)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
+                float av = ar[it][e];
+                if (edge) av *= (r0 + 8 * (fg[it] & 3) + e) < r_end ? 1.f : 0.f;
                 __bf16 x0, x1, x2;
-                split3(ar[it][e], x0, x1, x2);
+                split3(av, x0, x1, x2);
                 ah[it][e] = x0; am[it][e] = x1; al[it][e] = x2;
             }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
+                float bv = act_apply(br[ks][e], a.act) * amask;
+                if (HAS_B2) bv *= b2r[ks][e];
+                if (edge) {
+                    const int rb = r0 + 16 * ks + 8 * h + e;
+                    bv *= (rb < r_end && rb + a.off >= 0 && rb + a.off < a.rows_B_per_b) ? 1.f : 0.f;
+                }
                 __bf16 x0, x1, x2;
-                split3(br[ks][e], x0, x1, x2);
+                split3(bv, x0, x1, x2);
                 bh[ks][e] = x0; bm[ks][e] = x1; bl[ks][e] = x2;
             }
         __syncthreads();                                     // the previous chunk's MFMAs are done with the image
@@ -575,12 +581,21 @@ int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
 }
 
 int launch_wgrad_b3(const WGArgs& a, int mt, dim3 grid, hipStream_t s) {
+    bool any_b2 = false, all_b2 = true;
+    for (int q = 0; q < a.nprob; ++q) { any_b2 |= a.B2p[q] != nullptr; all_b2 &= a.B2p[q] != nullptr; }
+    if (any_b2 != all_b2) { wn::set_error("wgrad_b3: the B2 factor must be given for all problems or for none"); return WN_EARG; }
+#define WG_LAUNCH(MT_)                                                                              \
+    do {                                                                                            \
+        if (any_b2) hipLaunchKernelGGL((k_wgrad_b3<MT_, true>), grid, dim3(256), 0, s, a);          \
+        else hipLaunchKernelGGL((k_wgrad_b3<MT_, false>), grid, dim3(256), 0, s, a);                \
+    } while (0)
     switch (mt) {
-        case 8: hipLaunchKernelGGL(k_wgrad_b3<8>, grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(k_wgrad_b3<4>, grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(k_wgrad_b3<2>, grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(k_wgrad_b3<1>, grid, dim3(256), 0, s, a); break;
+        case 8: WG_LAUNCH(8); break;
+        case 4: WG_LAUNCH(4); break;
+        case 2: WG_LAUNCH(2); break;
+        default: WG_LAUNCH(1); break;
     }
+#undef WG_LAUNCH
     WN_LAUNCH_CHECK();
     return WN_OK;
 }
