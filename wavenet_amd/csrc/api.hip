@@ -169,7 +169,7 @@ int wn_skip_sum_bwd_dz(int L, const float* const* Ws, const int* cd, const float
     for (int l = 0; l < L; ++l) WN_CHECK_ARG(dz[l] && Ws[l] && cd[l] > 0, "wn_skip_sum_bwd_dz: bad entry %d", l);
     bool fast = !force_generic() && Cs % 32 == 0;
     for (int l = 0; l < L && fast; ++l) fast = cd[l] % 32 == 0;
-    if (fast) return mfma_skip_bwd_dz(L, Ws, cd, dskip, dz, B, T, t_off, Tw, Cs, as_stream(stream));
+    if (fast) return mfma_skip_bwd_dz(L, Ws, cd, dskip, dz, B, T, t_off, Tw, Cs, false, as_stream(stream));
     return generic_skip_bwd_dz(L, Ws, cd, dskip, dz, B, T, t_off, Tw, Cs, as_stream(stream));
 }
 

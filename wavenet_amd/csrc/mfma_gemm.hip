@@ -37,10 +37,12 @@ __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
     const bool nvalid = n < a.N;
     long long rb0 = 0;                 // first source row of this column's clip
     int rbase = -(1 << 30);            // row inside the clip before the per-source shift (invalid column: far out)
+    long long no = n;                  // output row of this column
     if (nvalid) {
         long long b = n / a.rows_out_per_b;
         rbase = (int)(n - b * a.rows_out_per_b) + a.off;
         rb0 = b * a.rows_src_per_b;
+        if (a.out_rows_per_b) no = b * a.out_rows_per_b + a.out_row0 + (n - b * a.rows_out_per_b);
     }
     f32x16 acc[MT];
 #pragma unroll
@@ -126,24 +128,24 @@ __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
         if (!more) break;
     }
     if (!nvalid) return;
-    float* __restrict__ orow = a.out[MODE == 2 ? 0 : prob] + n * a.ldo + m0 + 4 * h;
+    float* __restrict__ orow = a.out[MODE == 2 ? 0 : prob] + no * a.ldo + m0 + 4 * h;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (MODE == 2) {
             if (prob + mt >= a.nprob) break;
-            orow = a.out[prob + mt] + n * a.ldo + 4 * h - mt * 32;
+            orow = a.out[prob + mt] + no * a.ldo + 4 * h - mt * 32;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 v = make_float4(acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
             float* p = orow + mt * 32 + 8 * q;
             if (a.gate_x) {
-                float4 gx = *reinterpret_cast<const float4*>(a.gate_x + n * a.ldo + m0 + 4 * h + mt * 32 + 8 * q);
+                float4 gx = *reinterpret_cast<const float4*>(a.gate_x + no * a.ldo + m0 + 4 * h + mt * 32 + 8 * q);
                 v.x *= act_grad(gx.x, a.gate_act); v.y *= act_grad(gx.y, a.gate_act);
                 v.z *= act_grad(gx.z, a.gate_act); v.w *= act_grad(gx.w, a.gate_act);
             }
             if (a.residual && MODE == 0) {
-                const float4 rr = *reinterpret_cast<const float4*>(a.residual + n * a.ldo + m0 + 4 * h + mt * 32 + 8 * q);
+                const float4 rr = *reinterpret_cast<const float4*>(a.residual + no * a.ldo + m0 + 4 * h + mt * 32 + 8 * q);
                 v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
             }
             if (a.accumulate) {
@@ -216,8 +218,9 @@ int mfma_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, cons
     return WN_OK;
 }
 
+// window_only: compute (and write) columns t >= t_off only; the rows below are left untouched
 int mfma_skip_bwd_dz(int L, const float* const* Ws, const int* cd, const float* dskip, float* const* dz, int B,
-                     int T, int t_off, int Tw, int Cs, hipStream_t s) {
+                     int T, int t_off, int Tw, int Cs, bool window_only, hipStream_t s) {
     // every layer is cd/32 problems of 32 output rows sharing X = dskip; batches of <= WN_MAX_SRC problems with
     // one row stride (ldo = cd) per launch
     int l = 0, j = 0;                 // next layer, next 32-row tile inside it
@@ -231,8 +234,13 @@ int mfma_skip_bwd_dz(int L, const float* const* Ws, const int* cd, const float* 
         }
         a.nsrc = 1; a.X[0] = dskip; a.K[0] = Cs; a.bias[0] = nullptr;
         a.wsk = width;                                    // W[m][k] = Ws[k][m]
-        a.M = 32; a.ldo = width; a.N = (long long)B * T;
-        a.rows_out_per_b = T; a.rows_src_per_b = Tw; a.off = -t_off;
+        a.M = 32; a.ldo = width;
+        if (window_only) {
+            a.N = (long long)B * Tw; a.rows_out_per_b = Tw; a.rows_src_per_b = Tw; a.off = 0;
+            a.out_rows_per_b = T; a.out_row0 = t_off;
+        } else {
+            a.N = (long long)B * T; a.rows_out_per_b = T; a.rows_src_per_b = Tw; a.off = -t_off;
+        }
         a.act = WN_ACT_NONE; a.gate_x = nullptr; a.accumulate = 0;
         int rc = launch_colgemm<true>(a, np, s);
         if (rc) return rc;

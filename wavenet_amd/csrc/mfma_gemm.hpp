@@ -16,6 +16,7 @@ struct CGArgs {
     int nsrc, nprob, M, ldo;
     long long N;                     // output rows
     int rows_out_per_b, rows_src_per_b, off;   // src row = b*rows_src_per_b + (n % rows_out_per_b) + off + soff[src]
+    int out_rows_per_b, out_row0;    // out row of column n = b*out_rows_per_b + out_row0 + n % rows_out_per_b; 0, 0 = row n
     int soff[WN_MAX_SRC];            // per-source row shift (dilated taps); rows outside [0, rows_src_per_b) read as 0
     int act;                         // applied to X on load
     const float* gate_x; int gate_act;         // out *= act'(gate_x[n][m])   (dx of a pre-activated conv)

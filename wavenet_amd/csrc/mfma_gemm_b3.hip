@@ -96,10 +96,12 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
     const bool nvalid = n < a.N;
     long long rb0 = 0;                 // first source row of this column's clip
     int rbase = -(1 << 30);            // row inside the clip before the per-source shift (invalid column: far out)
+    long long no = n;                  // output row of this column
     if (nvalid) {
         long long b = n / a.rows_out_per_b;
         rbase = (int)(n - b * a.rows_out_per_b) + a.off;
         rb0 = b * a.rows_src_per_b;
+        if (a.out_rows_per_b) no = b * a.out_rows_per_b + a.out_row0 + (n - b * a.rows_out_per_b);
     }
     float ms = 0.f, ms_next = 0.f;     // masks of the chunk being computed / being fetched
 
@@ -189,19 +191,19 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (t0 + mt >= mtiles) break;
-        float* __restrict__ orow = (MODE == 2) ? a.out[t0 + mt] + n * a.ldo + 4 * h
-                                               : a.out[0] + n * a.ldo + (t0 + mt) * 32 + 4 * h;
+        float* __restrict__ orow = (MODE == 2) ? a.out[t0 + mt] + no * a.ldo + 4 * h
+                                               : a.out[0] + no * a.ldo + (t0 + mt) * 32 + 4 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 v = make_float4(acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
             float* p = orow + 8 * q;
             if (MODE == 0 && a.gate_x) {
-                const float4 gx = *reinterpret_cast<const float4*>(a.gate_x + n * a.ldo + (t0 + mt) * 32 + 4 * h + 8 * q);
+                const float4 gx = *reinterpret_cast<const float4*>(a.gate_x + no * a.ldo + (t0 + mt) * 32 + 4 * h + 8 * q);
                 v.x *= act_grad(gx.x, a.gate_act); v.y *= act_grad(gx.y, a.gate_act);
                 v.z *= act_grad(gx.z, a.gate_act); v.w *= act_grad(gx.w, a.gate_act);
             }
             if (MODE == 0 && a.residual) {
-                const float4 rr = *reinterpret_cast<const float4*>(a.residual + n * a.ldo + (t0 + mt) * 32 + 4 * h + 8 * q);
+                const float4 rr = *reinterpret_cast<const float4*>(a.residual + no * a.ldo + (t0 + mt) * 32 + 4 * h + 8 * q);
                 v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
             }
             if (a.accumulate) {

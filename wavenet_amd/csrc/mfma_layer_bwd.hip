@@ -166,196 +166,22 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p1(
 // Chained backward (no pass 2, no (da,dg) scratch).  The gradient of the residual stream is kept in the
 // split form    dout_l[t] = V[t] + U[t + dU]    where the layer above (dilation dU) wrote
 //     V = dout + [Wf1;Wg1]^T dab      (tap 1 reads x[t])        U = [Wf0;Wg0]^T dab    (tap 0 reads x[t-d])
-// so this kernel reads its dout on the fly from two tensors, does everything k_layer_bwd_p1 does, and
+// so the kernel reads its dout on the fly from two tensors, does everything k_layer_bwd_p1 does, and
 // additionally runs the two transposed-weight GEMMs on the (da,dg) it still holds in registers (their
-// accumulator layout IS the MFMA B-operand layout) to emit its own V and U.  The transposed weights sit in
-// LDS in A-operand order (shared by the workgroup's waves).  Per layer this removes the pass-2 kernel,
-// the 256 B/column scratch write and its two re-reads.
+// accumulator layout IS the MFMA B-operand layout) to emit its own V and U.  Per layer this removes the pass-2
+// kernel, the 256 B/column scratch write and its two re-reads.
+//
+// Structures tried on the way, all measured on config 2 (8 x 16,384 columns; DESIGN.md section 5 has the numbers):
+//   1. 4 waves x 2 workgroups per CU, operands loaded straight from memory in MFMA layout, weight-gradient operands
+//      re-read channel-on-lanes: 64 us per layer (96 scalar loads per tile queue behind the V/U stores; 165 MB fetched
+//      for 117 MB of distinct data);
+//   2. one wave per SIMD, every tensor through LDS-DMA exactly once, whole-row stores: 49 us;
+//   3. producer / consumer wave pairs sharing a SIMD: 47 us -- a wave that streams MFMAs starves its sibling's VALU
+//      issue (11,000 cycles for 300 VALU instructions next to the consumer's MFMA stream);
+//   4. (this one) one wave per SIMD, software-pipelined: 45 us.
 // =============================================================================================
-template <bool HAS_DO, bool HAS_U, bool HAS_DZ>
-__global__ __launch_bounds__(256, 2) void k_layer_bwd_chain(
-    const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
-    const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
-    const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, const float* __restrict__ dzs,
-    float* __restrict__ Vout, float* __restrict__ Uout, float* __restrict__ part, int B, int T, int d, int Z,
-    int tiles_per_b, int ntiles) {
-    __shared__ __attribute__((aligned(16))) float lds[kWaves * 2 * 32 * kPad + 5 * 16 * 64 + 4 * 16 * 64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    float* lda = lds + wv * (2 * 32 * kPad);
-    float* ldg = lda + 32 * kPad;
-    float* red = lds + kWaves * 2 * 32 * kPad;
-    float* wT = red + 5 * 16 * 64;                   // [mat f1,g1,f0,g0][s][lane]: W[cd=ch(s,h)][cr=lane&31][k]
-    const int wave = blockIdx.x * kWaves + wv;
-    const int nwaves = gridDim.x * kWaves;
-    for (int e = threadIdx.x; e < 4 * 16 * 64; e += 256) {
-        const int mat = e >> 10, s2 = (e >> 6) & 15, ln = e & 63;
-        const float* W = (mat & 1) ? Wg : Wf;
-        wT[e] = W[(bch(s2, ln >> 5) * 32 + (ln & 31)) * 2 + (mat < 2 ? 1 : 0)];
-    }
-    float wpT[16];                                   // A operand of dz: lane (i=cd,h), step s: Wp[ch(s,h)][i]
-#pragma unroll
-    for (int s = 0; s < 16; ++s) wpT[s] = Wp[bch(s, h) * 32 + j];
-    __syncthreads();
-
-    f32x16 aWf0, aWf1, aWg0, aWg1, aWp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { aWf0[r] = 0.f; aWf1[r] = 0.f; aWg0[r] = 0.f; aWg1[r] = 0.f; aWp[r] = 0.f; }
-
-    for (int tile = wave; tile < ntiles; tile += nwaves) {
-        const int b = tile / tiles_per_b;
-        const int t0 = (tile - b * tiles_per_b) * 32;
-        const int t = t0 + j;
-        const bool valid = t < T;
-        const int tc = valid ? t : T - 1;                                         // clamped rows, masked values
-        const long long rowc = ((long long)b * T + tc) * 32 + 4 * h;
-        const long long rowu = ((long long)b * T + (tc + dU < T ? tc + dU : T - 1)) * 32 + 4 * h;
-        const float mu = (HAS_U && valid && t + dU < T) ? 1.f : 0.f;
-        f32x16 acc;
-        float ff[16], gg[16], dob[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 z4 = make_float4(0, 0, 0, 0), o4 = z4;
-            const float4 f4 = *reinterpret_cast<const float4*>(f + rowc + 8 * q);
-            const float4 g4 = *reinterpret_cast<const float4*>(g + rowc + 8 * q);
-            if (HAS_DZ) z4 = *reinterpret_cast<const float4*>(dzs + rowc + 8 * q);
-            if (HAS_DO) o4 = *reinterpret_cast<const float4*>(Vin + rowc + 8 * q);
-            if (HAS_U) {
-                const float4 u4 = *reinterpret_cast<const float4*>(Uin + rowu + 8 * q);
-                o4.x += u4.x * mu; o4.y += u4.y * mu; o4.z += u4.z * mu; o4.w += u4.w * mu;
-            }
-            acc[4 * q] = z4.x; acc[4 * q + 1] = z4.y; acc[4 * q + 2] = z4.z; acc[4 * q + 3] = z4.w;
-            ff[4 * q] = f4.x; ff[4 * q + 1] = f4.y; ff[4 * q + 2] = f4.z; ff[4 * q + 3] = f4.w;
-            gg[4 * q] = g4.x; gg[4 * q + 1] = g4.y; gg[4 * q + 2] = g4.z; gg[4 * q + 3] = g4.w;
-            dob[4 * q] = o4.x; dob[4 * q + 1] = o4.y; dob[4 * q + 2] = o4.z; dob[4 * q + 3] = o4.w;
-        }
-        if (HAS_DO || HAS_U) {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wpT[s], dob[s], acc, 0, 0, 0);
-        }
-        const bool live = valid && t >= Z;
-        float da[16], dg[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float dz = live ? acc[r] : 0.f;
-            da[r] = dz * gg[r] * (1.f - ff[r] * ff[r]);
-            dg[r] = dz * ff[r] * gg[r] * (1.f - gg[r]);
-        }
-        // V = dout + [Wf1;Wg1]^T dab,  U = [Wf0;Wg0]^T dab: (da,dg) registers are the B operands as they stand
-        {
-            f32x16 v1, u0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { v1[r] = dob[r]; u0[r] = 0.f; }
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wT[(0 * 16 + s) * 64 + lane], da[s], v1, 0, 0, 0);
-                u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wT[(2 * 16 + s) * 64 + lane], da[s], u0, 0, 0, 0);
-                v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wT[(1 * 16 + s) * 64 + lane], dg[s], v1, 0, 0, 0);
-                u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wT[(3 * 16 + s) * 64 + lane], dg[s], u0, 0, 0, 0);
-            }
-            if (valid) {
-                const long long row = ((long long)b * T + t) * 32 + 4 * h;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    *reinterpret_cast<float4*>(Vout + row + 8 * q) = make_float4(v1[4 * q], v1[4 * q + 1], v1[4 * q + 2], v1[4 * q + 3]);
-                    *reinterpret_cast<float4*>(Uout + row + 8 * q) = make_float4(u0[4 * q], u0[4 * q + 1], u0[4 * q + 2], u0[4 * q + 3]);
-                }
-            }
-        }
-        // transposed LDS patches of (da,dg) for the weight gradients
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            *reinterpret_cast<float4*>(lda + j * kPad + 8 * q + 4 * h) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
-            *reinterpret_cast<float4*>(ldg + j * kPad + 8 * q + 4 * h) = make_float4(dg[4 * q], dg[4 * q + 1], dg[4 * q + 2], dg[4 * q + 3]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        float bxc[16], bxo[16], ado[16], adu[16], bfz[16], bgz[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {                                        // all operand loads in flight first
-            const int tt = t0 + 2 * u + h;
-            const int ttc = tt < T ? tt : T - 1;
-            const long long r0 = ((long long)b * T + ttc) * 32 + j;
-            const long long r1 = ((long long)b * T + (ttc - d >= 0 ? ttc - d : 0)) * 32 + j;
-            bxc[u] = x[r0];
-            bxo[u] = x[r1];
-            if (HAS_DO || HAS_U) { bfz[u] = f[r0]; bgz[u] = g[r0]; }
-            if (HAS_DO) ado[u] = Vin[r0];
-            if (HAS_U) adu[u] = Uin[((long long)b * T + (ttc + dU < T ? ttc + dU : T - 1)) * 32 + j];
-        }
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int tt = t0 + 2 * s + h;
-            const float mv = tt < T ? 1.f : 0.f, mo = (tt < T && tt - d >= 0) ? 1.f : 0.f;
-            const float a_da = lda[(2 * s + h) * kPad + j];
-            const float a_dg = ldg[(2 * s + h) * kPad + j];
-            const float b_xc = bxc[s] * mv, b_xo = bxo[s] * mo;
-            aWf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xc, aWf1, 0, 0, 0);
-            aWf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xo, aWf0, 0, 0, 0);
-            aWg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xc, aWg1, 0, 0, 0);
-            aWg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xo, aWg0, 0, 0, 0);
-            if (HAS_DO || HAS_U) {
-                float a_do = HAS_DO ? ado[s] * mv : 0.f;
-                if (HAS_U) a_do += adu[s] * ((tt < T && tt + dU < T) ? 1.f : 0.f);
-                aWp = __builtin_amdgcn_mfma_f32_32x32x2f32(a_do, bfz[s] * bgz[s], aWp, 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    for (int w = 1; w < kWaves; ++w) {
-        __syncthreads();
-        if (wv == w) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                red[(0 * 16 + r) * 64 + lane] = aWf0[r]; red[(1 * 16 + r) * 64 + lane] = aWf1[r];
-                red[(2 * 16 + r) * 64 + lane] = aWg0[r]; red[(3 * 16 + r) * 64 + lane] = aWg1[r];
-                red[(4 * 16 + r) * 64 + lane] = aWp[r];
-            }
-        }
-        __syncthreads();
-        if (wv == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                aWf0[r] += red[(0 * 16 + r) * 64 + lane]; aWf1[r] += red[(1 * 16 + r) * 64 + lane];
-                aWg0[r] += red[(2 * 16 + r) * 64 + lane]; aWg1[r] += red[(3 * 16 + r) * 64 + lane];
-                aWp[r] += red[(4 * 16 + r) * 64 + lane];
-            }
-        }
-    }
-    if (wv == 0) {
-        float* __restrict__ o = part + (long long)blockIdx.x * kPartFloats + lane;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o[(0 * 16 + r) * 64] = aWf0[r]; o[(1 * 16 + r) * 64] = aWf1[r];
-            o[(2 * 16 + r) * 64] = aWg0[r]; o[(3 * 16 + r) * 64] = aWg1[r];
-            o[(4 * 16 + r) * 64] = aWp[r];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Same maths, second structure (the one the stack uses): 4 waves per workgroup, one workgroup per CU (one wave per
-// SIMD, 512 registers), 148 KB of LDS.  What the s_memtime stamps of the kernel above showed (cycles per wave and
-// tile): ~15,000 waiting for the 96 channel-on-lanes operand loads of the weight gradients, which queue behind the
-// V/U stores in vmcnt order and re-read five tensors L2 no longer holds (165 MB fetched per launch for 117 MB of
-// distinct data), and 250+ cycles of issue time for EVERY float4 access in the MFMA operand pattern (lane = row,
-// 32 bytes of each of 32 rows per instruction) -- against 10,240 cycles of MFMA.  Here every tensor crosses the
-// memory pipeline exactly once and in whole 128-byte rows:
-//   * f, g, V, U (time on lanes) and x[t], x[t-d] (channel on lanes, for the weight gradients): LDS-DMA
-//     (global_load_lds: lane L of piece k fetches 16 bytes of row 8k + L/8, 1 KB contiguous per instruction, no
-//     registers), the first four one tile ahead.  The time-on-lanes tiles are stored XOR-swizzled (16-byte chunk c
-//     of row r at position c ^ (r & 7), done by permuting the SOURCE addresses), so that the float4 read of lane
-//     (j,h) -- row j, chunks 2q+h -- is bank-conflict free;
-//   * V, U results: written to the swizzled patches, read back row-wise, stored as whole rows;
-//   * da, dg, then dout, z = f g: transposed through the same two patches for the weight gradients;
-//   * weights: raw Wf/Wg/Wp copied to LDS with coalesced float4 loads; Wf[cd][cr][0..1] is one ds_read_b64 that
-//     yields the A operands of both the V (tap 1) and the U (tap 0) MFMA.
-// Vector-memory operations retire in issue order, so "the DMA has landed" is an s_waitcnt vmcnt(N) with N = the
-// number of operations issued after it (always counted conservatively: conditional stores are not counted).
-// ---------------------------------------------------------------------------------------------
 static constexpr int kCWaves = 4;
-static constexpr int kCWaveFloats = 8192;                       // f, g, V, U tiles | xc, xo tiles | patch A, patch B
+static constexpr int kCWaveFloats = 8192;                       // two groups of four 4 KB slots per wave
 static constexpr int kCWFloats = 2048 + 2048 + 1024;            // Wf, Wg, Wp
 static constexpr int kCLdsBytes = (kCWFloats + kCWaves * kCWaveFloats) * 4;
 static constexpr int kCMaxBlocks = 256;
@@ -363,575 +189,33 @@ static constexpr int kCMaxBlocks = 256;
 #define WN_LDS_DMA16(src, dst) \
     __builtin_amdgcn_global_load_lds((src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <bool HAS_DO, bool HAS_U, bool HAS_DZ>
-__global__ __launch_bounds__(64 * kCWaves, 1) void k_layer_bwd_chain8(
-    const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
-    const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
-    const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, const float* __restrict__ dzs,
-    float* __restrict__ Vout, float* __restrict__ Uout, float* __restrict__ part, int B, int T, int d, int Z,
-    int tiles_per_b, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) float dyn[];
-    float* lWf = dyn;
-    float* lWg = dyn + 2048;
-    float* lWp = dyn + 4096;
-    float* wbase = dyn + kCWFloats;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // wave-uniform: tile maths on the SALU
-    const int j = lane & 31, h = lane >> 5;
-    float* tf = wbase + wv * kCWaveFloats;
-    float* tg = tf + 1024;
-    float* tv = tf + 2048;
-    float* tu = tf + 3072;
-    float* xsc = tf + 4096;
-    float* xso = tf + 5120;
-    float* pa = tf + 6144;
-    float* pb = tf + 7168;
-    // Tile order: workgroups are dealt to the 8 XCDs round-robin, so XCD k = blockIdx % 8 is given the k-th contiguous
-    // eighth of the tiles.  x[t-d] (and the layer above's U[t+dU]) of a tile are then rows that a neighbouring CU of
-    // the SAME XCD fetches in the same round: the second fetch is an L2 hit instead of another trip to HBM.
-    int first, stride, last;                        // this wave's tiles: first, first + stride, ... < last
-    if ((gridDim.x & 7) == 0) {
-        const int per_xcd = (ntiles + 7) >> 3;
-        const int xcd = blockIdx.x & 7;
-        stride = (gridDim.x >> 3) * kCWaves;
-        first = xcd * per_xcd + (blockIdx.x >> 3) * kCWaves + wv;
-        last = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
-    } else {
-        stride = gridDim.x * kCWaves;
-        first = blockIdx.x * kCWaves + wv;
-        last = ntiles;
-    }
-    constexpr int kAOps = 4 * (2 + (HAS_DO ? 1 : 0) + (HAS_U ? 1 : 0));        // DMA pieces of one tile's f, g, V, U
-    constexpr int kZOps = HAS_DZ ? 4 : 0;
-    const int lr = lane >> 3, lp = lane & 7;                                    // DMA: row inside a piece, LDS position
-
-    // f, g, V, U of a tile -> LDS (swizzled), dz -> registers (time on lanes only, nothing to transpose)
-    auto fetch_a = [&](int tile, float4 (&dz4)[4]) {
-        const int b = tile / tiles_per_b;
-        const int t0 = (tile - b * tiles_per_b) * 32;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = 8 * k + lr;
-            const int tt = t0 + r;
-            const int ttc = tt < T ? tt : T - 1;
-            const int ttu = ttc + dU < T ? ttc + dU : T - 1;
-            const long long o = ((long long)b * T + ttc) * 32 + ((lp ^ (r & 7)) << 2);
-            WN_LDS_DMA16(f + o, tf + k * 256);
-            WN_LDS_DMA16(g + o, tg + k * 256);
-            if (HAS_DO) WN_LDS_DMA16(Vin + o, tv + k * 256);
-            if (HAS_U) WN_LDS_DMA16(Uin + ((long long)b * T + ttu) * 32 + ((lp ^ (r & 7)) << 2), tu + k * 256);
-        }
-        if (HAS_DZ) {
-            const int t = t0 + j;
-            const long long rowc = ((long long)b * T + (t < T ? t : T - 1)) * 32 + 4 * h;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dz4[q] = *reinterpret_cast<const float4*>(dzs + rowc + 8 * q);
-        }
-    };
-
-    // ---- weights -> LDS (coalesced), first tile's operands in flight meanwhile -------------------
-    constexpr int kThreads = 64 * kCWaves;
-    float4 s_wf[512 / kThreads], s_wg[512 / kThreads];
-#pragma unroll
-    for (int k = 0; k < 512 / kThreads; ++k) {
-        s_wf[k] = reinterpret_cast<const float4*>(Wf)[threadIdx.x + k * kThreads];
-        s_wg[k] = reinterpret_cast<const float4*>(Wg)[threadIdx.x + k * kThreads];
-    }
-    const float4 s_wp = reinterpret_cast<const float4*>(Wp)[threadIdx.x & 255];
-    float4 dzc[4], dzn[4];
-    if (first < last) fetch_a(first, dzc);
-#pragma unroll
-    for (int k = 0; k < 512 / kThreads; ++k) {
-        reinterpret_cast<float4*>(lWf)[threadIdx.x + k * kThreads] = s_wf[k];
-        reinterpret_cast<float4*>(lWg)[threadIdx.x + k * kThreads] = s_wg[k];
-    }
-    if (threadIdx.x < 256) reinterpret_cast<float4*>(lWp)[threadIdx.x] = s_wp;
-    __syncthreads();
-
-    f32x16 aWf0, aWf1, aWg0, aWg1, aWp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { aWf0[r] = 0.f; aWf1[r] = 0.f; aWg0[r] = 0.f; aWg1[r] = 0.f; aWp[r] = 0.f; }
-
-    for (int tile = first; tile < last; tile += stride) {
-        const int b = tile / tiles_per_b;
-        const int t0 = (tile - b * tiles_per_b) * 32;
-        const int t = t0 + j;
-        const bool valid = t < T;
-        const bool more = tile + stride < last;
-        // x[t] and x[t-d] of the tile -> LDS, row-major, not swizzled (only read channel-on-lanes)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int tt = t0 + 8 * k + lr;
-            const int ttc = tt < T ? tt : T - 1;
-            const int tto = ttc - d >= 0 ? ttc - d : 0;
-            WN_LDS_DMA16(x + ((long long)b * T + ttc) * 32 + lp * 4, xsc + k * 256);
-            WN_LDS_DMA16(x + ((long long)b * T + tto) * 32 + lp * 4, xso + k * 256);
-        }
-        // this tile's f, g, V, U (and dz) were issued before the eight x pieces
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        const float mu = (HAS_U && valid && t + dU < T) ? 1.f : 0.f;
-        f32x16 acc;
-        float ff[16], gg[16], dob[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
-            float4 z4 = make_float4(0, 0, 0, 0), o4 = z4;
-            const float4 f4 = *reinterpret_cast<const float4*>(tf + o);
-            const float4 g4 = *reinterpret_cast<const float4*>(tg + o);
-            if (HAS_DZ) z4 = dzc[q];
-            if (HAS_DO) o4 = *reinterpret_cast<const float4*>(tv + o);
-            if (HAS_U) {
-                const float4 u4 = *reinterpret_cast<const float4*>(tu + o);
-                o4.x += u4.x * mu; o4.y += u4.y * mu; o4.z += u4.z * mu; o4.w += u4.w * mu;
-            }
-            acc[4 * q] = z4.x; acc[4 * q + 1] = z4.y; acc[4 * q + 2] = z4.z; acc[4 * q + 3] = z4.w;
-            ff[4 * q] = f4.x; ff[4 * q + 1] = f4.y; ff[4 * q + 2] = f4.z; ff[4 * q + 3] = f4.w;
-            gg[4 * q] = g4.x; gg[4 * q + 1] = g4.y; gg[4 * q + 2] = g4.z; gg[4 * q + 3] = g4.w;
-            dob[4 * q] = o4.x; dob[4 * q + 1] = o4.y; dob[4 * q + 2] = o4.z; dob[4 * q + 3] = o4.w;
-        }
-        // the tiles are in registers: the next tile's may overwrite them (issued before this tile's stores)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (more) fetch_a(tile + stride, dzn);
-        if (HAS_DO || HAS_U) {
-#pragma unroll
-            for (int s = 0; s < 16; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lWp[bch(s, h) * 32 + j], dob[s], acc, 0, 0, 0);
-        }
-        const bool live = valid && t >= Z;
-        float da[16], dg[16], zz[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float dz = live ? acc[r] : 0.f;
-            da[r] = dz * gg[r] * (1.f - ff[r] * ff[r]);
-            dg[r] = dz * ff[r] * gg[r] * (1.f - gg[r]);
-            zz[r] = ff[r] * gg[r];
-        }
-        // V = dout + [Wf1;Wg1]^T dab,  U = [Wf0;Wg0]^T dab
-        f32x16 v1, u0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { v1[r] = dob[r]; u0[r] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float2 wf = *reinterpret_cast<const float2*>(lWf + (bch(s, h) * 32 + j) * 2);
-            const float2 wg = *reinterpret_cast<const float2*>(lWg + (bch(s, h) * 32 + j) * 2);
-            v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, da[s], v1, 0, 0, 0);
-            u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, da[s], u0, 0, 0, 0);
-            v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.y, dg[s], v1, 0, 0, 0);
-            u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.x, dg[s], u0, 0, 0, 0);
-        }
-        // V, U leave through the patches as whole rows
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
-            *reinterpret_cast<float4*>(pa + o) = make_float4(v1[4 * q], v1[4 * q + 1], v1[4 * q + 2], v1[4 * q + 3]);
-            *reinterpret_cast<float4*>(pb + o) = make_float4(u0[4 * q], u0[4 * q + 1], u0[4 * q + 2], u0[4 * q + 3]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = 8 * k + lr;
-            const float4 vv = *reinterpret_cast<const float4*>(pa + k * 256 + lane * 4);
-            const float4 uu = *reinterpret_cast<const float4*>(pb + k * 256 + lane * 4);
-            if (t0 + r < T) {
-                const long long o = ((long long)b * T + t0 + r) * 32 + ((lp ^ (r & 7)) << 2);
-                *reinterpret_cast<float4*>(Vout + o) = vv;
-                *reinterpret_cast<float4*>(Uout + o) = uu;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        // transposed patches of (da, dg)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
-            *reinterpret_cast<float4*>(pa + o) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
-            *reinterpret_cast<float4*>(pb + o) = make_float4(dg[4 * q], dg[4 * q + 1], dg[4 * q + 2], dg[4 * q + 3]);
-        }
-        // the x tiles must have landed: after them went the next tile's operands (if any) and the (uncounted) stores
-        if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAOps + kZOps) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // weight gradients: contraction over the tile's 32 columns, step s covers columns 2s and 2s+1
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int r = 2 * s + h;
-            const int tt = t0 + r;
-            const float mv = tt < T ? 1.f : 0.f, mo = (tt < T && tt - d >= 0) ? 1.f : 0.f;
-            const int po = r * 32 + ((((j >> 2) ^ (r & 7)) << 2) | (j & 3));
-            const float a_da = pa[po], a_dg = pb[po];
-            const float b_xc = xsc[r * 32 + j] * mv, b_xo = xso[r * 32 + j] * mo;
-            aWf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xc, aWf1, 0, 0, 0);
-            aWf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da, b_xo, aWf0, 0, 0, 0);
-            aWg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xc, aWg1, 0, 0, 0);
-            aWg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg, b_xo, aWg0, 0, 0, 0);
-        }
-        if (HAS_DO || HAS_U) {                       // dWp += dout z^T through the same two patches
-            __builtin_amdgcn_wave_barrier();
-            const float mvj = valid ? 1.f : 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
-                *reinterpret_cast<float4*>(pa + o) = make_float4(dob[4 * q] * mvj, dob[4 * q + 1] * mvj, dob[4 * q + 2] * mvj, dob[4 * q + 3] * mvj);
-                *reinterpret_cast<float4*>(pb + o) = make_float4(zz[4 * q], zz[4 * q + 1], zz[4 * q + 2], zz[4 * q + 3]);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int r = 2 * s + h;
-                const int po = r * 32 + ((((j >> 2) ^ (r & 7)) << 2) | (j & 3));
-                aWp = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[po], pb[po], aWp, 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (HAS_DZ && more) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dzc[q] = dzn[q];
-        }
-    }
-
-    // ---- sum the five accumulators over the waves (tree through the per-wave LDS space) -----
-    __syncthreads();
-    for (int half = kCWaves / 2; half >= 1; half >>= 1) {
-        if (wv >= half && wv < 2 * half) {
-            float* red = wbase + (wv - half) * kPartFloats;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                red[(0 * 16 + r) * 64 + lane] = aWf0[r]; red[(1 * 16 + r) * 64 + lane] = aWf1[r];
-                red[(2 * 16 + r) * 64 + lane] = aWg0[r]; red[(3 * 16 + r) * 64 + lane] = aWg1[r];
-                red[(4 * 16 + r) * 64 + lane] = aWp[r];
-            }
-        }
-        __syncthreads();
-        if (wv < half) {
-            const float* red = wbase + wv * kPartFloats;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                aWf0[r] += red[(0 * 16 + r) * 64 + lane]; aWf1[r] += red[(1 * 16 + r) * 64 + lane];
-                aWg0[r] += red[(2 * 16 + r) * 64 + lane]; aWg1[r] += red[(3 * 16 + r) * 64 + lane];
-                aWp[r] += red[(4 * 16 + r) * 64 + lane];
-            }
-        }
-        __syncthreads();
-    }
-    if (wv == 0) {
-        float* __restrict__ o = part + (long long)blockIdx.x * kPartFloats + lane;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o[(0 * 16 + r) * 64] = aWf0[r]; o[(1 * 16 + r) * 64] = aWf1[r];
-            o[(2 * 16 + r) * 64] = aWg0[r]; o[(3 * 16 + r) * 64] = aWg1[r];
-            o[(4 * 16 + r) * 64] = aWp[r];
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Third structure: producer / consumer wave pairs.  With one wave per SIMD (k_layer_bwd_chain8) the 160 MFMAs of a tile
-// (10,240 cycles) run strictly between that wave's own DMA waits, LDS traffic, gate arithmetic and stores: ~21,000
-// cycles per tile, the matrix pipe idle half of the time and HBM at 2.8 TB/s.  Here a workgroup is 8 waves = 4 pairs
-// that share a SIMD each (waves w and w+4):
-//   producer (w < 4):  f, g, V, U tiles (LDS-DMA, swizzled) -> dz = Wp^T dout + dz_skip -> gate -> da, dg -> V, U
-//                      (80 MFMAs); stores V/U as whole rows; leaves da, dg, dout, z = f g as swizzled patches IN THE
-//                      SLOTS ITS INPUT TILES CAME IN (they are consumed by then);
-//   consumer (w >= 4): takes the four patches into registers (channel on lanes), reads x[t], x[t-d] straight from
-//                      memory in that layout (a half wave = one 128-byte row), prefetched one tile ahead in registers,
-//                      and runs the 80 weight-gradient MFMAs into the five accumulators it alone holds.
-// A pair owns two groups of four 4 KB slots; tile n lives in group n % 2, so the producer issues the DMA of tile n+1
-// (into the other group, whose patches the consumer took at the previous hand-over) before it starts on tile n: every
-// fetch has a whole tile of time to land.  Two LDS-only workgroup barriers per tile hand the patches over (ready /
-// taken); they wait for LDS traffic only, not for outstanding stores or DMA.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lds_only_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-template <bool HAS_DO, bool HAS_U, bool HAS_DZ>
-__global__ __launch_bounds__(512, 1) void k_layer_bwd_chainpc(
-    const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
-    const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
-    const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, const float* __restrict__ dzs,
-    float* __restrict__ Vout, float* __restrict__ Uout, float* __restrict__ part, int B, int T, int d, int Z,
-    int tiles_per_b, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) float dyn[];
-    float* lWf = dyn;
-    float* lWg = dyn + 2048;
-    float* lWp = dyn + 4096;
-    float* wbase = dyn + kCWFloats;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = wv & 3;
-    const bool producer = wv < 4;
-    const int j = lane & 31, h = lane >> 5;
-    float* pbase = wbase + pair * kCWaveFloats;      // group k: pbase + 4096 k = {f | dout, g | z, V | da, U | dg}
-    int first0, stride, last;                        // pair p walks first0 + p, + stride, ... < last (XCD-aware, see above)
-    if ((gridDim.x & 7) == 0) {
-        const int per_xcd = (ntiles + 7) >> 3;
-        const int xcd = blockIdx.x & 7;
-        stride = (gridDim.x >> 3) * 4;
-        first0 = xcd * per_xcd + (blockIdx.x >> 3) * 4;
-        last = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
-    } else {
-        stride = gridDim.x * 4;
-        first0 = blockIdx.x * 4;
-        last = ntiles;
-    }
-    const int first = first0 + pair;
-    const int iters = first0 < last ? (last - first0 + stride - 1) / stride : 0;    // same for the whole workgroup
-    const int lr = lane >> 3, lp = lane & 7;                                    // DMA: row inside a piece, LDS position
-    constexpr int kFetchOps = 4 * (2 + (HAS_DO ? 1 : 0) + (HAS_U ? 1 : 0) + (HAS_DZ ? 1 : 0));
-
-    auto fetch_a = [&](int tile, float* grp, float4 (&dz4)[4]) {
-        const int b = tile / tiles_per_b;
-        const int t0 = (tile - b * tiles_per_b) * 32;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int r = 8 * k + lr;
-            const int tt = t0 + r;
-            const int ttc = tt < T ? tt : T - 1;
-            const int ttu = ttc + dU < T ? ttc + dU : T - 1;
-            const long long o = ((long long)b * T + ttc) * 32 + ((lp ^ (r & 7)) << 2);
-            WN_LDS_DMA16(f + o, grp + k * 256);
-            WN_LDS_DMA16(g + o, grp + 1024 + k * 256);
-            if (HAS_DO) WN_LDS_DMA16(Vin + o, grp + 2048 + k * 256);
-            if (HAS_U) WN_LDS_DMA16(Uin + ((long long)b * T + ttu) * 32 + ((lp ^ (r & 7)) << 2), grp + 3072 + k * 256);
-        }
-        if (HAS_DZ) {
-            const int t = t0 + j;
-            const long long rowc = ((long long)b * T + (t < T ? t : T - 1)) * 32 + 4 * h;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dz4[q] = *reinterpret_cast<const float4*>(dzs + rowc + 8 * q);
-        }
-    };
-    // x[t], x[t-d] of a tile as B operands of the weight-gradient MFMAs: lane (j,h), step s: row 2s+h, channel j
-    auto fetch_x = [&](int tile, float (&xc)[16], float (&xo)[16]) {
-        const int b = tile / tiles_per_b;
-        const int t0 = (tile - b * tiles_per_b) * 32;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int tt = t0 + 2 * s + h;
-            const int ttc = tt < T ? tt : T - 1;
-            const int tto = ttc - d >= 0 ? ttc - d : 0;
-            xc[s] = x[((long long)b * T + ttc) * 32 + j];
-            xo[s] = x[((long long)b * T + tto) * 32 + j];
-        }
-    };
-
-    // ---- weights -> LDS (coalesced), first tile's operands in flight meanwhile -------------------
-    const float4 s_wf = reinterpret_cast<const float4*>(Wf)[threadIdx.x];
-    const float4 s_wg = reinterpret_cast<const float4*>(Wg)[threadIdx.x];
-    const float4 s_wp = reinterpret_cast<const float4*>(Wp)[threadIdx.x & 255];
-    float4 dzc[4], dzn[4];
-    float xcn[16], xon[16];
-    if (first < last) {
-        if (producer) fetch_a(first, pbase, dzc);
-        else fetch_x(first, xcn, xon);
-    }
-    reinterpret_cast<float4*>(lWf)[threadIdx.x] = s_wf;
-    reinterpret_cast<float4*>(lWg)[threadIdx.x] = s_wg;
-    if (threadIdx.x < 256) reinterpret_cast<float4*>(lWp)[threadIdx.x] = s_wp;
-    __syncthreads();
-
-    f32x16 aWf0, aWf1, aWg0, aWg1, aWp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { aWf0[r] = 0.f; aWf1[r] = 0.f; aWg0[r] = 0.f; aWg1[r] = 0.f; aWp[r] = 0.f; }
-
-    if (producer) {
-        for (int it = 0; it < iters; ++it) {
-            const int tile = first + it * stride;
-            float* grp = pbase + (it & 1) * 4096;
-            float* tf = grp;
-            float* tg = grp + 1024;
-            float* tv = grp + 2048;
-            float* tu = grp + 3072;
-            const bool more = tile + stride < last;
-            // the next tile's operands go to the other group (its patches were taken at the last hand-over)
-            if (more) fetch_a(tile + stride, pbase + ((it + 1) & 1) * 4096, dzn);
-            if (tile < last) {
-                const int b = tile / tiles_per_b;
-                const int t0 = (tile - b * tiles_per_b) * 32;
-                const int t = t0 + j;
-                const bool valid = t < T;
-                // this tile's f, g, V, U have landed (issued before the next tile's; stores are not counted)
-                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFetchOps) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const float mu = (HAS_U && valid && t + dU < T) ? 1.f : 0.f;
-                f32x16 acc;
-                float ff[16], gg[16], dob[16];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
-                    float4 z4 = make_float4(0, 0, 0, 0), o4 = z4;
-                    const float4 f4 = *reinterpret_cast<const float4*>(tf + o);
-                    const float4 g4 = *reinterpret_cast<const float4*>(tg + o);
-                    if (HAS_DZ) z4 = dzc[q];
-                    if (HAS_DO) o4 = *reinterpret_cast<const float4*>(tv + o);
-                    if (HAS_U) {
-                        const float4 u4 = *reinterpret_cast<const float4*>(tu + o);
-                        o4.x += u4.x * mu; o4.y += u4.y * mu; o4.z += u4.z * mu; o4.w += u4.w * mu;
-                    }
-                    acc[4 * q] = z4.x; acc[4 * q + 1] = z4.y; acc[4 * q + 2] = z4.z; acc[4 * q + 3] = z4.w;
-                    ff[4 * q] = f4.x; ff[4 * q + 1] = f4.y; ff[4 * q + 2] = f4.z; ff[4 * q + 3] = f4.w;
-                    gg[4 * q] = g4.x; gg[4 * q + 1] = g4.y; gg[4 * q + 2] = g4.z; gg[4 * q + 3] = g4.w;
-                    dob[4 * q] = o4.x; dob[4 * q + 1] = o4.y; dob[4 * q + 2] = o4.z; dob[4 * q + 3] = o4.w;
-                }
-                if (HAS_DO || HAS_U) {
-#pragma unroll
-                    for (int s = 0; s < 16; ++s)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lWp[bch(s, h) * 32 + j], dob[s], acc, 0, 0, 0);
-                }
-                const bool live = valid && t >= Z;
-                float da[16], dg[16], zz[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float dz = live ? acc[r] : 0.f;
-                    da[r] = dz * gg[r] * (1.f - ff[r] * ff[r]);
-                    dg[r] = dz * ff[r] * gg[r] * (1.f - gg[r]);
-                    zz[r] = ff[r] * gg[r];
-                }
-                f32x16 v1, u0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { v1[r] = dob[r]; u0[r] = 0.f; }
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const float2 wf = *reinterpret_cast<const float2*>(lWf + (bch(s, h) * 32 + j) * 2);
-                    const float2 wg = *reinterpret_cast<const float2*>(lWg + (bch(s, h) * 32 + j) * 2);
-                    v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, da[s], v1, 0, 0, 0);
-                    u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, da[s], u0, 0, 0, 0);
-                    v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.y, dg[s], v1, 0, 0, 0);
-                    u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.x, dg[s], u0, 0, 0, 0);
-                }
-                // V, U leave as whole rows through the (consumed) V/U input slots
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
-                    *reinterpret_cast<float4*>(tv + o) = make_float4(v1[4 * q], v1[4 * q + 1], v1[4 * q + 2], v1[4 * q + 3]);
-                    *reinterpret_cast<float4*>(tu + o) = make_float4(u0[4 * q], u0[4 * q + 1], u0[4 * q + 2], u0[4 * q + 3]);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int r = 8 * k + lr;
-                    const float4 vv = *reinterpret_cast<const float4*>(tv + k * 256 + lane * 4);
-                    const float4 uu = *reinterpret_cast<const float4*>(tu + k * 256 + lane * 4);
-                    if (t0 + r < T) {
-                        const long long o = ((long long)b * T + t0 + r) * 32 + ((lp ^ (r & 7)) << 2);
-                        *reinterpret_cast<float4*>(Vout + o) = vv;
-                        *reinterpret_cast<float4*>(Uout + o) = uu;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                // the four patches for the consumer: dout (0 beyond T), z, da, dg
-                const float mvj = valid ? 1.f : 0.f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
-                    *reinterpret_cast<float4*>(tf + o) = make_float4(dob[4 * q] * mvj, dob[4 * q + 1] * mvj, dob[4 * q + 2] * mvj, dob[4 * q + 3] * mvj);
-                    *reinterpret_cast<float4*>(tg + o) = make_float4(zz[4 * q], zz[4 * q + 1], zz[4 * q + 2], zz[4 * q + 3]);
-                    *reinterpret_cast<float4*>(tv + o) = make_float4(da[4 * q], da[4 * q + 1], da[4 * q + 2], da[4 * q + 3]);
-                    *reinterpret_cast<float4*>(tu + o) = make_float4(dg[4 * q], dg[4 * q + 1], dg[4 * q + 2], dg[4 * q + 3]);
-                }
-            }
-            lds_only_barrier();                       // patches ready
-            lds_only_barrier();                       // patches taken
-            if (HAS_DZ && more) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dzc[q] = dzn[q];
-            }
-        }
-    } else {
-        for (int it = 0; it < iters; ++it) {
-            const int tile = first + it * stride;
-            const bool active = tile < last;
-            const float* grp = pbase + (it & 1) * 4096;
-            float a_da[16], a_dg[16], a_do[16], b_z[16], b_xc[16], b_xo[16];
-            if (active) {
-                const int b = tile / tiles_per_b;
-                const int t0 = (tile - b * tiles_per_b) * 32;
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int tt = t0 + 2 * s + h;
-                    b_xc[s] = xcn[s] * (tt < T ? 1.f : 0.f);
-                    b_xo[s] = xon[s] * ((tt < T && tt - d >= 0) ? 1.f : 0.f);
-                }
-            }
-            lds_only_barrier();                       // patches ready
-            if (active) {
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int r = 2 * s + h;
-                    const int po = r * 32 + ((((j >> 2) ^ (r & 7)) << 2) | (j & 3));
-                    a_do[s] = grp[po]; b_z[s] = grp[1024 + po]; a_da[s] = grp[2048 + po]; a_dg[s] = grp[3072 + po];
-                }
-            }
-            lds_only_barrier();                       // patches taken
-            if (tile + stride < last) fetch_x(tile + stride, xcn, xon);
-            if (active) {
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    aWf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da[s], b_xc[s], aWf1, 0, 0, 0);
-                    aWf0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_da[s], b_xo[s], aWf0, 0, 0, 0);
-                    aWg1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg[s], b_xc[s], aWg1, 0, 0, 0);
-                    aWg0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_dg[s], b_xo[s], aWg0, 0, 0, 0);
-                    if (HAS_DO || HAS_U) aWp = __builtin_amdgcn_mfma_f32_32x32x2f32(a_do[s], b_z[s], aWp, 0, 0, 0);
-                }
-            }
-        }
-    }
-
-    // ---- sum the five accumulators over the four consumer waves (tree through the slot groups) -----
-    __syncthreads();
-    for (int half = 2; half >= 1; half >>= 1) {
-        if (!producer && pair >= half && pair < 2 * half) {
-            float* red = wbase + (pair - half) * kPartFloats;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                red[(0 * 16 + r) * 64 + lane] = aWf0[r]; red[(1 * 16 + r) * 64 + lane] = aWf1[r];
-                red[(2 * 16 + r) * 64 + lane] = aWg0[r]; red[(3 * 16 + r) * 64 + lane] = aWg1[r];
-                red[(4 * 16 + r) * 64 + lane] = aWp[r];
-            }
-        }
-        __syncthreads();
-        if (!producer && pair < half) {
-            const float* red = wbase + pair * kPartFloats;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                aWf0[r] += red[(0 * 16 + r) * 64 + lane]; aWf1[r] += red[(1 * 16 + r) * 64 + lane];
-                aWg0[r] += red[(2 * 16 + r) * 64 + lane]; aWg1[r] += red[(3 * 16 + r) * 64 + lane];
-                aWp[r] += red[(4 * 16 + r) * 64 + lane];
-            }
-        }
-        __syncthreads();
-    }
-    if (!producer && pair == 0) {
-        float* __restrict__ o = part + (long long)blockIdx.x * kPartFloats + lane;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o[(0 * 16 + r) * 64] = aWf0[r]; o[(1 * 16 + r) * 64] = aWf1[r];
-            o[(2 * 16 + r) * 64] = aWg0[r]; o[(3 * 16 + r) * 64] = aWg1[r];
-            o[(4 * 16 + r) * 64] = aWp[r];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Fourth structure: ONE wave per SIMD again (4 waves per workgroup, 512 registers), software-pipelined: the loop
-// body holds the 80 weight-gradient MFMAs of tile n (operands already in registers) AND the whole first half of tile
-// n+1 (LDS reads, dz chain, gate, V/U MFMAs, patch writes) in one basic block, so the compiler's scheduler interleaves
-// the VALU / LDS work of one tile between the MFMAs of the other.  (Two waves per SIMD do not achieve that: a wave
-// that streams MFMAs starves its sibling's VALU issue -- the producer/consumer kernel above measured 11,000 cycles for
-// 300 VALU instructions next to the consumer's MFMA stream.)  LDS use and data movement are those of the
-// producer/consumer kernel: two groups of four slots per wave, x through registers.
+// k_layer_bwd_chainsp: one workgroup of 4 waves per CU (one wave per SIMD, 512 registers, 148 KB of LDS), software-
+// pipelined: the loop body holds the 80 weight-gradient MFMAs of tile n (operands already in registers) AND the whole
+// first half of tile n+1 (LDS reads, dz chain, gate, V/U MFMAs, patch writes) in one basic block, so the compiler's
+// scheduler interleaves the VALU / LDS work of one tile between the MFMAs of the other.
+// Data movement -- every tensor crosses the memory pipeline exactly once and in whole 128-byte rows:
+//   * f, g, V, U (time on lanes): LDS-DMA (global_load_lds: lane L of piece k fetches 16 bytes of row 8k + L/8, 1 KB
+//     contiguous per instruction, no registers), one tile ahead, into the wave's other slot group.  The tiles are
+//     stored XOR-swizzled (16-byte chunk c of row r at position c ^ (r & 7), done by permuting the SOURCE addresses),
+//     so that the float4 read of lane (j,h) -- row j, chunks 2q+h -- is bank-conflict free;
+//   * x[t], x[t-d] (channel on lanes, weight gradients only): plain loads, a half wave = one 128-byte row, one tile
+//     ahead in registers;  dz: float4 per lane (time on lanes, nothing to transpose);
+//   * V, U results: written to the (consumed) V/U slots, read back row-wise, stored as whole rows;
+//   * da, dg, dout, z = f g: left as swizzled patches in the slots the tile's inputs came in, taken into registers
+//     (channel on lanes) at the top of the next body;
+//   * weights: raw Wf/Wg/Wp copied to LDS with coalesced float4 loads; Wf[cd][cr][0..1] is one ds_read_b64 that
+//     yields the A operands of both the V (tap 1) and the U (tap 0) MFMA.
+// Vector-memory operations retire in issue order, so "it has landed" is an s_waitcnt vmcnt(N) with N = the number of
+// operations issued after it (the eight V/U stores of a complete tile).
+// Tile order: workgroups are dealt to the 8 XCDs round-robin, so XCD k = blockIdx % 8 gets the k-th contiguous eighth
+// of the tiles (x[t-d] and U[t+dU] of a tile are rows a neighbouring CU of the same XCD fetches in the same round).
 // ---------------------------------------------------------------------------------------------
 template <bool HAS_DO, bool HAS_U, bool HAS_DZ>
 __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
     const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
-    const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, const float* __restrict__ dzs,
+    const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, const float* __restrict__ dzs, int dz_t0,
     float* __restrict__ Vout, float* __restrict__ Uout, float* __restrict__ part, int B, int T, int d, int Z,
     int tiles_per_b, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float dyn[];
@@ -989,10 +273,25 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
             }
         }
         if (HAS_DZ) {
-            const int t = t0 + j;
-            const long long rowc = ((long long)b * T + (t < T ? t : T - 1)) * 32 + 4 * h;
+            // dz_skip exists for columns t >= dz_t0 only (the loss window): tiles below it load nothing, the tile
+            // that straddles dz_t0 selects (the memory below dz_t0 is uninitialised)
+            if (t0 + 32 > dz_t0) {
+                const int t = t0 + j;
+                const long long rowc = ((long long)b * T + (t < T ? t : T - 1)) * 32 + 4 * h;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dz4[q] = *reinterpret_cast<const float4*>(dzs + rowc + 8 * q);
+                for (int q = 0; q < 4; ++q) dz4[q] = *reinterpret_cast<const float4*>(dzs + rowc + 8 * q);
+                if (t0 < dz_t0) {
+                    const bool in = t >= dz_t0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        dz4[q].x = in ? dz4[q].x : 0.f; dz4[q].y = in ? dz4[q].y : 0.f;
+                        dz4[q].z = in ? dz4[q].z : 0.f; dz4[q].w = in ? dz4[q].w : 0.f;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dz4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     auto fetch_x = [&](int tile, float (&xc)[16], float (&xo)[16]) {
@@ -1398,43 +697,27 @@ size_t mfma_layer_bwd_extra_ws_floats() { return (size_t)kMaxBlocks * kPartFloat
 
 // One layer of the chained backward.  Vin/Uin (either may be NULL): dout[t] = Vin[t] + Uin[t + dU].
 int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
-                         const float* Wp, const float* Vin, const float* Uin, int dU, const float* dzs, float* Vout,
-                         float* Uout, float* dWf, float* dWg, float* dWp, float* part, int B, int T, int d, int Z,
-                         bool defer_reduce, hipStream_t s) {
+                         const float* Wp, const float* Vin, const float* Uin, int dU, const float* dzs, int dz_t0,
+                         float* Vout, float* Uout, float* dWf, float* dWg, float* dWp, float* part, int B, int T, int d,
+                         int Z, bool defer_reduce, hipStream_t s) {
     const int tiles_per_b = (T + 31) / 32;
     const long long nt = (long long)B * tiles_per_b;
     WN_CHECK_SHAPE(nt < (1ll << 31), "mfma_layer_bwd_chain: too many tiles");
     WN_CHECK_ARG(Vin || Uin || dzs, "mfma_layer_bwd_chain: no incoming gradient");
     const int ntiles = (int)nt;
-    static const int variant = [] {      // 0: producer/consumer pairs, 1: chain8, 2: first chained kernel, 3: software-pipelined
-        const char* e = getenv("WAVENET_HIP_CHAIN");
-        return !e ? 3 : !strcmp(e, "pc") ? 0 : !strcmp(e, "v2") ? 1 : !strcmp(e, "old") ? 2 : 3;
-    }();
-    int blocks = variant == 2 ? (ntiles + 3) / 4 : (ntiles + kCWaves - 1) / kCWaves;
-    const int maxb = variant == 2 ? kMaxBlocks : kCMaxBlocks;
-    if (blocks > maxb) blocks = maxb;
-#define CH_LAUNCH_LDS(KERNEL, THREADS)                                                                             \
+    int blocks = (ntiles + kCWaves - 1) / kCWaves;
+    if (blocks > kCMaxBlocks) blocks = kCMaxBlocks;
+#define CH_LAUNCH(DO, UU, DZ)                                                                                      \
     do {                                                                                                           \
         static bool attr_set = false;                                                                              \
         if (!attr_set) {                                                                                           \
-            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL),                                      \
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chainsp<DO, UU, DZ>),             \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kCLdsBytes));                   \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL(KERNEL, dim3(blocks), dim3(THREADS), kCLdsBytes, s, x, f, g, Wp, Wf, Wg, Vin, Uin, dU, dzs, \
-                           Vout, Uout, part, B, T, d, Z, tiles_per_b, ntiles);                                     \
+        hipLaunchKernelGGL((k_layer_bwd_chainsp<DO, UU, DZ>), dim3(blocks), dim3(64 * kCWaves), kCLdsBytes, s, x, f, g, \
+                           Wp, Wf, Wg, Vin, Uin, dU, dzs, dz_t0, Vout, Uout, part, B, T, d, Z, tiles_per_b, ntiles); \
     } while (0)
-#define CH_LAUNCH(DO, UU, DZ)                                                                                      \
-    if (variant == 2) {                                                                                            \
-        hipLaunchKernelGGL((k_layer_bwd_chain<DO, UU, DZ>), dim3(blocks), dim3(256), 0, s, x, f, g, Wp, Wf, Wg, Vin, Uin, \
-                           dU, dzs, Vout, Uout, part, B, T, d, Z, tiles_per_b, ntiles);                            \
-    } else if (variant == 1) {                                                                                     \
-        CH_LAUNCH_LDS((k_layer_bwd_chain8<DO, UU, DZ>), 64 * kCWaves);                                             \
-    } else if (variant == 3) {                                                                                     \
-        CH_LAUNCH_LDS((k_layer_bwd_chainsp<DO, UU, DZ>), 256);                                                     \
-    } else {                                                                                                       \
-        CH_LAUNCH_LDS((k_layer_bwd_chainpc<DO, UU, DZ>), 512);                                                     \
-    }
     const int key = (Vin ? 4 : 0) | (Uin ? 2 : 0) | (dzs ? 1 : 0);
     switch (key) {
         case 7: CH_LAUNCH(true, true, true); break;
@@ -1446,7 +729,6 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
         default: CH_LAUNCH(false, false, true); break;
     }
 #undef CH_LAUNCH
-#undef CH_LAUNCH_LDS
     WN_LAUNCH_CHECK();
     if (defer_reduce) return WN_OK;                  // the caller sums all layers' partial tiles with mfma_chain_reduce_all
     hipLaunchKernelGGL(k_layer_bwd_reduce, dim3(kPartFloats / 256, kRedParts), dim3(256), 0, s, part, blocks, dWf, dWg,
@@ -1455,7 +737,7 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
     return WN_OK;
 }
 
-size_t mfma_chain_part_floats() { return (size_t)kMaxBlocks * kPartFloats; }
+size_t mfma_chain_part_floats() { return (size_t)kCMaxBlocks * kPartFloats; }
 
 // Sum the partial tiles of L layers (layer l at part + l * mfma_chain_part_floats()) into their weight gradients.
 // dWp[l] == NULL: that layer had no gradient through its output (the top layer of the stack).
@@ -1463,10 +745,8 @@ int mfma_chain_reduce_all(const float* part, int L, int B, int T, float* const* 
                           float* const* dWp, hipStream_t s) {
     const int tiles_per_b = (T + 31) / 32;
     const long long nt = (long long)B * tiles_per_b;
-    static const bool old_kernel = [] { const char* e = getenv("WAVENET_HIP_CHAIN"); return e && !strcmp(e, "old"); }();
-    int blocks = old_kernel ? (int)((nt + 3) / 4) : (int)((nt + kCWaves - 1) / kCWaves);     // as mfma_layer_bwd_chain
-    const int maxb = old_kernel ? kMaxBlocks : kCMaxBlocks;
-    if (blocks > maxb) blocks = maxb;
+    int blocks = (int)((nt + kCWaves - 1) / kCWaves);        // as mfma_layer_bwd_chain
+    if (blocks > kCMaxBlocks) blocks = kCMaxBlocks;
     for (int l0 = 0; l0 < L; l0 += kRedAllMax) {
         const int n = L - l0 < kRedAllMax ? L - l0 : kRedAllMax;
         RedAllArgs a{};

@@ -100,18 +100,24 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
     }
     float* gbuf[2] = {dab + lw, dab + lw + n * d->Cr};
     const int Tw = T - t_off;
+    // ---- chained path: every layer on the MFMA kernels and no conv / projection bias gradients --------------
+    bool chain = true;
+    for (int l = 0; l < L && chain; ++l)
+        chain = wn_layer_fast_path(d->Cr, d->cd[l], d->fw) && !(dbf && dbf[l]) && !(dbg && dbg[l]) && !(dbp && dbp[l]);
     if (dskip) {
-        rc = wn_skip_sum_bwd_dz(L, d->Ws, d->cd, dskip, dzp.data(), B, T, t_off, Tw, d->Cs, stream);
+        if (chain && d->Cs % 32 == 0) {
+            // the chained layer kernels take dz as 0 below t_off and never read it there: only the loss window is computed
+            wn::ProfScope prof__("wn_skip_sum_bwd_dz", stream);
+            rc = mfma_skip_bwd_dz(L, d->Ws, d->cd, dskip, dzp.data(), B, T, t_off, Tw, d->Cs, true, as_stream(stream));
+        } else {
+            rc = wn_skip_sum_bwd_dz(L, d->Ws, d->cd, dskip, dzp.data(), B, T, t_off, Tw, d->Cs, stream);
+        }
         if (rc) return rc;
         if (dWs) {
             rc = wn_skip_sum_bwd_dw(L, zp.data(), d->cd, dskip, dWs, dbs, B, T, t_off, Tw, d->Cs, stream);
             if (rc) return rc;
         }
     }
-    // ---- chained path: every layer on the MFMA kernels and no conv / projection bias gradients --------------
-    bool chain = true;
-    for (int l = 0; l < L && chain; ++l)
-        chain = wn_layer_fast_path(d->Cr, d->cd[l], d->fw) && !(dbf && dbf[l]) && !(dbg && dbg[l]) && !(dbp && dbp[l]);
     if (chain) {
         // the (da,dg) scratch is not needed: its room holds the partial weight-gradient tiles and, together with the
         // two ping-pong buffers, the split gradient (V, U) of two consecutive layers
@@ -128,7 +134,8 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
             const float* in = l == 0 ? x : xs + (size_t)(l - 1) * n * d->Cr;
             int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
             rc = mfma_layer_bwd_chain(in, f + off[l], g + off[l], d->Wf[l], d->Wg[l], d->Wp[l], Vin, Uin, dU,
-                                      dskip ? dzp[l] : nullptr, Vb[l & 1], Ub[l & 1], dWf[l], dWg[l], dWp[l],
+                                      dskip ? dzp[l] : nullptr, (dskip && d->Cs % 32 == 0) ? t_off : 0, Vb[l & 1], Ub[l & 1],
+                                      dWf[l], dWg[l], dWp[l],
                                       parts + (size_t)l * mfma_chain_part_floats(), B, T, d->dilation[l], Z, true,
                                       as_stream(stream));
             if (rc) return rc;

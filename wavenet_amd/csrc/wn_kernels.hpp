@@ -50,10 +50,11 @@ int mfma_layer_bwd(const float* x, const float* f, const float* g, const float* 
                    const float* Wp, const float* dout, const float* dzs, float* dx, float* dWf, float* dWg,
                    float* dWp, float* dab, int B, int T, int d, int Z, hipStream_t s);
 size_t mfma_layer_bwd_extra_ws_floats();
+// dzs (may be NULL) holds dz_skip for columns t >= dz_t0 only; below that it is taken as 0 and never read
 int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
-                         const float* Wp, const float* Vin, const float* Uin, int dU, const float* dzs, float* Vout,
-                         float* Uout, float* dWf, float* dWg, float* dWp, float* part, int B, int T, int d, int Z,
-                         bool defer_reduce, hipStream_t s);
+                         const float* Wp, const float* Vin, const float* Uin, int dU, const float* dzs, int dz_t0,
+                         float* Vout, float* Uout, float* dWf, float* dWg, float* dWp, float* part, int B, int T, int d,
+                         int Z, bool defer_reduce, hipStream_t s);
 size_t mfma_chain_part_floats();
 int mfma_chain_reduce_all(const float* part, int L, int B, int T, float* const* dWf, float* const* dWg,
                           float* const* dWp, hipStream_t s);
@@ -76,7 +77,7 @@ bool mfma_skip_supported(int L, const int* cd, int Cs);
 int mfma_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const float* const* bs, const int* cd,
                       float* skip, int B, int T, int t_off, int Tw, int Cs, int accumulate, hipStream_t s);
 int mfma_skip_bwd_dz(int L, const float* const* Ws, const int* cd, const float* dskip, float* const* dz, int B,
-                     int T, int t_off, int Tw, int Cs, hipStream_t s);
+                     int T, int t_off, int Tw, int Cs, bool window_only, hipStream_t s);
 bool mfma_pointwise_supported(int Cin, int Cout);
 int mfma_pointwise_fwd(const float* x, const float* W, const float* bias, float* out, long long N, int Cin,
                        int Cout, int act, hipStream_t s);
