@@ -215,9 +215,13 @@ template <bool HAS_DO, bool HAS_U, bool HAS_DZ>
 __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
     const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
-    const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, const float* __restrict__ dzs, int dz_t0,
-    float* __restrict__ Vout, float* __restrict__ Uout, float* __restrict__ part, int B, int T, int d, int Z,
-    int tiles_per_b, int ntiles) {
+    const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, int vu_t0,
+    const float* __restrict__ dzs, int dz_t0, float* __restrict__ Vout, float* __restrict__ Uout,
+    float* __restrict__ part, int B, int T, int d, int Z, int tile_lo, int tiles_per_b, int ntiles) {
+    // tiles_per_b counts the LIVE tiles of a clip: tile k of the grid is tile tile_lo + k % tiles_per_b of clip
+    // k / tiles_per_b.  Columns below 32 * tile_lo cannot receive gradient (they are further from the loss window than
+    // the layers above reach): they are not computed, and Vin / Uin rows below vu_t0 (which the layer above did not
+    // write for the same reason) are taken as 0 without being trusted.
     extern __shared__ __attribute__((aligned(16))) float dyn[];
     float* lWf = dyn;
     float* lWg = dyn + 2048;
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
 
     auto fetch_a = [&](int tile, float* grp, float4 (&dz4)[4]) {
         const int b = tile / tiles_per_b;
-        const int t0 = (tile - b * tiles_per_b) * 32;
+        const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
         if (t0 + 32 + (HAS_U ? dU : 0) <= T) {
             // interior tile (wave-uniform test): one base address per tensor, the four pieces are 1 KB apart
             const long long o = ((long long)b * T + t0 + lr) * 32 + ((lp ^ lr) << 2);
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     };
     auto fetch_x = [&](int tile, float (&xc)[16], float (&xo)[16]) {
         const int b = tile / tiles_per_b;
-        const int t0 = (tile - b * tiles_per_b) * 32;
+        const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
         if (t0 - d >= 0 && t0 + 32 <= T) {               // interior tile: rows 2s+h are 256 B apart from one base
             const float* pc = x + ((long long)b * T + t0 + h) * 32 + j;
             const float* po = pc - (long long)d * 32;
@@ -327,10 +331,11 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
         float* tv = grp + 2048;
         float* tu = grp + 3072;
         const int b = tile / tiles_per_b;
-        const int t0 = (tile - b * tiles_per_b) * 32;
+        const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
         const int t = t0 + j;
         const bool valid = t < T;
-        const float mu = (HAS_U && valid && t + dU < T) ? 1.f : 0.f;
+        const bool vin = t >= vu_t0;                                  // select, never multiply: unwritten rows may hold anything
+        const bool uin = HAS_U && valid && t + dU < T && t + dU >= vu_t0;
         f32x16 acc;
         float ff[16], gg[16], dob[16];
 #pragma unroll
@@ -340,10 +345,13 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
             const float4 f4 = *reinterpret_cast<const float4*>(tf + o);
             const float4 g4 = *reinterpret_cast<const float4*>(tg + o);
             if (HAS_DZ) z4 = dz4[q];
-            if (HAS_DO) o4 = *reinterpret_cast<const float4*>(tv + o);
+            if (HAS_DO) {
+                const float4 v4 = *reinterpret_cast<const float4*>(tv + o);
+                o4.x = vin ? v4.x : 0.f; o4.y = vin ? v4.y : 0.f; o4.z = vin ? v4.z : 0.f; o4.w = vin ? v4.w : 0.f;
+            }
             if (HAS_U) {
                 const float4 u4 = *reinterpret_cast<const float4*>(tu + o);
-                o4.x += u4.x * mu; o4.y += u4.y * mu; o4.z += u4.z * mu; o4.w += u4.w * mu;
+                o4.x += uin ? u4.x : 0.f; o4.y += uin ? u4.y : 0.f; o4.z += uin ? u4.z : 0.f; o4.w += uin ? u4.w : 0.f;
             }
             acc[4 * q] = z4.x; acc[4 * q + 1] = z4.y; acc[4 * q + 2] = z4.z; acc[4 * q + 3] = z4.w;
             ff[4 * q] = f4.x; ff[4 * q + 1] = f4.y; ff[4 * q + 2] = f4.z; ff[4 * q + 3] = f4.w;
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     // flight across the next s_waitcnt vmcnt)
     auto store_vu = [&](int tile) -> bool {
         const int b = tile / tiles_per_b;
-        const int t0 = (tile - b * tiles_per_b) * 32;
+        const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
         const bool full = t0 + 32 <= T;
         if (full) {
             float* pv = Vout + ((long long)b * T + t0 + lr) * 32 + ((lp ^ lr) << 2);
@@ -431,7 +439,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     struct WOps { float a_da[16], a_dg[16], a_do[16], b_z[16], b_xc[16], b_xo[16]; };
     auto take = [&](int tile, const float* grp, const float (&xc)[16], const float (&xo)[16], WOps& w) {
         const int b = tile / tiles_per_b;
-        const int t0 = (tile - b * tiles_per_b) * 32;
+        const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int r = 2 * s + h;
@@ -542,14 +550,15 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
 
 // dx[t] = V[t] + U[t + dU]   (the split gradient of the stack input, materialised once at the bottom)
 __global__ void k_chain_combine(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ dx,
-                                int B, int T, int dU) {
+                                int B, int T, int dU, int vu_t0) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index
     const long long n4 = (long long)B * T * 8;
     if (i >= n4) return;
     const long long col = i >> 3;
     const int t = (int)(col % T);
-    float4 v = reinterpret_cast<const float4*>(V)[i];
-    if (t + dU < T) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);          // rows below vu_t0 were not written: exact zeros
+    if (t >= vu_t0) v = reinterpret_cast<const float4*>(V)[i];
+    if (t + dU < T && t + dU >= vu_t0) {
         const float4 u = reinterpret_cast<const float4*>(U)[i + (long long)dU * 8];
         v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
     }
@@ -582,11 +591,12 @@ __global__ void k_layer_bwd_reduce(const float* __restrict__ part, int nwg, floa
 // The same sum for up to kRedAllMax layers in one launch (blockIdx.z = layer): the stack's chained backward keeps
 // every layer's partial tiles and reduces them all at the end, instead of 40 small launches between the layer kernels.
 static constexpr int kRedAllMax = 64;
-struct RedAllArgs { float* dWf[kRedAllMax]; float* dWg[kRedAllMax]; float* dWp[kRedAllMax]; };
-__global__ void k_layer_bwd_reduce_all(const float* __restrict__ part, long long layer_stride, int nwg, RedAllArgs a) {
+struct RedAllArgs { float* dWf[kRedAllMax]; float* dWg[kRedAllMax]; float* dWp[kRedAllMax]; int nwg[kRedAllMax]; };
+__global__ void k_layer_bwd_reduce_all(const float* __restrict__ part, long long layer_stride, RedAllArgs a) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= kPartFloats) return;
     const int l = blockIdx.z;
+    const int nwg = a.nwg[l];
     const float* __restrict__ p = part + (long long)l * layer_stride;
     const int per = (nwg + kRedParts - 1) / kRedParts;
     const int w0 = blockIdx.y * per, w1 = min(nwg, w0 + per);
@@ -695,18 +705,24 @@ int mfma_layer_bwd(const float* x, const float* f, const float* g, const float* 
 
 size_t mfma_layer_bwd_extra_ws_floats() { return (size_t)kMaxBlocks * kPartFloats; }
 
-// One layer of the chained backward.  Vin/Uin (either may be NULL): dout[t] = Vin[t] + Uin[t + dU].
+// One layer of the chained backward.  Vin/Uin (either may be NULL): dout[t] = Vin[t] + Uin[t + dU] with rows below
+// vu_t0 taken as 0; columns below t_live are not computed (no gradient reaches them).  Returns the number of
+// workgroups (= partial weight-gradient tiles written to `part`) through *nwg.
 int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
-                         const float* Wp, const float* Vin, const float* Uin, int dU, const float* dzs, int dz_t0,
-                         float* Vout, float* Uout, float* dWf, float* dWg, float* dWp, float* part, int B, int T, int d,
-                         int Z, bool defer_reduce, hipStream_t s) {
-    const int tiles_per_b = (T + 31) / 32;
+                         const float* Wp, const float* Vin, const float* Uin, int dU, int vu_t0, const float* dzs,
+                         int dz_t0, float* Vout, float* Uout, float* part, int B, int T, int d, int Z, int t_live,
+                         int* nwg, hipStream_t s) {
+    const int tiles_all = (T + 31) / 32;
+    const int tile_lo = t_live > 0 ? t_live / 32 : 0;
+    const int tiles_per_b = tiles_all - tile_lo;
     const long long nt = (long long)B * tiles_per_b;
     WN_CHECK_SHAPE(nt < (1ll << 31), "mfma_layer_bwd_chain: too many tiles");
+    WN_CHECK_ARG(tiles_per_b > 0, "mfma_layer_bwd_chain: no live column");
     WN_CHECK_ARG(Vin || Uin || dzs, "mfma_layer_bwd_chain: no incoming gradient");
     const int ntiles = (int)nt;
     int blocks = (ntiles + kCWaves - 1) / kCWaves;
     if (blocks > kCMaxBlocks) blocks = kCMaxBlocks;
+    if (nwg) *nwg = blocks;
 #define CH_LAUNCH(DO, UU, DZ)                                                                                      \
     do {                                                                                                           \
         static bool attr_set = false;                                                                              \
@@ -716,7 +732,8 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
             attr_set = true;                                                                                       \
         }                                                                                                          \
         hipLaunchKernelGGL((k_layer_bwd_chainsp<DO, UU, DZ>), dim3(blocks), dim3(64 * kCWaves), kCLdsBytes, s, x, f, g, \
-                           Wp, Wf, Wg, Vin, Uin, dU, dzs, dz_t0, Vout, Uout, part, B, T, d, Z, tiles_per_b, ntiles); \
+                           Wp, Wf, Wg, Vin, Uin, dU, vu_t0, dzs, dz_t0, Vout, Uout, part, B, T, d, Z, tile_lo,     \
+                           tiles_per_b, ntiles);                                                                   \
     } while (0)
     const int key = (Vin ? 4 : 0) | (Uin ? 2 : 0) | (dzs ? 1 : 0);
     switch (key) {
@@ -730,37 +747,31 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
     }
 #undef CH_LAUNCH
     WN_LAUNCH_CHECK();
-    if (defer_reduce) return WN_OK;                  // the caller sums all layers' partial tiles with mfma_chain_reduce_all
-    hipLaunchKernelGGL(k_layer_bwd_reduce, dim3(kPartFloats / 256, kRedParts), dim3(256), 0, s, part, blocks, dWf, dWg,
-                       (Vin || Uin) ? dWp : (float*)nullptr);
-    WN_LAUNCH_CHECK();
     return WN_OK;
 }
 
 size_t mfma_chain_part_floats() { return (size_t)kCMaxBlocks * kPartFloats; }
 
-// Sum the partial tiles of L layers (layer l at part + l * mfma_chain_part_floats()) into their weight gradients.
-// dWp[l] == NULL: that layer had no gradient through its output (the top layer of the stack).
-int mfma_chain_reduce_all(const float* part, int L, int B, int T, float* const* dWf, float* const* dWg,
+// Sum the partial tiles of L layers (layer l: nwg[l] tiles at part + l * mfma_chain_part_floats()) into their weight
+// gradients.  dWp[l] == NULL: that layer had no gradient through its output (the top layer of the stack).
+int mfma_chain_reduce_all(const float* part, int L, const int* nwg, float* const* dWf, float* const* dWg,
                           float* const* dWp, hipStream_t s) {
-    const int tiles_per_b = (T + 31) / 32;
-    const long long nt = (long long)B * tiles_per_b;
-    int blocks = (int)((nt + kCWaves - 1) / kCWaves);        // as mfma_layer_bwd_chain
-    if (blocks > kCMaxBlocks) blocks = kCMaxBlocks;
     for (int l0 = 0; l0 < L; l0 += kRedAllMax) {
         const int n = L - l0 < kRedAllMax ? L - l0 : kRedAllMax;
         RedAllArgs a{};
-        for (int l = 0; l < n; ++l) { a.dWf[l] = dWf[l0 + l]; a.dWg[l] = dWg[l0 + l]; a.dWp[l] = dWp[l0 + l]; }
+        for (int l = 0; l < n; ++l) {
+            a.dWf[l] = dWf[l0 + l]; a.dWg[l] = dWg[l0 + l]; a.dWp[l] = dWp[l0 + l]; a.nwg[l] = nwg[l0 + l];
+        }
         hipLaunchKernelGGL(k_layer_bwd_reduce_all, dim3(kPartFloats / 256, kRedParts, n), dim3(256), 0, s,
-                           part + (size_t)l0 * mfma_chain_part_floats(), (long long)mfma_chain_part_floats(), blocks, a);
+                           part + (size_t)l0 * mfma_chain_part_floats(), (long long)mfma_chain_part_floats(), a);
         WN_LAUNCH_CHECK();
     }
     return WN_OK;
 }
 
-int mfma_chain_combine(const float* V, const float* U, float* dx, int B, int T, int dU, hipStream_t s) {
+int mfma_chain_combine(const float* V, const float* U, float* dx, int B, int T, int dU, int vu_t0, hipStream_t s) {
     const long long n4 = (long long)B * T * 8;
-    hipLaunchKernelGGL(k_chain_combine, dim3(cdiv(n4, 256)), dim3(256), 0, s, V, U, dx, B, T, dU);
+    hipLaunchKernelGGL(k_chain_combine, dim3(cdiv(n4, 256)), dim3(256), 0, s, V, U, dx, B, T, dU, vu_t0);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

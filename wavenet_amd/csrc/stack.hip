@@ -124,30 +124,39 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
         float* parts = gbuf[1] + n * d->Cr;          // L x mfma_chain_part_floats(): summed once, after the last layer
         float* vu = dab + mfma_layer_bwd_extra_ws_floats();
         std::vector<float*> dWp_eff(L);
+        std::vector<int> nwg(L);
         float* Vb[2] = {vu, vu + n * d->Cr};
         float* Ub[2] = {vu + 2 * n * d->Cr, vu + 3 * n * d->Cr};
         const float* Vin = dout;
         const float* Uin = nullptr;
         int dU = 0;
+        // Dead columns: with no gradient through the stack's residual output, layer l receives gradient only at columns
+        // t >= t_off - (reach of the layers above it) -- everything below is exactly zero and is neither computed nor
+        // stored.  t_live is rounded down to a tile; the layer below is told where the written rows start.
+        int t_live = dout ? 0 : t_off;               // first column of the current layer that can carry gradient
+        int vu_t0 = 0;                               // first written row of Vin / Uin
         for (int l = L - 1; l >= 0; --l) {
             wn::ProfScope prof__("wn_layer_bwd", stream);
             const float* in = l == 0 ? x : xs + (size_t)(l - 1) * n * d->Cr;
             int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
-            rc = mfma_layer_bwd_chain(in, f + off[l], g + off[l], d->Wf[l], d->Wg[l], d->Wp[l], Vin, Uin, dU,
-                                      dskip ? dzp[l] : nullptr, (dskip && d->Cs % 32 == 0) ? t_off : 0, Vb[l & 1], Ub[l & 1],
-                                      dWf[l], dWg[l], dWp[l],
-                                      parts + (size_t)l * mfma_chain_part_floats(), B, T, d->dilation[l], Z, true,
-                                      as_stream(stream));
+            const int live = (t_live / 32) * 32;
+            rc = mfma_layer_bwd_chain(in, f + off[l], g + off[l], d->Wf[l], d->Wg[l], d->Wp[l], Vin, Uin, dU, vu_t0,
+                                      dskip ? dzp[l] : nullptr, (dskip && d->Cs % 32 == 0) ? t_off : 0, Vb[l & 1],
+                                      Ub[l & 1], parts + (size_t)l * mfma_chain_part_floats(), B, T, d->dilation[l], Z,
+                                      live, &nwg[l], as_stream(stream));
             if (rc) return rc;
             dWp_eff[l] = (Vin || Uin) ? dWp[l] : nullptr;
             Vin = Vb[l & 1]; Uin = Ub[l & 1]; dU = d->dilation[l];
+            vu_t0 = live;
+            t_live = t_live - (d->fw - 1) * d->dilation[l];      // the layer below: one more dilation of reach
+            if (t_live < 0) t_live = 0;
         }
         {
             wn::ProfScope prof__("wn_layer_bwd", stream);
-            rc = mfma_chain_reduce_all(parts, L, B, T, dWf, dWg, dWp_eff.data(), as_stream(stream));
+            rc = mfma_chain_reduce_all(parts, L, nwg.data(), dWf, dWg, dWp_eff.data(), as_stream(stream));
             if (rc) return rc;
         }
-        if (dx) return mfma_chain_combine(Vin, Uin, dx, B, T, dU, as_stream(stream));
+        if (dx) return mfma_chain_combine(Vin, Uin, dx, B, T, dU, vu_t0, as_stream(stream));
         return WN_OK;
     }
     const float* gout = dout;

@@ -50,15 +50,16 @@ int mfma_layer_bwd(const float* x, const float* f, const float* g, const float* 
                    const float* Wp, const float* dout, const float* dzs, float* dx, float* dWf, float* dWg,
                    float* dWp, float* dab, int B, int T, int d, int Z, hipStream_t s);
 size_t mfma_layer_bwd_extra_ws_floats();
-// dzs (may be NULL) holds dz_skip for columns t >= dz_t0 only; below that it is taken as 0 and never read
+// Chained backward of the fused layer (mfma_layer_bwd.hip).  dout[t] = Vin[t] + Uin[t + dU], rows below vu_t0 taken as
+// 0; dzs (may be NULL) is dz_skip for columns t >= dz_t0; columns below t_live are not computed.
 int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
-                         const float* Wp, const float* Vin, const float* Uin, int dU, const float* dzs, int dz_t0,
-                         float* Vout, float* Uout, float* dWf, float* dWg, float* dWp, float* part, int B, int T, int d,
-                         int Z, bool defer_reduce, hipStream_t s);
+                         const float* Wp, const float* Vin, const float* Uin, int dU, int vu_t0, const float* dzs,
+                         int dz_t0, float* Vout, float* Uout, float* part, int B, int T, int d, int Z, int t_live,
+                         int* nwg, hipStream_t s);
 size_t mfma_chain_part_floats();
-int mfma_chain_reduce_all(const float* part, int L, int B, int T, float* const* dWf, float* const* dWg,
+int mfma_chain_reduce_all(const float* part, int L, const int* nwg, float* const* dWf, float* const* dWg,
                           float* const* dWp, hipStream_t s);
-int mfma_chain_combine(const float* V, const float* U, float* dx, int B, int T, int dU, hipStream_t s);
+int mfma_chain_combine(const float* V, const float* U, float* dx, int B, int T, int dU, int vu_t0, hipStream_t s);
 int generic_layer_bwd_biases(const float* dab, const float* dout, float* dbf, float* dbg, float* dbp, int B,
                              int T, int Cr, int Cd, int Z, hipStream_t s);
 
