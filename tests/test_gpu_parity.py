@@ -308,6 +308,42 @@ def test_train_step_grads_general(over, B, T, tw, bias):
             assert np.abs(got - want).max() <= 2e-4 * scale + 1e-7, (fused, ln.name, kind)
 
 
+@pytest.mark.parametrize("B,T,tw,with_out", [(3, 1000, 200, True), (2, 777, 333, True), (2, 1000, 64, False)])
+def test_chained_backward_live_columns_and_residual_output_gradient(B, T, tw, with_out):
+    """The chained stack backward skips the columns no gradient can reach (everything further below the loss window
+    than the layers above a layer can see) unless the residual output itself carries gradient.  Both cases, ragged T
+    (not a multiple of the 32-column tile), against the oracle's autograd: loss = CE(window) [+ <residual out, R>]."""
+    over = dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 5, residual_num_blocks=2,
+                softmax_conv_channels=[64, 256])
+    p, w, net = build(over, seed=31)
+    Q = p["quantization_steps"]
+    rs = np.random.RandomState(8)
+    idx = rs.randint(0, Q, (B, T)).astype(np.int32)
+    tgt = rs.randint(0, Q, (B, tw)).astype(np.int32)
+    Rw = (rs.standard_normal((B, 32, 1, T)) * 1e-3).astype(np.float32)
+    ref = R.RefWaveNet(p, w, requires_grad=True)
+    o = ref.forward_causal_block(R.onehot_t(idx, Q))
+    o, sk = ref.forward_residual_block(o)
+    lref = ref.cross_entropy(ref.forward_softmax_block(sk[:, :, :, T - tw:], apply_softmax=False), tgt)
+    if with_out:
+        lref = lref + (o * torch.tensor(Rw)).sum()
+    lref.backward()
+    c = net.forward_causal_block(idx)
+    out, s = net.forward_residual_block(c, t_off=T - tw)
+    loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt)
+    if with_out:
+        loss = loss + (out * dev(Rw)).sum()
+    net.zero_grads()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(lref.detach())) < 2e-4
+    for ln, kind, off, n, shape in net._spans:
+        gr = ref.w["%s/%s" % (ln.name, kind)].grad
+        want = gr.numpy() if gr is not None else np.zeros(shape, np.float32)
+        got = to_np(net._grad_arena[off:off + n].view(shape))
+        scale = max(np.abs(want).max(), 1e-6)
+        assert np.abs(got - want).max() <= 2e-4 * scale + 1e-7, (ln.name, kind, np.abs(got - want).max(), scale)
+
+
 def test_adam_step_matches_chainer_rule():
     p, w, net = build(CFG1, gradient_clipping=0.05)
     net.params.weight_decay = 0.01
