@@ -224,8 +224,8 @@ def main():
         Cr, Cd, Cs = 32, 32, 256
         alg_bytes_layer = 4 * (2 * Cr + 2 * Cs) * B_PER_GPU * T            # 2,304 B per sample-layer
         alg_flops_layer = 2 * (2 * 2 * Cr * Cd + Cd * Cr + Cd * Cs) * B_PER_GPU * T
-        layer_ms = ms2["wn_layer_fwd"][1] / ms2["wn_layer_fwd"][0]
-        skip_ms = ms2["wn_skip_sum_fwd"][1] / ms2["wn_skip_sum_fwd"][0]
+        layer_ms = ms2["wn_layer_fwd"][1] / 10 / nl           # one event bracket per stack call around its nl launches
+        skip_ms = ms2["wn_skip_sum_fwd"][1] / 10
         stack_ms = layer_ms * nl + skip_ms
         out["stack_forward"] = {
             "samples_per_s": B_PER_GPU * T / sdt, "ms_wall": sdt * 1e3, "ms_kernels": stack_ms,
@@ -246,7 +246,7 @@ def main():
         units = {
             # name: (bound, algorithmic amount per launch, launches per step, kernels for PMC traffic)
             "wn_layer_bwd": ("hbm", es * (3 * Cr + Cs + 2 * Cd) * n_col, nl,
-                             ["wn::k_layer_bwd_chain8<true, true, true>", "wn::k_layer_bwd_reduce"]),
+                             ["wn::k_layer_bwd_chainsp<true, true, true>"]),
             "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl, ["wn::k_layer_fwd_mfma32<true, false>"]),
             "wn_skip_sum_fwd": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<0>"]),
             "wn_skip_sum_bwd_dw": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_wgrad_b3<4>"]),

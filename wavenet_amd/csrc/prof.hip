@@ -16,6 +16,7 @@ std::mutex g_mu;
 bool g_on = false;
 std::vector<std::string> g_names;
 std::vector<Rec> g_recs;
+thread_local int tl_group = -1;      // id of the open ProfGroup of this thread, if any
 int name_id(const char* n) {
     for (size_t i = 0; i < g_names.size(); ++i)
         if (g_names[i] == n) return (int)i;
@@ -29,6 +30,7 @@ ProfScope::ProfScope(const char* name, void* stream) : on(false) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!g_on) return;
     id = name_id(name);
+    if (id == tl_group) return;          // inside a ProfGroup of the same name: the group's bracket covers this call
     s = as_stream(stream);
     if (hipEventCreate(&e0) != hipSuccess) return;
     if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return; }
@@ -40,6 +42,12 @@ ProfScope::~ProfScope() {
     (void)hipEventRecord(e1, s);
     std::lock_guard<std::mutex> lk(g_mu);
     g_recs.push_back(Rec{id, e0, e1});
+}
+ProfGroup::ProfGroup(const char* name, void* stream) : scope(name, stream) {
+    if (scope.on) tl_group = scope.id;
+}
+ProfGroup::~ProfGroup() {
+    if (scope.on) tl_group = -1;
 }
 }  // namespace wn
 

@@ -58,16 +58,19 @@ int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, floa
     std::vector<const float*> zp(L);
     size_t zoff = 0;
     const float* in = x;
-    for (int l = 0; l < L; ++l) {
-        float* out = xs + (size_t)l * n * d->Cr;
-        int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
-        rc = wn_layer_fwd(in, d->Wf[l], d->bf ? d->bf[l] : nullptr, d->Wg[l], d->bg ? d->bg[l] : nullptr, d->Wp[l],
-                          d->bp ? d->bp[l] : nullptr, out, z + zoff, f ? f + zoff : nullptr, g ? g + zoff : nullptr,
-                          B, T, d->Cr, d->cd[l], d->fw, d->dilation[l], Z, stream);
-        if (rc) return rc;
-        zp[l] = z + zoff;
-        zoff += n * d->cd[l];
-        in = out;
+    {
+        wn::ProfGroup prof_layers__("wn_layer_fwd", stream);     // one bracket around the L launches
+        for (int l = 0; l < L; ++l) {
+            float* out = xs + (size_t)l * n * d->Cr;
+            int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
+            rc = wn_layer_fwd(in, d->Wf[l], d->bf ? d->bf[l] : nullptr, d->Wg[l], d->bg ? d->bg[l] : nullptr, d->Wp[l],
+                              d->bp ? d->bp[l] : nullptr, out, z + zoff, f ? f + zoff : nullptr, g ? g + zoff : nullptr,
+                              B, T, d->Cr, d->cd[l], d->fw, d->dilation[l], Z, stream);
+            if (rc) return rc;
+            zp[l] = z + zoff;
+            zoff += n * d->cd[l];
+            in = out;
+        }
     }
     if (skip)
         return wn_skip_sum_fwd(L, zp.data(), d->Ws, d->bs, d->cd, skip, B, T, t_off, T - t_off, d->Cs, 0, stream);
@@ -135,8 +138,8 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
         // stored.  t_live is rounded down to a tile; the layer below is told where the written rows start.
         int t_live = dout ? 0 : t_off;               // first column of the current layer that can carry gradient
         int vu_t0 = 0;                               // first written row of Vin / Uin
+        wn::ProfScope prof__("wn_layer_bwd", stream);        // one bracket: 40 layer kernels + the tile reduction
         for (int l = L - 1; l >= 0; --l) {
-            wn::ProfScope prof__("wn_layer_bwd", stream);
             const float* in = l == 0 ? x : xs + (size_t)(l - 1) * n * d->Cr;
             int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
             const int live = (t_live / 32) * 32;
@@ -151,11 +154,8 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
             t_live = t_live - (d->fw - 1) * d->dilation[l];      // the layer below: one more dilation of reach
             if (t_live < 0) t_live = 0;
         }
-        {
-            wn::ProfScope prof__("wn_layer_bwd", stream);
-            rc = mfma_chain_reduce_all(parts, L, nwg.data(), dWf, dWg, dWp_eff.data(), as_stream(stream));
-            if (rc) return rc;
-        }
+        rc = mfma_chain_reduce_all(parts, L, nwg.data(), dWf, dWg, dWp_eff.data(), as_stream(stream));
+        if (rc) return rc;
         if (dx) return mfma_chain_combine(Vin, Uin, dx, B, T, dU, vu_t0, as_stream(stream));
         return WN_OK;
     }

@@ -56,6 +56,13 @@ struct ProfScope {
     ProfScope(const char* name, void* stream);
     ~ProfScope();
 };
+// One bracket around a loop of calls that each have a ProfScope of the same name (the stack's layer loops): the
+// launches run back to back inside it, as they do in production, instead of each between its own pair of events.
+struct ProfGroup {
+    ProfScope scope;
+    ProfGroup(const char* name, void* stream);
+    ~ProfGroup();
+};
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- device math shared by the generic and the MFMA kernels ---------------------------------
