@@ -159,7 +159,10 @@ def main():
     # backward, clip + Adam; with N > 1 the RCCL all-reduce runs between a forward/backward graph and an optimiser
     # graph) and each timed step is one replay.  --no-graph times the same step launched op by op.
     graph = None
-    if not args.no_graph:
+    # N > 1: op-by-op launches by default (the gain of a replayed step is ~3 % and the two-graph data-parallel form has only
+    # been exercised with two ranks sharing one GPU); WAVENET_BENCH_GRAPH_DP=1 turns it on
+    use_graph = not args.no_graph and (world == 1 or os.environ.get("WAVENET_BENCH_GRAPH_DP") == "1")
+    if use_graph:
         try:
             graph = TrainStepGraph(net, x, tgt)
         except Exception as e:                                           # keep the bench alive: fall back to op-by-op

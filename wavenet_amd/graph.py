@@ -55,13 +55,14 @@ class TrainStepGraph(object):
             net._arena.copy_(keep[0]); opt.m.copy_(keep[1]); opt.v.copy_(keep[2])
         self._g1 = torch.cuda.CUDAGraph()
         self._g2 = None
-        with torch.cuda.graph(self._g1, stream=self._stream):
+        # thread_local: API calls of other threads (an RCCL watchdog, a data loader) must not invalidate the capture
+        with torch.cuda.graph(self._g1, stream=self._stream, capture_error_mode="thread_local"):
             self.loss = self._fwd_bwd()
             if not dp:
                 self._opt()
         if dp:
             self._g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g2, stream=self._stream, pool=self._g1.pool()):
+            with torch.cuda.graph(self._g2, stream=self._stream, pool=self._g1.pool(), capture_error_mode="thread_local"):
                 self._opt()
         opt.t = keep[3]
         net._weights_changed()
