@@ -4,18 +4,24 @@
 // Same algorithm and state as k_decode in decoder.hip (FasterWaveNet._forward_one_step restated with
 // rings instead of rolled windows); what changes is how ONE workgroup is used so that a step is not
 // a chain of L2 round trips and wide barriers:
-//   * 256 threads = one wave per SIMD: a workgroup barrier costs ~130 cycles instead of ~500 with 16
-//     waves (measured), and there are two per layer (gate -> z, projection -> next x);
+//   * 256 threads = one wave per SIMD;
 //   * the 64 KB embedding table of the causal layer sits in LDS for the whole launch;
 //   * the head's 256x256 weights live in registers for the whole launch (256 per thread: one wave
 //     per SIMD owns the whole 512-entry register file);
 //   * a layer's 13,312 weights are 52 per thread, fetched ONE LAYER AHEAD (the loads of layer l+1 are
 //     in flight while layer l computes; the in-loop barriers wait for LDS only, never for vmcnt), as
 //     is the ring column x[n-d] of the next layer;
-//   * the waves are specialised: waves 0-1 run only the dependent chain (gate rows over 2 lanes, the
-//     residual projection over 4, DPP reductions), waves 2-3 run the skip projection (61 % of the
-//     MACs) ONE LAYER BEHIND from a table of z columns in LDS, two rows per thread accumulated in
-//     registers over all 40 layers -- off the critical path, no reduction, no extra barrier.
+//   * the waves are specialised.  Wave 0 alone runs the dependent chain of the 40 layers WITHOUT any barrier and
+//     without an LDS round trip on the critical path: lane r owns gate row r (filter rows in lanes 0-31, gate rows in
+//     32-63) with its 64 weights in registers, the x[n] it multiplies them with reaches it as 32 scalar broadcasts
+//     (v_readlane -> SGPR operand of v_fmac), tanh and sigmoid are ONE exp + rcp sequence over the two half waves,
+//     v_permlane32_swap brings filter and gate together, the residual projection is 32 more broadcast-FMAs per lane;
+//     the x[n-d] half of the gate (known since the start of the step) comes from LDS broadcast reads off the critical
+//     path.  (The previous form -- gate rows over 2 lanes, projection over 4, DPP reductions, z and x through LDS with
+//     two workgroup barriers per layer -- took 1,650 cycles per layer.)
+//     Waves 2-3 run the skip projection (61 % of the MACs) behind the chain from the table of z columns in LDS, two
+//     rows per thread accumulated in registers over all 40 layers; they follow the chain through a layer counter in
+//     LDS (LDS operations of a wave retire in order, so the counter store after the z store publishes it).
 #include "wn_kernels.hpp"
 #include "decoder_types.hpp"
 
@@ -23,7 +29,8 @@ namespace wn {
 
 static constexpr int kFT = 256;      // waves 0-1: the dependent chain; waves 2-3: skip rows, one layer behind
 static constexpr int kMaxFastLayers = 128;
-static constexpr int kLayerFloats = 4096 + 1024 + 8192;     // gate | residual projection | skip projection
+static constexpr int kGateFloats = 4096, kProjFloats = 2048;
+static constexpr int kLayerFloats = kGateFloats + kProjFloats + 8192;     // gate | residual projection (both half waves) | skip projection
 
 __device__ __forceinline__ float dpp_f(float v, int ctrl_sel) {
     int r;
@@ -81,31 +88,29 @@ __device__ __forceinline__ double wave_scan_f64(double v) {
 }
 __device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-// ---- packing: every per-thread weight group is a float4 at [plane][thread] (coalesced 16-byte loads) --
-// chain threads t = 0..127:  gate  row r = t/2 = 2c + (0 filter | 1 gate), k = 32*(t%2) + 4j + e  (8 planes)
-//                            Wp    row o = t/4, k = 8*(t%4) + 4j + e                                (2 planes)
-// skip threads  t = 0..127:  rows cs = 2t (planes 0-7) and 2t+1 (planes 8-15), k = 4(j%8) + e
+// ---- packing: every per-lane weight group is a float4 at [plane][lane] (coalesced 16-byte loads) --
+// chain wave, lane r = 0..63:  gate row r (0-31 filter channel r, 32-63 gate channel r-32), k = 4j + e over
+//                              [x_old(32) | x_cur(32)]                                           (16 planes of 64 lanes)
+//                              Wp row o = r % 32, k = 4j + e (both half waves hold the same rows)  (8 planes)
+// skip threads t = 0..127:     rows cs = 2t (planes 0-7) and 2t+1 (planes 8-15), k = 4(j%8) + e
 __global__ void k_pack_fast_layer(const float* __restrict__ Wf, const float* __restrict__ Wg,
                                   const float* __restrict__ Wp, const float* __restrict__ Ws,
                                   float* __restrict__ dst) {
     const int t = threadIdx.x;     // 0..127
-    {
-        const int r = t >> 1, kp = t & 1, c = r >> 1;
-        const float* W = (r & 1) ? Wg : Wf;
-        for (int j = 0; j < 8; ++j)
+    if (t < 64) {
+        const int c = t & 31;
+        const float* W = (t >> 5) ? Wg : Wf;
+        for (int j = 0; j < 16; ++j)
             for (int e = 0; e < 4; ++e) {
-                const int k = 32 * kp + 4 * j + e, tap = k >> 5, ch = k & 31;     // [x_old(32) | x_cur(32)]
-                dst[(j * 128 + t) * 4 + e] = W[(c * 32 + ch) * 2 + tap];
+                const int k = 4 * j + e, tap = k >> 5, ch = k & 31;               // [x_old(32) | x_cur(32)]
+                dst[(j * 64 + t) * 4 + e] = W[(c * 32 + ch) * 2 + tap];
             }
-    }
-    {
-        const int o = t >> 2, kp = t & 3;
-        for (int j = 0; j < 2; ++j)
-            for (int e = 0; e < 4; ++e) dst[4096 + (j * 128 + t) * 4 + e] = Wp[o * 32 + 8 * kp + 4 * j + e];
+        for (int j = 0; j < 8; ++j)
+            for (int e = 0; e < 4; ++e) dst[kGateFloats + (j * 64 + t) * 4 + e] = Wp[c * 32 + 4 * j + e];
     }
     for (int j = 0; j < 16; ++j)
         for (int e = 0; e < 4; ++e)
-            dst[5120 + (j * 128 + t) * 4 + e] = Ws[(2 * t + (j >> 3)) * 32 + 4 * (j & 7) + e];
+            dst[kGateFloats + kProjFloats + (j * 128 + t) * 4 + e] = Ws[(2 * t + (j >> 3)) * 32 + 4 * (j & 7) + e];
 }
 // head: row q = tid, k = 4j+e  ->  Ph[j][tid][4], j = 0..63
 __global__ void k_pack_fast_head(const float* __restrict__ Wh, float* __restrict__ dst) {
@@ -114,19 +119,19 @@ __global__ void k_pack_fast_head(const float* __restrict__ Wh, float* __restrict
         for (int e = 0; e < 4; ++e) dst[(j * 256 + tid) * 4 + e] = Wh[tid * 256 + 4 * j + e];
 }
 
-struct ChainW { float4 g[8]; float4 p[2]; };
+struct ChainW { float4 g[16]; float4 p[8]; };
 struct SkipW { float4 s[16]; };
 
 // uniform plane base (SGPRs) + a 32-bit per-lane offset: global_load with an saddr, no 64-bit VALU adds
-__device__ __forceinline__ void load_chain(ChainW& w, const float* __restrict__ P, int l, unsigned t4) {
+__device__ __forceinline__ void load_chain(ChainW& w, const float* __restrict__ P, int l, unsigned l4) {
     const float* b = P + (long long)l * kLayerFloats;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w.g[j] = *reinterpret_cast<const float4*>(b + j * 512 + t4);
+    for (int j = 0; j < 16; ++j) w.g[j] = *reinterpret_cast<const float4*>(b + j * 256 + l4);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) w.p[j] = *reinterpret_cast<const float4*>(b + 4096 + j * 512 + t4);
+    for (int j = 0; j < 8; ++j) w.p[j] = *reinterpret_cast<const float4*>(b + kGateFloats + j * 256 + l4);
 }
 __device__ __forceinline__ void load_skip(SkipW& w, const float* __restrict__ P, int l, unsigned t4) {
-    const float* b = P + (long long)l * kLayerFloats + 5120;
+    const float* b = P + (long long)l * kLayerFloats + kGateFloats + kProjFloats;
 #pragma unroll
     for (int j = 0; j < 16; ++j) w.s[j] = *reinterpret_cast<const float4*>(b + j * 512 + t4);
 }
@@ -139,32 +144,69 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-struct FastLds { const float* xold; float* xcur; float* zall; };
+struct FastLds { const float* xold; float* xcur; float* zall; int* ready; };
 
-// chain waves: one residual layer of one step.  x_old = xold[l], x_cur = xcur[l]; writes z to zall[l]
-// and x of layer l+1 to xcur[l+1].
-__device__ __forceinline__ void chain_layer(const FastLds& S, const ChainW& wc, int l, int t) {
-    {   // gate: 64 rows x K=64, 2 lanes per row (lane 0: x_old, lane 1: x_cur)
-        const float* xk = ((t & 1) == 0 ? S.xold : S.xcur) + l * 32;
-        float p0 = 0.f, p1 = 0.f;
+__device__ __forceinline__ float f4c(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+__device__ __forceinline__ float bcast(float v, int k) {       // lane k's value as a scalar (SGPR) operand
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
+}
+
+// The chain wave: one residual layer of one step.  xc = x_l[n] (channel lane % 32, valid in every lane); returns
+// x_{l+1}[n].  Writes z to zall[l] and x_{l+1}[n] to xcur[l+1] (for the ring update), then publishes the layer.
+__device__ __forceinline__ void load_xold(float4 (&xo)[8], const FastLds& S, int l) {   // broadcast reads (uniform address)
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-            p0 += dot4(wc.g[j], *reinterpret_cast<const float4*>(xk + 4 * j));
-            p1 += dot4(wc.g[j + 1], *reinterpret_cast<const float4*>(xk + 4 * j + 4));
-        }
-        float p = p0 + p1;
-        p += dpp_f(p, 101);                               // both lanes of the pair hold the row's sum
-        const float fsum = dpp_f(p, 102);                 // gate pair (lanes 4c+2,3) <- filter pair (4c, 4c+1)
-        if ((t & 3) == 2) S.zall[l * 32 + (t >> 2)] = fast_tanh(fsum) * fast_sigmoid(p);
+    for (int j = 0; j < 8; ++j) xo[j] = *reinterpret_cast<const float4*>(S.xold + l * 32 + 4 * j);
+}
+__device__ __forceinline__ float chain_layer(const FastLds& S, const ChainW& w, float4 (&xo)[8], int l, int nlayers, int lane, float xc) {
+    // gate row `lane`: the x[n] half -- the critical path -- from 32 scalar broadcasts, all read before the first use
+    // (a v_readlane result needs wait states before a VALU may consume it: batched, the FMAs need no s_nop)
+    float sx[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) sx[k] = bcast(xc, k);
+    float a0 = 0.f, a1 = 0.f;
+    // ... the x[n-d] half was fetched from LDS (same address in every lane) a layer ago
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        a0 = fmaf(w.g[j].x, xo[j].x, a0); a1 = fmaf(w.g[j + 1].x, xo[j + 1].x, a1);
+        a0 = fmaf(w.g[j].y, xo[j].y, a0); a1 = fmaf(w.g[j + 1].y, xo[j + 1].y, a1);
+        a0 = fmaf(w.g[j].z, xo[j].z, a0); a1 = fmaf(w.g[j + 1].z, xo[j + 1].z, a1);
+        a0 = fmaf(w.g[j].w, xo[j].w, a0); a1 = fmaf(w.g[j + 1].w, xo[j + 1].w, a1);
     }
-    lds_barrier();
-    {   // residual projection: 32 rows x K=32, 4 lanes per row
-        const float* zk = S.zall + l * 32 + 8 * (t & 3);
-        float p = dot4(wc.p[0], *reinterpret_cast<const float4*>(zk)) + dot4(wc.p[1], *reinterpret_cast<const float4*>(zk + 4));
-        p = quad_allsum(p);
-        if ((t & 3) == 0) S.xcur[(l + 1) * 32 + (t >> 2)] = p + S.xcur[l * 32 + (t >> 2)];
+#pragma unroll
+    for (int k = 0; k < 32; k += 2) {
+        a0 = fmaf(sx[k], f4c(w.g[8 + (k >> 2)], k & 3), a0);
+        a1 = fmaf(sx[k + 1], f4c(w.g[8 + ((k + 1) >> 2)], (k + 1) & 3), a1);
     }
-    lds_barrier();
+    const float acc = a0 + a1;
+    // tanh (lanes 0-31) and sigmoid (lanes 32-63) as one sequence: 1 - 2/(1 + e^{2a})  |  1/(1 + e^{-g})
+    const bool lo = lane < 32;
+    const float r = __frcp_rn(1.0f + __expf(lo ? 2.0f * acc : -acc));
+    const float act = lo ? 1.0f - 2.0f * r : r;
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
+    const float z = __uint_as_float(sw[0]) * __uint_as_float(sw[1]);          // z[lane % 32] in every lane
+    if (lo) S.zall[l * 32 + lane] = z;
+    // residual projection row lane % 32
+    float sz[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) sz[k] = bcast(z, k);
+    float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; k += 2) {
+        p0 = fmaf(sz[k], f4c(w.p[k >> 2], k & 3), p0);
+        p1 = fmaf(sz[k + 1], f4c(w.p[(k + 1) >> 2], (k + 1) & 3), p1);
+    }
+    const float xn = (p0 + p1) + xc;
+    if (lo) S.xcur[(l + 1) * 32 + lane] = xn;
+    // publish: LDS operations of a wave retire in order, so the counter store only has to FOLLOW the z store in the
+    // instruction stream (a compiler-level fence; no s_waitcnt on the chain's critical path)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (lane == 0) __hip_atomic_store(S.ready, l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (l + 1 < nlayers) load_xold(xo, S, l + 1);      // the next layer's x[n-d]: lands behind its 32 broadcasts
+    return xn;
+}
+__device__ __forceinline__ void wait_layer(const FastLds& S, int l) {         // z of layers < l is in zall
+    while (__hip_atomic_load(S.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < l) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // the z reads stay behind the counter read
 }
 
 // skip waves: rows 2t and 2t+1 of Ws_l z_l, accumulated over the layers
@@ -204,6 +246,7 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
     int* s_tok = reinterpret_cast<int*>(cdf + 256);     // [4]: current token, previous token
     int* ringt = s_tok + 4;                             // [L] ring offset per layer
     int* dmask = ringt + kMaxFastLayers;                // [L] d - 1 (d is a power of two: fw = 2)
+    int* ready = dmask + kMaxFastLayers;                // [4] number of layers of this step whose z is in zall
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     for (int i = tid; i < 256 * 2 * 32 / 4; i += kFT)
@@ -212,7 +255,7 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
     const float hb = hbias ? hbias[tid] : 0.f;
     if (tid == 0) { s_tok[0] = first_token; s_tok[1] = tok_ring[0]; }     // fwc = 2: ring depth 1
     __syncthreads();
-    FastLds S{xold, xcur, zall};
+    FastLds S{xold, xcur, zall, ready};
     const unsigned t4 = 4u * (tid & 127);
 #ifdef WN_DECODE_STAMPS
     long long stamps[8];
@@ -229,21 +272,27 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
             xold[i] = arena[ringt[l] + (long long)(n & (unsigned)dmask[l]) * 32 + (i & 31)];
         }
         if (tid < 32) xcur[tid] = Elds[(tprev * 2 + 0) * 32 + tid] + Elds[(token * 2 + 1) * 32 + tid];
-        if (tid < 128) {
+        if (tid == 0) __hip_atomic_store(ready, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (wv == 0) {
             ChainW w[2];
-            load_chain(w[0], P, 0, t4);
+            load_chain(w[0], P, 0, 4u * lane);
             __syncthreads();
             STAMP(1);
+            float xc = xcur[lane & 31];
+            float4 xo[8];
+            load_xold(xo, S, 0);
             for (int l0 = 0; l0 < nlayers; l0 += kUnroll) {
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     const int l = l0 + u;
                     if (l < nlayers) {
-                        if (l + 1 < nlayers) load_chain(w[(u + 1) & 1], P, l + 1, t4);   // in flight during layer l
-                        chain_layer(S, w[u & 1], l, tid);
+                        if (l + 1 < nlayers) load_chain(w[(u + 1) & 1], P, l + 1, 4u * lane);   // in flight during layer l
+                        xc = chain_layer(S, w[u & 1], xo, l, nlayers, lane, xc);
                     }
                 }
             }
+        } else if (wv == 1) {
+            __syncthreads();
         } else {
             float skip0 = 0.f, skip1 = 0.f;
             SkipW w[2];
@@ -253,17 +302,15 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     const int l = l0 + u;
-                    if (l < nlayers) {
-                        // one layer behind the chain: fetch layer l's rows, use layer l-1's (loaded a trip ago)
-                        if (l > 0) {
-                            load_skip(w[u & 1], P, l, t4);
-                            skip_layer(S, w[(u + 1) & 1], l - 1, skip0, skip1);
-                        }
-                        lds_barrier();
-                        lds_barrier();
+                    if (l < nlayers && l > 0) {
+                        // behind the chain: fetch layer l's rows, use layer l-1's (loaded a trip ago) once its z is there
+                        load_skip(w[u & 1], P, l, t4);
+                        wait_layer(S, l);
+                        skip_layer(S, w[(u + 1) & 1], l - 1, skip0, skip1);
                     }
                 }
             }
+            wait_layer(S, nlayers);
             if ((nlayers - 1) & 1) skip_layer(S, w[1], nlayers - 1, skip0, skip1);
             else skip_layer(S, w[0], nlayers - 1, skip0, skip1);
             hvec[2 * (tid - 128)] = act_apply(skip0, head_act);
@@ -281,12 +328,13 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
             for (int j = 0; j < 16; ++j) wa[j] = *reinterpret_cast<const float4*>(Phs + j * 1024 + q4);
 #pragma unroll
             for (int j = 0; j < 16; ++j) wb[j] = *reinterpret_cast<const float4*>(Phs + (16 + j) * 1024 + q4);
+            lds_barrier();                                // the chain has written every x_cur, the skip waves hvec
+                                                          // (LDS only: the weight loads stay in flight)
             // this step's x_cur of every layer becomes the newest ring column
             for (int i = tid; i < nlayers * 32; i += kFT) {
                 const int l = i >> 5;
                 arena[ringt[l] + (long long)(n & (unsigned)dmask[l]) * 32 + (i & 31)] = xcur[i];
             }
-            lds_barrier();                                // hvec complete (LDS only: the weight loads stay in flight)
             float p0 = hb, p1 = 0.f, p2 = 0.f, p3 = 0.f;
 #define HEAD_ACC(W, J0)                                                                                   \
     _Pragma("unroll") for (int j = 0; j < 16; j += 4) {                                                   \
@@ -388,7 +436,7 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
 
 size_t decode_fast_lds_bytes() {
     return (size_t)(256 * 2 * 32 + kMaxFastLayers * 32 + (kMaxFastLayers + 1) * 32 + kMaxFastLayers * 32 + 256 + 256 + 16) * 4 +
-           256 * 8 + (4 + 2 * kMaxFastLayers) * 4;
+           256 * 8 + (4 + 2 * kMaxFastLayers + 4) * 4;
 }
 size_t decode_fast_pack_floats(int nlayers) { return (size_t)nlayers * kLayerFloats + 256 * 256; }
 
