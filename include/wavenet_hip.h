@@ -215,6 +215,12 @@ int wn_sqnorm(const float* grad, const float* param, int64_t n, float grad_mult,
 int wn_adam_step(float* param, const float* grad, float* m, float* v, int64_t n,
                  float lr_t, float beta1, float beta2, float eps, float weight_decay,
                  const float* sqnorm, float clip, float grad_mult, void* stream);
+/* Eve (wavenet.py:10-79, the reference's own optimizer class and its only device code, the elementwise kernel at
+ * 57-65): Adam's moments with the denominator d * sqrt(v) + eps.  d is the loss-feedback scalar the host maintains
+ * (wavenet.py:27-44); hooks as in wn_adam_step.                                                                   */
+int wn_eve_step(float* param, const float* grad, float* m, float* v, int64_t n,
+                float lr_t, float beta1, float beta2, float eps, float d, float weight_decay,
+                const float* sqnorm, float clip, float grad_mult, void* stream);
 /* The same update with the step size read from device memory (*lr_t_dev) at execution time: a training step
  * captured once into a hipGraph is replayed with a fresh bias-corrected step size by writing that scalar.  */
 int wn_adam_step_dev(float* param, const float* grad, float* m, float* v, int64_t n,

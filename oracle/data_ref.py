@@ -55,3 +55,44 @@ def synthetic_waveform(B: int, n: int, sr: int, b0: int = 0, Btot: int | None = 
         out[b] = 0.6 * np.sin(2 * np.pi * 220.0 * t + ph) + 0.3 * np.sin(2 * np.pi * 554.37 * t) \
             + 0.05 * noise[b0 + b]
     return np.clip(out, -1.0, 1.0)
+
+
+# --------------------------------------------------------------------------
+# wav side of the path (data.py:5-58), restated on arrays: literal loops, Python-2 semantics spelled out
+# --------------------------------------------------------------------------
+
+def load_audio_ref(signal: np.ndarray, quantization_steps: int = 256, fmt: str = "16bit_pcm",
+                   py2_mono_int_division: bool = False) -> np.ndarray:
+    """What data.py:5-35 does to the array wavfile.read returned (TEST INFRASTRUCTURE ONLY)."""
+    if len(signal.shape) > 1:
+        signal = signal[:, 0].astype(float)                       # data.py:7-9
+    mx = {"16bit_pcm": 1 << 15, "32bit_pcm": 1 << 31, "8bit_pcm": 1 << 8 - 1}[fmt]   # data.py:11-16 (1<<7 for 8 bit)
+    if np.issubdtype(signal.dtype, np.integer):
+        # data.py:17 on an integer array: Python 2 `/=` is floor division; the sane reading converts first
+        signal = (signal.astype(np.int64) // mx).astype(float) if py2_mono_int_division else signal.astype(float) / mx
+    else:
+        signal = signal / mx
+    q = mulaw_quantize(signal, quantization_steps)                # data.py:18-23
+    start = 0
+    for start in range(q.size):                                   # data.py:27-29
+        if abs(int(q[start]) - 127) > 1:
+            break
+    end = None
+    for end in range(1, q.size):                                  # data.py:30-32
+        if abs(int(q[-end]) - 127) > 1:
+            break
+    if end is None:
+        end = 1
+    return q[start:-end]                                          # data.py:33
+
+
+def save_audio_ref(quantized_signal: np.ndarray, quantization_steps: int = 256, fmt: str = "16bit_pcm") -> np.ndarray:
+    """The (N, 2) integer array data.py:37-58 hands to wavfile.write (TEST INFRASTRUCTURE ONLY)."""
+    q = quantized_signal.astype(float)
+    normalized = (q / quantization_steps - 0.5) * 2.0             # data.py:39
+    mu = quantization_steps - 1
+    s = np.sign(normalized) * ((1 + mu) ** np.absolute(normalized)) / mu      # data.py:43
+    mx, ty = {"16bit_pcm": (1 << 15, np.int16), "32bit_pcm": (1 << 31, np.int32), "8bit_pcm": (1 << 8 - 1, np.uint8)}[fmt]
+    s = s * mx
+    audio = s.reshape((-1, 1)).astype(ty)
+    return np.repeat(audio, 2, axis=1)                            # data.py:56-57

@@ -477,3 +477,55 @@ def generate(p, weights, n_emit: int, uniforms: np.ndarray, fast: bool, fast_hea
             trace.append(prob.copy())
         buf = np.append(buf, [choice_from_uniform(prob, uniforms[step])]).astype(np.int32)
     return buf[iw:]
+
+
+# --------------------------------------------------------------------------
+# Eve (wavenet.py:10-79), restated literally: one state per parameter array, float32 d / f arrays
+# --------------------------------------------------------------------------
+
+class EveRef(object):
+    """TEST INFRASTRUCTURE ONLY.  ``update(params, grads, loss)`` performs what Eve.update does to every parameter
+    (wavenet.py:46-53: _update_d_and_f then the moment / parameter update), hooks excluded."""
+
+    def __init__(self, alpha=0.001, beta1=0.9, beta2=0.999, beta3=0.999, eps=1e-8, lower_threshold=0.1,
+                 upper_threshold=10):
+        self.alpha, self.beta1, self.beta2, self.beta3, self.eps = alpha, beta1, beta2, beta3, eps
+        self.lower_threshold, self.upper_threshold = lower_threshold, upper_threshold
+        self.t = 0
+        self.states = {}
+
+    @property
+    def lr(self):                                                   # wavenet.py:67-71
+        fix1 = 1. - self.beta1 ** self.t
+        fix2 = 1. - self.beta2 ** self.t
+        return self.alpha * math.sqrt(fix2) / fix1
+
+    def _update_d_and_f(self, state, loss):                         # wavenet.py:27-44
+        d, f = state["d"], state["f"]
+        if self.t > 1:
+            old_f = float(f[0])
+            if loss > old_f:
+                delta = self.lower_threshold + 1.
+                Delta = self.upper_threshold + 1.
+            else:
+                delta = 1. / (self.upper_threshold + 1.)
+                Delta = 1. / (self.lower_threshold + 1.)
+            c = min(max(delta, loss / (old_f + 1e-12)), Delta)
+            new_f = c * old_f
+            r = abs(new_f - old_f) / (min(new_f, old_f) + 1e-12)
+            d += (1 - self.beta3) * (r - d)
+            f[:] = new_f
+        else:
+            f[:] = loss
+
+    def update(self, params, grads, loss):
+        self.t += 1
+        for k in params:
+            if k not in self.states:                                # init_state, wavenet.py:20-26
+                self.states[k] = dict(m=np.zeros_like(params[k]), v=np.zeros_like(params[k]),
+                                      d=np.ones(1, dtype=params[k].dtype), f=np.zeros(1, dtype=params[k].dtype))
+            st = self.states[k]
+            self._update_d_and_f(st, loss)
+            st["m"] += (1. - self.beta1) * (grads[k] - st["m"])
+            st["v"] += (1. - self.beta2) * (grads[k] * grads[k] - st["v"])
+            params[k] -= self.lr * st["m"] / (st["d"] * np.sqrt(st["v"]) + self.eps)

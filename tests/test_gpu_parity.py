@@ -366,6 +366,46 @@ def test_adam_step_matches_chainer_rule():
         np.testing.assert_allclose(to_np(net._arena), P, atol=2e-6)
 
 
+def test_eve_step_matches_the_reference_class():
+    """optimizer = "eve": wn_eve_step + the host's loss-feedback scalars vs the literal restatement of wavenet.py:10-79."""
+    p, w, net = build(CFG1, gradient_clipping=0.0)
+    net.params.optimizer = "eve"
+    net.setup_optimizer()
+    net.optimizer.to(net.device)
+    net.update_laerning_rate(0.002)
+    ref = R.EveRef(alpha=0.002, beta1=net.optimizer.beta1)
+    P = {"a": to_np(net._arena).copy()}
+    rs = np.random.RandomState(3)
+    for L in [3.0, 2.7, 2.9, 1.1, 1.0]:
+        g = (rs.standard_normal(P["a"].shape) * 0.01).astype(np.float32)
+        net._grad_arena.copy_(dev(g))
+        net.optimizer.update(1.0, loss=L)
+        ref.update(P, {"a": g}, L)
+        assert abs(net.optimizer.d - float(ref.states["a"]["d"][0])) == 0
+        np.testing.assert_allclose(to_np(net._arena), P["a"], atol=2e-6)
+    assert net.optimizer.d != 1.0
+
+
+def test_backprop_with_eve_learns_the_toy_staircase():
+    p, w, net = build(dict(quantization_steps=10, causal_conv_channels=[32], residual_conv_channels=[16, 16],
+                           residual_num_blocks=1, softmax_conv_channels=[32, 10]))
+    net.params.optimizer = "eve"
+    net.setup_optimizer()
+    net.optimizer.to(net.device)
+    net.update_laerning_rate(0.01)
+    sig = np.tile(np.arange(10), 40).astype(np.int32)
+    x, t = sig[None, :-1], sig[None, 1:]
+    first = last = None
+    for it in range(60):
+        c = net.forward_causal_block(x)
+        _, s = net.forward_residual_block(c)
+        loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), t)
+        net.backprop(loss)
+        last = float(loss.detach())
+        first = last if first is None else first
+    assert last < 0.5 * first
+
+
 def test_backprop_reduces_loss_on_toy_staircase():
     """KAT-8: the _tests_/training staircase (Q=10) is learnable: forward + backward + Adam."""
     p, w, net = build(dict(quantization_steps=10, causal_conv_channels=[32], residual_conv_channels=[16, 16],

@@ -122,3 +122,30 @@ def test_data_formats_match_oracle():
     xo, to = D.create_batch(sig, starts, 17, 20)
     np.testing.assert_array_equal(x, xo)
     np.testing.assert_array_equal(t, to)
+
+
+def test_eve_loss_feedback_scalars_follow_the_reference_recurrence():
+    """EveState keeps ONE (d, f) pair on the host; the reference keeps one float32 pair per parameter, all updated with the
+    same loss at the same t (wavenet.py:27-44).  Same numbers, step for step, including the clamps in both directions."""
+    from oracle import wavenet_ref as R
+    from wavenet_amd import Params, WaveNet
+    from wavenet_amd.wavenet import EveState
+    p = Params(dict(quantization_steps=16, causal_conv_channels=[4], residual_conv_channels=[4, 4], residual_num_blocks=1,
+                    softmax_conv_channels=[8, 16], optimizer="eve"))
+    net = WaveNet(p)
+    assert isinstance(net.optimizer, EveState)
+    ref = R.EveRef()
+    prm = {"w": np.zeros(3, np.float32)}
+    losses = [2.5, 2.4, 2.45, 30.0, 0.01, 0.0101, 5.0, 5.0, 4.0, 1e-9]
+    for L in losses:
+        net.optimizer.t += 1
+        net.optimizer._update_d_and_f(L)
+        ref.update(prm, {"w": np.zeros(3, np.float32)}, L)
+        assert net.optimizer.t == ref.t
+        assert net.optimizer.f == float(ref.states["w"]["f"][0])
+        assert net.optimizer.d == float(ref.states["w"]["d"][0])
+    with pytest.raises(RuntimeError):
+        net.optimizer.update(1.0)                                   # Eve.update requires the loss (wavenet.py:75-76)
+    with pytest.raises(NotImplementedError):
+        WaveNet(Params(dict(quantization_steps=16, causal_conv_channels=[4], residual_conv_channels=[4], residual_num_blocks=1,
+                            softmax_conv_channels=[8, 16], optimizer="adagrad")))

@@ -236,7 +236,17 @@ int wn_adam_step(float* param, const float* grad, float* m, float* v, int64_t n,
     NN(param); NN(grad); NN(m); NN(v);
     WN_CHECK_ARG(n > 0, "wn_adam_step: n <= 0");
     return generic_adam(param, grad, m, v, n, lr_t, beta1, beta2, eps, weight_decay, sqnorm, clip, grad_mult,
-                        nullptr, as_stream(stream));
+                        nullptr, 1.f, as_stream(stream));
+}
+
+int wn_eve_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2,
+                float eps, float d, float weight_decay, const float* sqnorm, float clip, float grad_mult,
+                void* stream) {
+    wn::ProfScope prof__("wn_adam_step", stream);
+    NN(param); NN(grad); NN(m); NN(v);
+    WN_CHECK_ARG(n > 0 && d > 0.f, "wn_eve_step: n <= 0 or d <= 0");
+    return generic_adam(param, grad, m, v, n, lr_t, beta1, beta2, eps, weight_decay, sqnorm, clip, grad_mult,
+                        nullptr, d, as_stream(stream));
 }
 
 int wn_adam_step_dev(float* param, const float* grad, float* m, float* v, int64_t n, const float* lr_t_dev,
@@ -246,7 +256,7 @@ int wn_adam_step_dev(float* param, const float* grad, float* m, float* v, int64_
     NN(param); NN(grad); NN(m); NN(v); NN(lr_t_dev);
     WN_CHECK_ARG(n > 0, "wn_adam_step_dev: n <= 0");
     return generic_adam(param, grad, m, v, n, 0.f, beta1, beta2, eps, weight_decay, sqnorm, clip, grad_mult,
-                        lr_t_dev, as_stream(stream));
+                        lr_t_dev, 1.f, as_stream(stream));
 }
 
 }  // extern "C"

@@ -623,7 +623,7 @@ __global__ void k_sqnorm(const float* __restrict__ g, const float* __restrict__ 
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                        float* __restrict__ v, long long n, float lr_t, float b1, float b2, float eps,
                        float wd, const float* __restrict__ sqnorm, float clip, float gmult,
-                       const float* __restrict__ lr_dev) {
+                       const float* __restrict__ lr_dev, float dscale) {
     // hook order of wavenet.py:477-480: WeightDecay first, then GradientClipping on the result
     if (lr_dev) lr_t = *lr_dev;          // captured-graph replays: the step size comes from device memory
     float rate = 1.f;
@@ -642,7 +642,7 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
         vi += (1.f - b2) * (gi * gi - vi);
         m[i] = mi;
         v[i] = vi;
-        p[i] = pi - lr_t * mi / (sqrtf(vi) + eps);
+        p[i] = pi - lr_t * mi / (dscale * sqrtf(vi) + eps);      // dscale = 1: Adam; Eve's d otherwise (wavenet.py:57-65)
     }
 }
 
@@ -938,12 +938,12 @@ int generic_sqnorm(const float* g, const float* p, long long n, float gmult, flo
 
 int generic_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2,
                  float eps, float wd, const float* sqnorm, float clip, float gmult, const float* lr_dev,
-                 hipStream_t s) {
+                 float dscale, hipStream_t s) {
     int blocks = (int)((n + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps, wd, sqnorm, clip,
-                       gmult, lr_dev);
+                       gmult, lr_dev, dscale);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

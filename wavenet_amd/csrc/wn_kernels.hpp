@@ -37,7 +37,7 @@ int generic_sample(const float*, const double*, int32_t*, int, int, hipStream_t)
 int generic_sqnorm(const float* g, const float* p, long long n, float gmult, float wd, float* out, hipStream_t s);
 int generic_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2,
                  float eps, float wd, const float* sqnorm, float clip, float gmult, const float* lr_dev,
-                 hipStream_t s);
+                 float dscale, hipStream_t s);
 
 // ---- mfma_layer.hip: fp32-MFMA fused residual layer, Cr = Cd = 32, fw = 2 -------------------
 bool mfma_layer_supported(int Cr, int Cd, int fw);

@@ -1,6 +1,15 @@
-"""Boundary data formats of the hot path (data.py of the reference): mu-law tokens and the
-one-hot "1 x W image".  Host-side numpy; file I/O (wav load/save, silence trimming) is out of scope
-for this round."""
+"""Boundary data formats of the hot path (data.py of the reference): mu-law tokens, the one-hot
+"1 x W image", and the wav files either side of them (load + silence trim, inverse mu-law + save;
+SURVEY.md section 8f rank 2).  Host-side numpy / scipy.io.wavfile, as in the reference.
+
+The reference's accidents are reproduced on purpose where a file written or read by it must match, and
+can be switched off (``compat=False``):
+  * 8-bit PCM scale ``1<<8 - 1`` == 128 (data.py:16,52; operator precedence);
+  * the inverse mu-law of save_audio_file lacks the ``- 1`` and divides the token by Q, not mu (data.py:39,43);
+  * the silence trim drops the last non-silent sample as well (``[start:-end]``, data.py:27-33);
+  * mono files: ``signal /= max`` on the integer array is Python-2 floor division (data.py:7-9,17: only the
+    stereo branch converts to float) -- every sample becomes -1 or 0.  Off by default here
+    (``compat_mono_int_division``): it destroys the audio."""
 from __future__ import annotations
 
 import numpy as np
@@ -25,6 +34,79 @@ def mulaw_encode_pcm16(pcm, quantization_steps: int = 256) -> np.ndarray:
         lut = mulaw_encode(np.arange(-32768, 32768, dtype=np.float64) / 32768.0, quantization_steps)
         _LUT16[quantization_steps] = lut
     return lut[np.asarray(pcm).astype(np.int64) + 32768]
+
+
+_PCM = {"16bit_pcm": (1 << 15, np.int16), "32bit_pcm": (1 << 31, np.int32), "8bit_pcm": (1 << 7, np.uint8)}
+
+
+def _pcm_format(fmt: str, compat: bool):
+    if fmt not in _PCM:
+        raise Exception("unknown PCM format: %s" % fmt)
+    scale, dtype = _PCM[fmt]
+    if fmt == "8bit_pcm" and not compat:
+        scale = (1 << 8) - 1
+    return scale, dtype
+
+
+def trim_silence(quantized_signal, silence_threshold: int = 1, compat: bool = True) -> np.ndarray:
+    """Strip leading / trailing tokens within ``silence_threshold`` of 127 (data.py:25-33).  With ``compat`` the
+    slice is the reference's ``[start:-end]``, which also drops the last non-silent sample."""
+    q = np.asarray(quantized_signal)
+    loud = np.nonzero(np.abs(q.astype(np.int64) - 127) > silence_threshold)[0]
+    if q.size == 0:
+        return q
+    # the reference's loops leave start = size-1 (no break) / end = size-1 when nothing is loud
+    start = int(loud[0]) if loud.size else q.size - 1
+    if q.size == 1:
+        end = 1                                        # xrange(1, 1) is empty: `end` would be unbound in the reference
+    else:
+        tail = np.nonzero(np.abs(q[:0:-1].astype(np.int64) - 127) > silence_threshold)[0]   # q[-1], q[-2], ... q[1]
+        end = int(tail[0]) + 1 if tail.size else q.size - 1
+    if compat:
+        return q[start:-end]
+    return q[start:q.size - end + 1]
+
+
+def load_audio_file(filename, quantization_steps: int = 256, format: str = "16bit_pcm", compat: bool = True,
+                    compat_mono_int_division: bool = False):
+    """wav file -> (mu-law tokens int32 with silence trimmed, sampling rate)   (data.py:5-35)."""
+    from scipy.io import wavfile
+    sampling_rate, signal = wavfile.read(filename)
+    scale, _ = _pcm_format(format, compat)
+    if signal.ndim > 1:
+        signal = signal[:, 0].astype(float)            # left channel only
+        signal = signal / scale
+    elif compat_mono_int_division and np.issubdtype(signal.dtype, np.integer):
+        signal = np.floor_divide(signal.astype(np.int64), scale).astype(float)
+    else:
+        signal = signal.astype(float) / scale
+    return trim_silence(mulaw_encode(signal, quantization_steps), 1, compat), sampling_rate
+
+
+def mulaw_decode(quantized_signal, quantization_steps: int = 256, compat: bool = True) -> np.ndarray:
+    """tokens -> float signal.  ``compat``: the reference's formula (data.py:37-43)
+    ``x = (q / Q - 0.5) * 2;  s = sign(x) (1 + mu)^|x| / mu``; otherwise the textbook inverse of
+    :func:`mulaw_encode`, ``x = 2 (q + 0.5) / mu - 1;  s = sign(x) ((1 + mu)^|x| - 1) / mu``."""
+    mu = quantization_steps - 1
+    q = np.asarray(quantized_signal).astype(float)
+    if compat:
+        x = (q / quantization_steps - 0.5) * 2.0
+        return np.sign(x) * ((1 + mu) ** np.absolute(x)) / mu
+    x = 2.0 * (q + 0.5) / mu - 1.0
+    return np.sign(x) * ((1 + mu) ** np.absolute(x) - 1.0) / mu
+
+
+def save_audio_file(filename, quantized_signal, quantization_steps: int = 256, format: str = "16bit_pcm",
+                    sampling_rate: int = 48000, compat: bool = True):
+    """tokens -> wav file (data.py:37-58): inverse mu-law, PCM scale, the mono signal duplicated into two channels."""
+    from scipy.io import wavfile
+    scale, dtype = _pcm_format(format, compat)
+    s = mulaw_decode(quantized_signal, quantization_steps, compat) * scale
+    if not compat:
+        info = np.iinfo(dtype)
+        s = np.clip(s, info.min, info.max)
+    audio = np.repeat(s.reshape((-1, 1)).astype(dtype), 2, axis=1)
+    wavfile.write(filename, sampling_rate, audio)
 
 
 def onehot_pixel_image(quantized_signal_batch, quantization_steps: int = 256) -> np.ndarray:

@@ -559,9 +559,14 @@ class WaveNet(object):
     # -- optimiser (wavenet.py:457-519) ---------------------------------------------------------
     def setup_optimizer(self):
         p = self.params
-        if p.optimizer != "adam":
-            raise NotImplementedError("only the reference's default optimizer 'adam' is built (got %r)" % p.optimizer)
-        self.optimizer = AdamState(self, alpha=0.0001, beta1=p.momentum)     # wavenet.py:475
+        name = str(p.optimizer).lower()
+        if name == "adam":
+            self.optimizer = AdamState(self, alpha=0.0001, beta1=p.momentum)     # wavenet.py:475, get_optimizer 81-84
+        elif name == "eve":
+            self.optimizer = EveState(self, alpha=0.0001, beta1=p.momentum)      # wavenet.py:85-86
+        else:
+            raise NotImplementedError("optimizers built: 'adam' (the reference's default) and 'eve' (its own class); "
+                                      "got %r" % p.optimizer)
 
     def update_laerning_rate(self, lr):
         self.optimizer.alpha = lr
@@ -581,7 +586,10 @@ class WaveNet(object):
         gmult = 1.0
         if self._dp_group is not None:
             gmult = self._dp_group.all_reduce_grads(self._grad_arena)
-        self.optimizer.update(gmult)
+        if isinstance(self.optimizer, EveState):
+            self.optimizer.update(gmult, loss=float(loss.detach()))      # Eve feeds the loss back (wavenet.py:73-79)
+        else:
+            self.optimizer.update(gmult)
         self._weights_changed()
 
     # -- device --------------------------------------------------------------------------------
@@ -784,8 +792,75 @@ class AdamState(object):
         return {"t": np.array(self.t), "alpha": np.array(self.alpha), "m": self.m.cpu().numpy(),
                 "v": self.v.cpu().numpy()}
 
+    def _hooks(self, grad_mult):
+        """WeightDecay then GradientClipping (wavenet.py:477-480): returns (norm pointer or None, clip, wd)."""
+        net = self.net
+        p = net.params
+        clip = float(p.gradient_clipping) if p.gradient_clipping and p.gradient_clipping > 0 else 0.0
+        wd = float(p.weight_decay) if p.weight_decay and p.weight_decay > 0 else 0.0
+        norm_ptr = None
+        if clip > 0:
+            self._norm.zero_()
+            check(_lib.lib().wn_sqnorm(ptr(net._grad_arena), ptr(net._arena), net._arena.numel(), grad_mult, wd,
+                                       ptr(self._norm), stream_ptr()), "wn_sqnorm")
+            norm_ptr = ptr(self._norm)
+        return norm_ptr, clip, wd
+
     def load_state_dict(self, sd):
         self.t = int(sd["t"])
         self.alpha = float(sd["alpha"])
         self.m.copy_(torch.from_numpy(np.asarray(sd["m"])))
         self.v.copy_(torch.from_numpy(np.asarray(sd["v"])))
+
+
+class EveState(AdamState):
+    """The reference's Eve optimizer (wavenet.py:10-79; Koushik & Hayashi 2016) on the flat arena: Adam's moments, the
+    update divided by ``d * sqrt(v) + eps`` where the scalar ``d`` tracks the relative change of the (clamped) loss.
+    Every parameter of the reference carries its own copy of (d, f) and updates it with the same loss at the same t
+    (wavenet.py:27-44 is called per parameter), so they are one pair of host scalars here."""
+
+    def __init__(self, net, alpha=0.001, beta1=0.9, beta2=0.999, beta3=0.999, eps=1e-8, lower_threshold=0.1,
+                 upper_threshold=10):
+        super().__init__(net, alpha, beta1, beta2, eps)
+        self.beta3, self.lower_threshold, self.upper_threshold = beta3, lower_threshold, upper_threshold
+        self.d, self.f = 1.0, 0.0                                    # wavenet.py:25-26
+
+    def _update_d_and_f(self, loss: float):
+        d32, f32 = np.float32(self.d), np.float32(self.f)            # the reference keeps both in float32 arrays
+        if self.t > 1:
+            old_f = float(f32)
+            if loss > old_f:
+                delta, Delta = self.lower_threshold + 1.0, self.upper_threshold + 1.0
+            else:
+                delta, Delta = 1.0 / (self.upper_threshold + 1.0), 1.0 / (self.lower_threshold + 1.0)
+            c = min(max(delta, loss / (old_f + 1e-12)), Delta)
+            new_f = c * old_f
+            r = abs(new_f - old_f) / (min(new_f, old_f) + 1e-12)
+            d32 = np.float32(d32 + np.float32((1 - self.beta3) * (r - float(d32))))
+            f32 = np.float32(new_f)
+        else:
+            f32 = np.float32(loss)
+        self.d, self.f = float(d32), float(f32)
+
+    def update(self, grad_mult: float = 1.0, loss=None, lr_dev=None):
+        if loss is None:
+            raise RuntimeError("Eve.update requires the loss value")            # wavenet.py:75-76
+        if lr_dev is not None:
+            raise RuntimeError("Eve needs the loss on the host every step: it cannot run inside a replayed graph")
+        net = self.net
+        _need_gpu(net._arena)
+        self.t += 1
+        self._update_d_and_f(float(loss))
+        norm_ptr, clip, wd = self._hooks(grad_mult)
+        check(_lib.lib().wn_eve_step(ptr(net._arena), ptr(net._grad_arena), ptr(self.m), ptr(self.v), net._arena.numel(),
+                                     self.lr, self.beta1, self.beta2, self.eps, self.d, wd, norm_ptr, clip, grad_mult,
+                                     stream_ptr()), "wn_eve_step")
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd.update(d=np.array(self.d), f=np.array(self.f))
+        return sd
+
+    def load_state_dict(self, sd):
+        super().load_state_dict(sd)
+        self.d, self.f = float(sd["d"]), float(sd["f"])
