@@ -236,6 +236,8 @@ def main():
             "algorithmic_GBps": nl * alg_bytes_layer / (stack_ms * 1e-3) / 1e9,
             "frac_of_hbm_8TBps": nl * alg_bytes_layer / (stack_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "TFLOPs": nl * alg_flops_layer / (stack_ms * 1e-3) / 1e12,
+            "note": "algorithmic bytes = SURVEY 8(d)'s 2,304 B per sample-layer, which include the per-layer skip "
+                    "read-modify-write; the deferred skip sum does not move those bytes, so the fraction can exceed 1",
         }
         # ---- roofline of the dominant unit of the TIMED REGION (the training step) -------------------
         # Units = the library's per-op entry points; times are HIP-event means over the timed steps.
