@@ -93,6 +93,20 @@ def test_layer_fwd_mfma(d, B, T, bias, save):
         np.testing.assert_allclose(to_np(g), btc(g_), atol=ATOL)
 
 
+def test_layer_fwd_one_tile_per_wave_kernel_is_covered():
+    """k_layer_fwd_mfma32_t1 (4 waves per SIMD, one tile per wave) is what config-2 sized launches use; at test sizes the
+    dispatcher picks the looping kernel.  Run the forward / training parity tests of this file again in a child process
+    with the threshold forced to 1 so that every 32/32/2 layer launch goes through it."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WAVENET_HIP_FWD_T1_MIN_BLOCKS="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "layer_fwd_mfma or operand_maps or cfg2_topology or train_step_grads_general or live_columns or "
+                        "tiny_and_ragged or causality"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_mfma_operand_maps_with_integer_data():
     """Exact-integer check of the MFMA lane maps: asymmetric weights, every channel distinct."""
     Cr = Cd = 32

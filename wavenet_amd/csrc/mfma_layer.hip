@@ -17,6 +17,8 @@
 // layout W[o][c][k] (tap pairs are adjacent, so two float4 give both taps of four channels).
 //
 // Per tile: 64 + 16 MFMAs (5120 SIMD cycles); 2 KB + 2 KB of x read, 4 KB out + 4 KB z written.
+#include <cstdlib>
+
 #include "wn_kernels.hpp"
 
 namespace wn {
@@ -181,6 +183,125 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One tile per wave, four waves per SIMD.  Same maths and data layout as k_layer_fwd_mfma32; what changes is the
+// occupancy: the A operands are read from LDS at each MFMA instead of living in 80 registers, so a wave fits in 128
+// registers, 16 waves share a CU, and a wave's load latency, gate arithmetic and stores run under the MFMAs of three
+// others instead of under one sibling's.  No tile loop, no prefetch, no tile-count quantisation: a workgroup is four
+// consecutive tiles.
+// ---------------------------------------------------------------------------------------------
+template <bool SAVE_FG, bool HAS_BIAS>
+__global__ __launch_bounds__(256, 4) void k_layer_fwd_mfma32_t1(
+    const float* __restrict__ x, const float* __restrict__ Wf, const float* __restrict__ bf,
+    const float* __restrict__ Wg, const float* __restrict__ bg, const float* __restrict__ Wp,
+    const float* __restrict__ bp, float* __restrict__ out, float* __restrict__ zout,
+    float* __restrict__ fout, float* __restrict__ gout, int B, int T, int d, int Z, int tiles_per_b,
+    int ntiles) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD k = blockIdx % 8 gets the k-th contiguous eighth of the workgroups (see k_layer_fwd_mfma32)
+    int wg = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int tile = wg * 4 + wv;
+    const bool tvalid = tile < ntiles;
+    const int tl = tvalid ? tile : ntiles - 1;
+    const int b = tl / tiles_per_b;
+    const int t = (tl - b * tiles_per_b) * 32 + j;
+    const bool valid = tvalid && t < T;
+    const int tc = t < T ? t : T - 1;
+
+    __shared__ __attribute__((aligned(16))) float wlds[2 * 32 * kWRow + 32 * kPRow];
+    float4 sa[2], sc[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        sa[k] = *reinterpret_cast<const float4*>(Wf + (threadIdx.x + 256 * k) * 4);
+        sc[k] = *reinterpret_cast<const float4*>(Wg + (threadIdx.x + 256 * k) * 4);
+    }
+    const float4 sp = *reinterpret_cast<const float4*>(Wp + threadIdx.x * 4);
+    // this tile's columns: unconditional loads from clamped rows, masked afterwards
+    float xc[16], xo[16];
+    {
+        const long long rowc = ((long long)b * T + tc) * 32 + 4 * h;
+        const long long rowo = ((long long)b * T + (tc - d >= 0 ? tc - d : 0)) * 32 + 4 * h;
+        const float mc = valid ? 1.f : 0.f, mo = (valid && t - d >= 0) ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(x + rowc + 8 * q);
+            const float4 o = *reinterpret_cast<const float4*>(x + rowo + 8 * q);
+            xc[4 * q + 0] = v.x * mc; xc[4 * q + 1] = v.y * mc; xc[4 * q + 2] = v.z * mc; xc[4 * q + 3] = v.w * mc;
+            xo[4 * q + 0] = o.x * mo; xo[4 * q + 1] = o.y * mo; xo[4 * q + 2] = o.z * mo; xo[4 * q + 3] = o.w * mo;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = (threadIdx.x + 256 * k) * 4;
+        float* lf = wlds + (e >> 6) * kWRow + (e & 63);
+        float* lg = lf + 32 * kWRow;
+        *reinterpret_cast<float2*>(lf) = make_float2(sa[k].x, sa[k].y);
+        *reinterpret_cast<float2*>(lf + 2) = make_float2(sa[k].z, sa[k].w);
+        *reinterpret_cast<float2*>(lg) = make_float2(sc[k].x, sc[k].y);
+        *reinterpret_cast<float2*>(lg + 2) = make_float2(sc[k].z, sc[k].w);
+    }
+    {
+        const int e = threadIdx.x * 4;
+        float* lp = wlds + 2 * 32 * kWRow + (e >> 5) * kPRow + (e & 31);
+        lp[0] = sp.x; lp[1] = sp.y; lp[2] = sp.z; lp[3] = sp.w;
+    }
+    __syncthreads();
+
+    f32x16 aa, ag;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        aa[r] = (HAS_BIAS && bf) ? bf[ch_of(r, h)] : 0.f;
+        ag[r] = (HAS_BIAS && bg) ? bg[ch_of(r, h)] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        // W[i = j][c = ch(s,h)][k = 0,1]: one 8-byte LDS read gives both taps
+        const float* pf = wlds + j * kWRow + 16 * (s >> 2) + 8 * h + 2 * (s & 3);
+        const float2 a = *reinterpret_cast<const float2*>(pf);
+        const float2 c = *reinterpret_cast<const float2*>(pf + 32 * kWRow);
+        aa = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, xo[s], aa, 0, 0, 0);
+        ag = __builtin_amdgcn_mfma_f32_32x32x2f32(c.x, xo[s], ag, 0, 0, 0);
+        aa = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, xc[s], aa, 0, 0, 0);
+        ag = __builtin_amdgcn_mfma_f32_32x32x2f32(c.y, xc[s], ag, 0, 0, 0);
+    }
+    const bool live = t >= Z;
+    const long long row = ((long long)b * T + t) * 32 + 4 * h;
+    float zz[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float f4[4], g4[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int r = 4 * q + m;
+            f4[m] = fast_tanh(live ? aa[r] : 0.f);
+            g4[m] = fast_sigmoid(live ? ag[r] : 0.f);
+            zz[r] = f4[m] * g4[m];
+        }
+        if (valid) {                                 // f, g and z leave as soon as they exist: registers stay under 128
+            if (SAVE_FG) {
+                *reinterpret_cast<float4*>(fout + row + 8 * q) = make_float4(f4[0], f4[1], f4[2], f4[3]);
+                *reinterpret_cast<float4*>(gout + row + 8 * q) = make_float4(g4[0], g4[1], g4[2], g4[3]);
+            }
+            *reinterpret_cast<float4*>(zout + row + 8 * q) = make_float4(zz[4 * q], zz[4 * q + 1], zz[4 * q + 2], zz[4 * q + 3]);
+        }
+    }
+    f32x16 ao;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ao[r] = xc[r] + ((HAS_BIAS && bp) ? bp[ch_of(r, h)] : 0.f);
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+        ao = __builtin_amdgcn_mfma_f32_32x32x2f32(wlds[2 * 32 * kWRow + j * kPRow + ch_of(s, h)], zz[s], ao, 0, 0, 0);
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(out + row + 8 * q) = make_float4(ao[4 * q], ao[4 * q + 1], ao[4 * q + 2], ao[4 * q + 3]);
+    }
+}
+
 bool mfma_layer_supported(int Cr, int Cd, int fw) { return Cr == 32 && Cd == 32 && fw == 2; }
 
 int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg,
@@ -191,8 +312,23 @@ int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float
     WN_CHECK_SHAPE(nt < (1ll << 31), "mfma_layer_fwd: too many tiles");
     const int ntiles = (int)nt;
     int blocks = (ntiles + 3) / 4;
-    if (blocks > 512) blocks = 512;          // 256 CUs x 2 resident workgroups; waves stride over tiles
     const bool hb = bf || bg || bp;
+    // enough workgroups to give every CU its four (16 waves): one tile per wave; otherwise the looping kernel.
+    // WAVENET_HIP_FWD_T1_MIN_BLOCKS overrides the threshold (1 = always, used by the parity tests; 0 = never).
+    static const int t1_min = getenv("WAVENET_HIP_FWD_T1_MIN_BLOCKS") ? atoi(getenv("WAVENET_HIP_FWD_T1_MIN_BLOCKS")) : 1024;
+    if (t1_min > 0 && blocks >= t1_min) {
+#define FWD1_LAUNCH(SAVE, BIAS)                                                                              \
+    hipLaunchKernelGGL((k_layer_fwd_mfma32_t1<SAVE, BIAS>), dim3(blocks), dim3(256), 0, s, x, Wf, bf, Wg, bg, Wp, bp, \
+                       out, z, fs, gs, B, T, d, Z, tiles_per_b, ntiles)
+        if (fs && hb) FWD1_LAUNCH(true, true);
+        else if (fs) FWD1_LAUNCH(true, false);
+        else if (hb) FWD1_LAUNCH(false, true);
+        else FWD1_LAUNCH(false, false);
+#undef FWD1_LAUNCH
+        WN_LAUNCH_CHECK();
+        return WN_OK;
+    }
+    if (blocks > 512) blocks = 512;          // 256 CUs x 2 resident workgroups; waves stride over tiles
 #define FWD_LAUNCH(SAVE, BIAS)                                                                               \
     hipLaunchKernelGGL((k_layer_fwd_mfma32<SAVE, BIAS>), dim3(blocks), dim3(256), 0, s, x, Wf, bf, Wg, bg, Wp, bp, \
                        out, z, fs, gs, B, T, d, Z, tiles_per_b, ntiles)
