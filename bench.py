@@ -45,7 +45,9 @@ def make_batch(rank, world, iw):
 
 def train_step(net, x, tgt, iw):
     c = net.forward_causal_block(x)
-    _, s = net.forward_residual_block(c, t_off=iw)            # skip sum for the columns train.py:73 keeps
+    # skip sum for the columns train.py:73 keeps; the residual output is discarded (train.py:72), so only what that
+    # window depends on is computed
+    _, s = net.forward_residual_block(c, t_off=iw, window_only=True)
     logits = net.forward_softmax_block(s, apply_softmax=False)
     loss = net.cross_entropy(logits, tgt)
     net.backprop(loss)

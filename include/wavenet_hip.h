@@ -134,9 +134,13 @@ typedef struct WnStackDesc {
 } WnStackDesc;
 /* xs (n_layers,B,T,Cr) receives every layer's output (xs[n_layers-1] is the stack output); z, f, g
  * are layer-major (layer l at offset sum_{i<l} B*T*cd[i]); f/g NULL for inference; skip (B,T-t_off,Cs)
- * may be NULL.  The zero prefix is derived from T per layer when compat_zero_prefix != 0.         */
+ * may be NULL.  The zero prefix is derived from T per layer when compat_zero_prefix != 0.
+ * window_only != 0 (training, train_audio/train.py:72-73 keeps skip[t_off:] only and discards the residual
+ * output): columns that cannot influence skip[t_off:] -- further below t_off than the layers above a layer
+ * reach -- are not computed; xs / z / f / g are left untouched there and wn_stack_bwd must then be called
+ * with dout == NULL.  Loss and gradients are unchanged.                                              */
 int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, float* f, float* g,
-                 float* skip, int B, int T, int t_off, int compat_zero_prefix, void* stream);
+                 float* skip, int B, int T, int t_off, int compat_zero_prefix, int window_only, void* stream);
 size_t wn_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T);
 /* dout: gradient of the last layer's output (NULL = unused, train_audio/train.py:72); dskip
  * (B,T-t_off,Cs): gradient of the skip sum (NULL = unused); dx (B,T,Cr) may be NULL.  Gradient

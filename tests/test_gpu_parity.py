@@ -343,10 +343,14 @@ def test_chained_backward_live_columns_and_residual_output_gradient(B, T, tw, wi
         lref = lref + (o * torch.tensor(Rw)).sum()
     lref.backward()
     c = net.forward_causal_block(idx)
-    out, s = net.forward_residual_block(c, t_off=T - tw)
+    # without a gradient through the residual output the forward may skip the dead columns as well
+    out, s = net.forward_residual_block(c, t_off=T - tw, window_only=not with_out)
     loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt)
     if with_out:
         loss = loss + (out * dev(Rw)).sum()
+    else:
+        with pytest.raises(_lib.WaveNetHipError, match="window_only"):
+            (out * dev(Rw)).sum().backward(retain_graph=True)
     net.zero_grads()
     loss.backward()
     assert abs(float(loss.detach()) - float(lref.detach())) < 2e-4
@@ -507,6 +511,29 @@ def test_causality_and_batch_independence_at_full_size():
     with torch.no_grad():
         r = ref.forward_one_step(R.onehot_t(crop, 256), apply_softmax=False).numpy()
     np.testing.assert_allclose(to_np(a)[2, :, 0, t0], r[0, :, 0, -1], atol=ATOL)
+
+
+def test_window_only_forward_at_full_size_changes_nothing_but_the_work():
+    """Config-2 topology and width (T = 16,384, loss over the last 12,290 columns): the step that skips the columns outside
+    the window's receptive field gives the same loss and the same gradients as the step that computes everything."""
+    p, w, net = build(CFG2, cls=FasterWaveNet, seed=3)
+    B, T = 2, 16384
+    iw = net.input_width
+    rs = np.random.RandomState(12)
+    idx = dev(rs.randint(0, 256, (B, T)).astype(np.int32))
+    tgt = dev(rs.randint(0, 256, (B, T - iw)).astype(np.int32))
+    res = []
+    for wo in (False, True):
+        c = net.forward_causal_block(idx)
+        _, s = net.forward_residual_block(c, t_off=iw, window_only=wo)
+        loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt)
+        net.zero_grads()
+        loss.backward()
+        res.append((float(loss.detach()), to_np(net._grad_arena).copy()))
+    assert abs(res[0][0] - res[1][0]) < 1e-6
+    scale = np.abs(res[0][1]).max()
+    assert np.isfinite(res[1][1]).all()
+    assert np.abs(res[0][1] - res[1][1]).max() <= 2e-5 * scale
 
 
 @pytest.mark.parametrize("N,Cin,Cout,act,bias", [(1000, 64, 96, "elu", True), (37, 32, 32, "none", False),

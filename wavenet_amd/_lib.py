@@ -58,7 +58,7 @@ _SIGS = {
     "wn_skip_sum_fwd": (_i, [_i, _pp, _pp, _pp, _ip, _p, _i, _i, _i, _i, _i, _i, _p]),
     "wn_skip_sum_bwd_dz": (_i, [_i, _pp, _ip, _p, _pp, _i, _i, _i, _i, _i, _p]),
     "wn_skip_sum_bwd_dw": (_i, [_i, _pp, _ip, _p, _pp, _pp, _i, _i, _i, _i, _i, _p]),
-    "wn_stack_fwd": (_i, [C.POINTER(WnStackDesc), _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "wn_stack_fwd": (_i, [C.POINTER(WnStackDesc), _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "wn_stack_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(WnStackDesc), _i, _i]),
     "wn_stack_bwd": (_i, [C.POINTER(WnStackDesc)] + [_p] * 8 + [_pp] * 8 + [_p, C.c_size_t, _i, _i, _i, _i, _p]),
     "wn_softmax_fwd": (_i, [_p, _p, _i, _i, _p]),

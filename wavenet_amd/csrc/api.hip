@@ -77,7 +77,7 @@ int wn_layer_fwd(const float* x, const float* Wf, const float* bf, const float* 
     WN_CHECK_ARG((f_save == nullptr) == (g_save == nullptr), "wn_layer_fwd: f_save and g_save go together");
     WN_CHECK_ARG(out != x, "wn_layer_fwd: out must not alias x (taps read x[t-d])");
     if (wn_layer_fast_path(Cr, Cd, fw))
-        return mfma_layer_fwd(x, Wf, bf, Wg, bg, Wp, bp, out, z, f_save, g_save, B, T, d, Z, as_stream(stream));
+        return mfma_layer_fwd(x, Wf, bf, Wg, bg, Wp, bp, out, z, f_save, g_save, B, T, d, Z, 0, as_stream(stream));
     if (!force_generic() && wide_layer_supported(Cr, Cd, fw) && (f_save || Cd <= Cr))
         return wide_layer_fwd(x, Wf, bf, Wg, bg, Wp, bp, out, z, f_save, g_save, B, T, Cr, Cd, fw, d, Z,
                               as_stream(stream));

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
     const float* __restrict__ x, const float* __restrict__ Wf, const float* __restrict__ bf,
     const float* __restrict__ Wg, const float* __restrict__ bg, const float* __restrict__ Wp,
     const float* __restrict__ bp, float* __restrict__ out, float* __restrict__ zout,
-    float* __restrict__ fout, float* __restrict__ gout, int B, int T, int d, int Z, int tiles_per_b,
+    float* __restrict__ fout, float* __restrict__ gout, int B, int T, int d, int Z, int tile_lo, int tiles_per_b,
     int ntiles) {
     const int lane = threadIdx.x & 63;
     const int j = lane & 31;      // time column inside the tile (B/D operand), weight row (A operand)
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
     // makes hipcc branch around every load and drain vmcnt per element)
     auto load_tile = [&](int tile, float (&xc)[16], float (&xo)[16]) {
         const int b = tile / tiles_per_b;
-        const int t = (tile - b * tiles_per_b) * 32 + j;
+        const int t = (tile_lo + tile - b * tiles_per_b) * 32 + j;
         const bool valid = t < T;
         const int tc = valid ? t : T - 1;
         const long long rowc = ((long long)b * T + tc) * 32 + 4 * h;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
     }
     for (int tile = first; tile < last; tile += stride) {
         const int b = tile / tiles_per_b;
-        const int t = (tile - b * tiles_per_b) * 32 + j;
+        const int t = (tile_lo + tile - b * tiles_per_b) * 32 + j;
         const bool valid = t < T;
         const long long row = ((long long)b * T + t) * 32 + 4 * h;
         // the next tile's columns are fetched while this tile computes
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 4) void k_layer_fwd_mfma32_t1(
     const float* __restrict__ x, const float* __restrict__ Wf, const float* __restrict__ bf,
     const float* __restrict__ Wg, const float* __restrict__ bg, const float* __restrict__ Wp,
     const float* __restrict__ bp, float* __restrict__ out, float* __restrict__ zout,
-    float* __restrict__ fout, float* __restrict__ gout, int B, int T, int d, int Z, int tiles_per_b,
+    float* __restrict__ fout, float* __restrict__ gout, int B, int T, int d, int Z, int tile_lo, int tiles_per_b,
     int ntiles) {
     const int lane = threadIdx.x & 63;
     const int j = lane & 31;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 4) void k_layer_fwd_mfma32_t1(
     const bool tvalid = tile < ntiles;
     const int tl = tvalid ? tile : ntiles - 1;
     const int b = tl / tiles_per_b;
-    const int t = (tl - b * tiles_per_b) * 32 + j;
+    const int t = (tile_lo + tl - b * tiles_per_b) * 32 + j;
     const bool valid = tvalid && t < T;
     const int tc = t < T ? t : T - 1;
 
@@ -306,20 +306,23 @@ bool mfma_layer_supported(int Cr, int Cd, int fw) { return Cr == 32 && Cd == 32 
 
 int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg,
                    const float* Wp, const float* bp, float* out, float* z, float* fs, float* gs, int B, int T,
-                   int d, int Z, hipStream_t s) {
-    const int tiles_per_b = (T + 31) / 32;
+                   int d, int Z, int t_live, hipStream_t s) {
+    // columns below t_live (a multiple of 32) are not computed: tiles_per_b counts the live tiles of a clip
+    const int tile_lo = t_live > 0 ? t_live / 32 : 0;
+    const int tiles_per_b = (T + 31) / 32 - tile_lo;
+    WN_CHECK_ARG(tiles_per_b > 0, "mfma_layer_fwd: no live column");
     const long long nt = (long long)B * tiles_per_b;
     WN_CHECK_SHAPE(nt < (1ll << 31), "mfma_layer_fwd: too many tiles");
     const int ntiles = (int)nt;
     int blocks = (ntiles + 3) / 4;
     const bool hb = bf || bg || bp;
-    // enough workgroups to give every CU its four (16 waves): one tile per wave; otherwise the looping kernel.
+    // enough workgroups to give every CU two to four of them (8-16 waves): one tile per wave; otherwise the looping kernel.
     // WAVENET_HIP_FWD_T1_MIN_BLOCKS overrides the threshold (1 = always, used by the parity tests; 0 = never).
-    static const int t1_min = getenv("WAVENET_HIP_FWD_T1_MIN_BLOCKS") ? atoi(getenv("WAVENET_HIP_FWD_T1_MIN_BLOCKS")) : 1024;
+    static const int t1_min = getenv("WAVENET_HIP_FWD_T1_MIN_BLOCKS") ? atoi(getenv("WAVENET_HIP_FWD_T1_MIN_BLOCKS")) : 512;
     if (t1_min > 0 && blocks >= t1_min) {
 #define FWD1_LAUNCH(SAVE, BIAS)                                                                              \
     hipLaunchKernelGGL((k_layer_fwd_mfma32_t1<SAVE, BIAS>), dim3(blocks), dim3(256), 0, s, x, Wf, bf, Wg, bg, Wp, bp, \
-                       out, z, fs, gs, B, T, d, Z, tiles_per_b, ntiles)
+                       out, z, fs, gs, B, T, d, Z, tile_lo, tiles_per_b, ntiles)
         if (fs && hb) FWD1_LAUNCH(true, true);
         else if (fs) FWD1_LAUNCH(true, false);
         else if (hb) FWD1_LAUNCH(false, true);
@@ -331,7 +334,7 @@ int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float
     if (blocks > 512) blocks = 512;          // 256 CUs x 2 resident workgroups; waves stride over tiles
 #define FWD_LAUNCH(SAVE, BIAS)                                                                               \
     hipLaunchKernelGGL((k_layer_fwd_mfma32<SAVE, BIAS>), dim3(blocks), dim3(256), 0, s, x, Wf, bf, Wg, bg, Wp, bp, \
-                       out, z, fs, gs, B, T, d, Z, tiles_per_b, ntiles)
+                       out, z, fs, gs, B, T, d, Z, tile_lo, tiles_per_b, ntiles)
     if (fs && hb) FWD_LAUNCH(true, true);
     else if (fs) FWD_LAUNCH(true, false);
     else if (hb) FWD_LAUNCH(false, true);

@@ -47,7 +47,7 @@ size_t wn_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T) {
 }
 
 int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, float* f, float* g, float* skip,
-                 int B, int T, int t_off, int compat_zero_prefix, void* stream) {
+                 int B, int T, int t_off, int compat_zero_prefix, int window_only, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     WN_CHECK_ARG(x && xs && z && B > 0 && T > 0, "wn_stack_fwd: bad argument");
@@ -58,14 +58,41 @@ int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, floa
     std::vector<const float*> zp(L);
     size_t zoff = 0;
     const float* in = x;
+    // window_only: only what skip[t_off:] depends on is computed.  Layer l's columns below
+    //     live[l] = 32 * floor((live[l+1] - (fw-1) d_{l+1}) / 32),   live[L-1] = 32 * floor(t_off / 32)
+    // cannot reach the window through the layers above (and the backward never reads them: its own live ranges start
+    // at or above these); xs, z, f, g are left untouched there.  Only for stacks that run on the fused MFMA kernels.
+    std::vector<int> live(L, 0);
+    if (window_only && skip && t_off > 0) {
+        // the same condition under which wn_stack_bwd takes the chained path (which honours these ranges): fused
+        // layers without conv / projection biases
+        bool fast = true;
+        for (int l = 0; l < L && fast; ++l)
+            fast = wn_layer_fast_path(d->Cr, d->cd[l], d->fw) != 0 && !(d->bf && d->bf[l]) && !(d->bg && d->bg[l]) &&
+                   !(d->bp && d->bp[l]);
+        if (fast) {
+            live[L - 1] = (t_off / 32) * 32;
+            for (int l = L - 2; l >= 0; --l) {
+                int v = live[l + 1] - (d->fw - 1) * d->dilation[l + 1];
+                live[l] = v > 0 ? (v / 32) * 32 : 0;
+            }
+        }
+    }
     {
         wn::ProfGroup prof_layers__("wn_layer_fwd", stream);     // one bracket around the L launches
         for (int l = 0; l < L; ++l) {
             float* out = xs + (size_t)l * n * d->Cr;
             int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
-            rc = wn_layer_fwd(in, d->Wf[l], d->bf ? d->bf[l] : nullptr, d->Wg[l], d->bg ? d->bg[l] : nullptr, d->Wp[l],
-                              d->bp ? d->bp[l] : nullptr, out, z + zoff, f ? f + zoff : nullptr, g ? g + zoff : nullptr,
-                              B, T, d->Cr, d->cd[l], d->fw, d->dilation[l], Z, stream);
+            if (live[l] > 0) {
+                wn::ProfScope prof__("wn_layer_fwd", stream);
+                rc = mfma_layer_fwd(in, d->Wf[l], d->bf ? d->bf[l] : nullptr, d->Wg[l], d->bg ? d->bg[l] : nullptr,
+                                    d->Wp[l], d->bp ? d->bp[l] : nullptr, out, z + zoff, f ? f + zoff : nullptr,
+                                    g ? g + zoff : nullptr, B, T, d->dilation[l], Z, live[l], as_stream(stream));
+            } else {
+                rc = wn_layer_fwd(in, d->Wf[l], d->bf ? d->bf[l] : nullptr, d->Wg[l], d->bg ? d->bg[l] : nullptr, d->Wp[l],
+                                  d->bp ? d->bp[l] : nullptr, out, z + zoff, f ? f + zoff : nullptr, g ? g + zoff : nullptr,
+                                  B, T, d->Cr, d->cd[l], d->fw, d->dilation[l], Z, stream);
+            }
             if (rc) return rc;
             zp[l] = z + zoff;
             zoff += n * d->cd[l];

@@ -43,7 +43,7 @@ int generic_adam(float* p, const float* g, float* m, float* v, long long n, floa
 bool mfma_layer_supported(int Cr, int Cd, int fw);
 int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg,
                    const float* Wp, const float* bp, float* out, float* z, float* fs, float* gs, int B, int T,
-                   int d, int Z, hipStream_t s);
+                   int d, int Z, int t_live, hipStream_t s);
 
 // ---- mfma_layer_bwd.hip: backward of the same shape; bias gradients come from the scratch -----
 int mfma_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,

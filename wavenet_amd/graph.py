@@ -21,7 +21,7 @@ from . import _lib
 def default_loss(net, x, tgt):
     """train_audio/train.py:60-75: loss over the last ``tgt.shape[1]`` columns of the window."""
     c = net.forward_causal_block(x)
-    _, s = net.forward_residual_block(c, t_off=x.shape[1] - tgt.shape[1])
+    _, s = net.forward_residual_block(c, t_off=x.shape[1] - tgt.shape[1], window_only=True)   # residual output unused
     logits = net.forward_softmax_block(s, apply_softmax=False)
     return net.cross_entropy(logits, tgt)
 

@@ -237,7 +237,7 @@ class _StackFn(_Fn):
     (WaveNet.forward_residual_block, wavenet.py:572-582)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, net, t_off, train):
+    def forward(ctx, x, anchor, net, t_off, train, window_only=False):
         # `anchor` is a dummy leaf that requires grad: it keeps this node on the tape even when x
         # does not require grad, because the weights are not tensor inputs of the node.
         ctx.set_materialize_grads(False)
@@ -253,8 +253,9 @@ class _StackFn(_Fn):
         g = torch.empty_like(z) if train else None
         skip = torch.empty((B, T - t_off, net._Cs), device=dev_, dtype=torch.float32)
         check(_lib.lib().wn_stack_fwd(desc, ptr(x), ptr(xs), ptr(z), ptr(f), ptr(g), ptr(skip), B, T, t_off,
-                                      1 if net.compat_zero_prefix else 0, stream_ptr()), "wn_stack_fwd")
-        ctx.net, ctx.t_off, ctx.shape = net, t_off, (B, T, Cr)
+                                      1 if net.compat_zero_prefix else 0, 1 if window_only else 0, stream_ptr()),
+              "wn_stack_fwd")
+        ctx.net, ctx.t_off, ctx.shape, ctx.window_only = net, t_off, (B, T, Cr), bool(window_only)
         ctx.saved = (x, xs, z, f, g) if train else None
         net._last_layer_inputs = [x] + [xs[l] for l in range(L - 1)]      # FasterWaveNet seeds its rings from these
         return xs[L - 1], skip
@@ -266,6 +267,9 @@ class _StackFn(_Fn):
         if ctx.saved is None:
             raise _lib.WaveNetHipError("backward through a forward that ran without grad enabled")
         x, xs, z, f, g = ctx.saved
+        if ctx.window_only and dout is not None:
+            raise _lib.WaveNetHipError("forward_residual_block(window_only=True) computed only what the skip window needs: "
+                                       "the residual output cannot carry a gradient")
         lib = _lib.lib()
         desc = net._stack_desc()
         gt = net._grad_tables()
@@ -279,7 +283,7 @@ class _StackFn(_Fn):
                                ptr(ws), nbytes, B, T, t_off, 1 if net.compat_zero_prefix else 0, stream_ptr()),
               "wn_stack_bwd")
         ctx.saved = None
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -676,12 +680,16 @@ class WaveNet(object):
         self._last_causal_outputs = outs                          # FasterWaveNet seeds its rings from these
         return _as_view(out)
 
-    def forward_residual_block(self, x_batch, t_off: int = 0):
+    def forward_residual_block(self, x_batch, t_off: int = 0, window_only: bool = False):
         """(output, sum_skip_connections).  ``t_off`` > 0 (an extension) computes the skip sum for
-        columns t_off.. only -- what train.py:73 keeps -- instead of slicing it afterwards."""
+        columns t_off.. only -- what train.py:73 keeps -- instead of slicing it afterwards.
+        ``window_only`` (training, where train.py:72 discards the residual output): columns that cannot influence
+        ``skip[t_off:]`` are not computed at all, so the returned residual output is UNDEFINED below the window's
+        receptive field and must not be used; loss and gradients are unchanged."""
         x = self.to_variable(x_batch)
         _need_gpu(x)
-        out, skip = _StackFn.apply(_to_btc(x), self._anchor, self, int(t_off), torch.is_grad_enabled())
+        out, skip = _StackFn.apply(_to_btc(x), self._anchor, self, int(t_off), torch.is_grad_enabled(),
+                                   bool(window_only))
         return _as_view(out), _as_view(skip)
 
     def forward_softmax_block(self, x_batch, apply_softmax=True, activation: Optional[str] = None):
