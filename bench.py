@@ -254,7 +254,7 @@ def main():
             # name: (bound, algorithmic amount per launch, launches per step, kernels for PMC traffic)
             "wn_layer_bwd": ("hbm", es * (3 * Cr + Cs + 2 * Cd) * n_col, nl,
                              ["wn::k_layer_bwd_chainsp<true, true, true>"]),
-            "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl, ["wn::k_layer_fwd_mfma32<true, false>"]),
+            "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl, ["wn::k_layer_fwd_mfma32_t1<true, false>"]),
             "wn_skip_sum_fwd": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<0>"]),
             "wn_skip_sum_bwd_dw": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_wgrad_b3<4>"]),
             "wn_skip_sum_bwd_dz": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<2>"]),
