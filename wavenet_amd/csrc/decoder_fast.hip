@@ -146,6 +146,7 @@ __device__ __forceinline__ void lds_barrier() {
 
 struct FastLds { const float* xold; float* xcur; float* zall; int* ready; };
 
+typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float f4c(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 __device__ __forceinline__ float bcast(float v, int k) {       // lane k's value as a scalar (SGPR) operand
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
@@ -163,21 +164,20 @@ __device__ __forceinline__ float chain_layer(const FastLds& S, const ChainW& w, 
     float sx[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) sx[k] = bcast(xc, k);
-    float a0 = 0.f, a1 = 0.f;
+    // packed FMAs (v_pk_fma_f32: two MACs per instruction, the scalar pair as an SGPR operand): two accumulator pairs
+    f2 A0 = {0.f, 0.f}, A1 = {0.f, 0.f};
     // ... the x[n-d] half was fetched from LDS (same address in every lane) a layer ago
 #pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-        a0 = fmaf(w.g[j].x, xo[j].x, a0); a1 = fmaf(w.g[j + 1].x, xo[j + 1].x, a1);
-        a0 = fmaf(w.g[j].y, xo[j].y, a0); a1 = fmaf(w.g[j + 1].y, xo[j + 1].y, a1);
-        a0 = fmaf(w.g[j].z, xo[j].z, a0); a1 = fmaf(w.g[j + 1].z, xo[j + 1].z, a1);
-        a0 = fmaf(w.g[j].w, xo[j].w, a0); a1 = fmaf(w.g[j + 1].w, xo[j + 1].w, a1);
+    for (int j = 0; j < 8; ++j) {
+        A0 = __builtin_elementwise_fma(f2{w.g[j].x, w.g[j].y}, f2{xo[j].x, xo[j].y}, A0);
+        A1 = __builtin_elementwise_fma(f2{w.g[j].z, w.g[j].w}, f2{xo[j].z, xo[j].w}, A1);
     }
 #pragma unroll
-    for (int k = 0; k < 32; k += 2) {
-        a0 = fmaf(sx[k], f4c(w.g[8 + (k >> 2)], k & 3), a0);
-        a1 = fmaf(sx[k + 1], f4c(w.g[8 + ((k + 1) >> 2)], (k + 1) & 3), a1);
+    for (int j = 0; j < 8; ++j) {
+        A0 = __builtin_elementwise_fma(f2{sx[4 * j], sx[4 * j + 1]}, f2{w.g[8 + j].x, w.g[8 + j].y}, A0);
+        A1 = __builtin_elementwise_fma(f2{sx[4 * j + 2], sx[4 * j + 3]}, f2{w.g[8 + j].z, w.g[8 + j].w}, A1);
     }
-    const float acc = a0 + a1;
+    const float acc = (A0.x + A0.y) + (A1.x + A1.y);
     // tanh (lanes 0-31) and sigmoid (lanes 32-63) as one sequence: 1 - 2/(1 + e^{2a})  |  1/(1 + e^{-g})
     const bool lo = lane < 32;
     const float r = __frcp_rn(1.0f + __expf(lo ? 2.0f * acc : -acc));
@@ -189,13 +189,13 @@ __device__ __forceinline__ float chain_layer(const FastLds& S, const ChainW& w, 
     float sz[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) sz[k] = bcast(z, k);
-    float p0 = 0.f, p1 = 0.f;
+    f2 P0 = {0.f, 0.f}, P1 = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 32; k += 2) {
-        p0 = fmaf(sz[k], f4c(w.p[k >> 2], k & 3), p0);
-        p1 = fmaf(sz[k + 1], f4c(w.p[(k + 1) >> 2], (k + 1) & 3), p1);
+    for (int j = 0; j < 8; ++j) {
+        P0 = __builtin_elementwise_fma(f2{sz[4 * j], sz[4 * j + 1]}, f2{w.p[j].x, w.p[j].y}, P0);
+        P1 = __builtin_elementwise_fma(f2{sz[4 * j + 2], sz[4 * j + 3]}, f2{w.p[j].z, w.p[j].w}, P1);
     }
-    const float xn = (p0 + p1) + xc;
+    const float xn = ((P0.x + P0.y) + (P1.x + P1.y)) + xc;
     if (lo) S.xcur[(l + 1) * 32 + lane] = xn;
     // publish: LDS operations of a wave retire in order, so the counter store only has to FOLLOW the z store in the
     // instruction stream (a compiler-level fence; no s_waitcnt on the chain's critical path)
