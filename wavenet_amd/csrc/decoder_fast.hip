@@ -19,6 +19,9 @@
 //     the x[n-d] half of the gate (known since the start of the step) comes from LDS broadcast reads off the critical
 //     path.  (The previous form -- gate rows over 2 lanes, projection over 4, DPP reductions, z and x through LDS with
 //     two workgroup barriers per layer -- took 1,650 cycles per layer.)
+//     Wave 1 runs AHEAD of the chain: the x[n-d] half of every gate row depends only on the rings, which are known
+//     when the step starts, so it computes all 40 layers' partial sums into LDS (its own copy of those weights, its
+//     own layer counter) and the chain wave adds one float per row instead of 16 packed FMAs and 8 broadcast reads.
 //     Waves 2-3 run the skip projection (61 % of the MACs) behind the chain from the table of z columns in LDS, two
 //     rows per thread accumulated in registers over all 40 layers; they follow the chain through a layer counter in
 //     LDS (LDS operations of a wave retire in order, so the counter store after the z store publishes it).
@@ -119,16 +122,22 @@ __global__ void k_pack_fast_head(const float* __restrict__ Wh, float* __restrict
         for (int e = 0; e < 4; ++e) dst[(j * 256 + tid) * 4 + e] = Wh[tid * 256 + 4 * j + e];
 }
 
-struct ChainW { float4 g[16]; float4 p[8]; };
+struct ChainW { float4 g[8]; float4 p[8]; };      // gate rows, x[n] half | projection rows
+struct OldW { float4 g[8]; };                      // gate rows, x[n-d] half (wave 1)
 struct SkipW { float4 s[16]; };
 
 // uniform plane base (SGPRs) + a 32-bit per-lane offset: global_load with an saddr, no 64-bit VALU adds
 __device__ __forceinline__ void load_chain(ChainW& w, const float* __restrict__ P, int l, unsigned l4) {
     const float* b = P + (long long)l * kLayerFloats;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) w.g[j] = *reinterpret_cast<const float4*>(b + j * 256 + l4);
+    for (int j = 0; j < 8; ++j) w.g[j] = *reinterpret_cast<const float4*>(b + (8 + j) * 256 + l4);
 #pragma unroll
     for (int j = 0; j < 8; ++j) w.p[j] = *reinterpret_cast<const float4*>(b + kGateFloats + j * 256 + l4);
+}
+__device__ __forceinline__ void load_old(OldW& w, const float* __restrict__ P, int l, unsigned l4) {
+    const float* b = P + (long long)l * kLayerFloats;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w.g[j] = *reinterpret_cast<const float4*>(b + j * 256 + l4);
 }
 __device__ __forceinline__ void load_skip(SkipW& w, const float* __restrict__ P, int l, unsigned t4) {
     const float* b = P + (long long)l * kLayerFloats + kGateFloats + kProjFloats;
@@ -144,7 +153,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-struct FastLds { const float* xold; float* xcur; float* zall; int* ready; };
+struct FastLds { const float* xold; float* xcur; float* zall; float* aold; int* ready; int* ready_old; };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float f4c(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
@@ -154,28 +163,39 @@ __device__ __forceinline__ float bcast(float v, int k) {       // lane k's value
 
 // The chain wave: one residual layer of one step.  xc = x_l[n] (channel lane % 32, valid in every lane); returns
 // x_{l+1}[n].  Writes z to zall[l] and x_{l+1}[n] to xcur[l+1] (for the ring update), then publishes the layer.
-__device__ __forceinline__ void load_xold(float4 (&xo)[8], const FastLds& S, int l) {   // broadcast reads (uniform address)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) xo[j] = *reinterpret_cast<const float4*>(S.xold + l * 32 + 4 * j);
+__device__ __forceinline__ void wait_count(const int* c, int v) {               // *c >= v, then an acquire at compile level
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__device__ __forceinline__ float chain_layer(const FastLds& S, const ChainW& w, float4 (&xo)[8], int l, int nlayers, int lane, float xc) {
-    // gate row `lane`: the x[n] half -- the critical path -- from 32 scalar broadcasts, all read before the first use
-    // (a v_readlane result needs wait states before a VALU may consume it: batched, the FMAs need no s_nop)
+// wave 1: the x[n-d] half of gate row `lane` of layer l -> aold[l][lane]
+__device__ __forceinline__ void old_layer(const FastLds& S, const OldW& w, int l, int lane) {
+    const float* xo = S.xold + l * 32;                 // same address in every lane: broadcast reads
+    f2 A0 = {0.f, 0.f}, A1 = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 x4 = *reinterpret_cast<const float4*>(xo + 4 * j);
+        A0 = __builtin_elementwise_fma(f2{w.g[j].x, w.g[j].y}, f2{x4.x, x4.y}, A0);
+        A1 = __builtin_elementwise_fma(f2{w.g[j].z, w.g[j].w}, f2{x4.z, x4.w}, A1);
+    }
+    S.aold[l * 64 + lane] = (A0.x + A0.y) + (A1.x + A1.y);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (lane == 0) __hip_atomic_store(S.ready_old, l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// The chain wave: one residual layer of one step.  xc = x_l[n] (channel lane % 32, valid in every lane); a_old = the
+// x[n-d] half of this lane's gate row (from wave 1).  Returns x_{l+1}[n]; a_old is replaced by the next layer's.
+__device__ __forceinline__ float chain_layer(const FastLds& S, const ChainW& w, float& a_old, int l, int nlayers, int lane,
+                                             float xc) {
+    // gate row `lane`: 32 scalar broadcasts of x[n], all read before the first use (a v_readlane result needs wait
+    // states before a VALU may consume it: batched, the FMAs need no s_nop); packed FMAs (v_pk_fma_f32: two MACs per
+    // instruction, the scalar pair as an SGPR operand), two accumulator pairs
     float sx[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) sx[k] = bcast(xc, k);
-    // packed FMAs (v_pk_fma_f32: two MACs per instruction, the scalar pair as an SGPR operand): two accumulator pairs
-    f2 A0 = {0.f, 0.f}, A1 = {0.f, 0.f};
-    // ... the x[n-d] half was fetched from LDS (same address in every lane) a layer ago
+    f2 A0 = {a_old, 0.f}, A1 = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        A0 = __builtin_elementwise_fma(f2{w.g[j].x, w.g[j].y}, f2{xo[j].x, xo[j].y}, A0);
-        A1 = __builtin_elementwise_fma(f2{w.g[j].z, w.g[j].w}, f2{xo[j].z, xo[j].w}, A1);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        A0 = __builtin_elementwise_fma(f2{sx[4 * j], sx[4 * j + 1]}, f2{w.g[8 + j].x, w.g[8 + j].y}, A0);
-        A1 = __builtin_elementwise_fma(f2{sx[4 * j + 2], sx[4 * j + 3]}, f2{w.g[8 + j].z, w.g[8 + j].w}, A1);
+        A0 = __builtin_elementwise_fma(f2{sx[4 * j], sx[4 * j + 1]}, f2{w.g[j].x, w.g[j].y}, A0);
+        A1 = __builtin_elementwise_fma(f2{sx[4 * j + 2], sx[4 * j + 3]}, f2{w.g[j].z, w.g[j].w}, A1);
     }
     const float acc = (A0.x + A0.y) + (A1.x + A1.y);
     // tanh (lanes 0-31) and sigmoid (lanes 32-63) as one sequence: 1 - 2/(1 + e^{2a})  |  1/(1 + e^{-g})
@@ -201,13 +221,13 @@ __device__ __forceinline__ float chain_layer(const FastLds& S, const ChainW& w, 
     // instruction stream (a compiler-level fence; no s_waitcnt on the chain's critical path)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (lane == 0) __hip_atomic_store(S.ready, l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (l + 1 < nlayers) load_xold(xo, S, l + 1);      // the next layer's x[n-d]: lands behind its 32 broadcasts
+    if (l + 1 < nlayers) {                             // wave 1 is normally many layers ahead
+        wait_count(S.ready_old, l + 2);
+        a_old = S.aold[(l + 1) * 64 + lane];
+    }
     return xn;
 }
-__device__ __forceinline__ void wait_layer(const FastLds& S, int l) {         // z of layers < l is in zall
-    while (__hip_atomic_load(S.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < l) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // the z reads stay behind the counter read
-}
+__device__ __forceinline__ void wait_layer(const FastLds& S, int l) { wait_count(S.ready, l); }   // z of layers < l is in zall
 
 // skip waves: rows 2t and 2t+1 of Ws_l z_l, accumulated over the layers
 __device__ __forceinline__ void skip_layer(const FastLds& S, const SkipW& w, int l, float& s0, float& s1) {
@@ -246,7 +266,8 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
     int* s_tok = reinterpret_cast<int*>(cdf + 256);     // [4]: current token, previous token
     int* ringt = s_tok + 4;                             // [L] ring offset per layer
     int* dmask = ringt + kMaxFastLayers;                // [L] d - 1 (d is a power of two: fw = 2)
-    int* ready = dmask + kMaxFastLayers;                // [4] number of layers of this step whose z is in zall
+    int* ready = dmask + kMaxFastLayers;                // [2] layers of this step whose z is in zall | whose aold is there
+    float* aold = reinterpret_cast<float*>(ready + 4);  // [L][64] x[n-d] half of every gate row, from wave 1
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
     for (int i = tid; i < 256 * 2 * 32 / 4; i += kFT)
@@ -255,7 +276,7 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
     const float hb = hbias ? hbias[tid] : 0.f;
     if (tid == 0) { s_tok[0] = first_token; s_tok[1] = tok_ring[0]; }     // fwc = 2: ring depth 1
     __syncthreads();
-    FastLds S{xold, xcur, zall, ready};
+    FastLds S{xold, xcur, zall, aold, ready, ready + 1};
     const unsigned t4 = 4u * (tid & 127);
 #ifdef WN_DECODE_STAMPS
     long long stamps[8];
@@ -272,27 +293,42 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
             xold[i] = arena[ringt[l] + (long long)(n & (unsigned)dmask[l]) * 32 + (i & 31)];
         }
         if (tid < 32) xcur[tid] = Elds[(tprev * 2 + 0) * 32 + tid] + Elds[(token * 2 + 1) * 32 + tid];
-        if (tid == 0) __hip_atomic_store(ready, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (tid == 0) {
+            __hip_atomic_store(ready, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(ready + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         if (wv == 0) {
             ChainW w[2];
             load_chain(w[0], P, 0, 4u * lane);
             __syncthreads();
             STAMP(1);
             float xc = xcur[lane & 31];
-            float4 xo[8];
-            load_xold(xo, S, 0);
+            wait_count(S.ready_old, 1);
+            float a_old = aold[lane];
             for (int l0 = 0; l0 < nlayers; l0 += kUnroll) {
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     const int l = l0 + u;
                     if (l < nlayers) {
                         if (l + 1 < nlayers) load_chain(w[(u + 1) & 1], P, l + 1, 4u * lane);   // in flight during layer l
-                        xc = chain_layer(S, w[u & 1], xo, l, nlayers, lane, xc);
+                        xc = chain_layer(S, w[u & 1], a_old, l, nlayers, lane, xc);
                     }
                 }
             }
         } else if (wv == 1) {
+            OldW wo[2];
+            load_old(wo[0], P, 0, 4u * lane);
             __syncthreads();
+            for (int l0 = 0; l0 < nlayers; l0 += kUnroll) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const int l = l0 + u;
+                    if (l < nlayers) {
+                        if (l + 1 < nlayers) load_old(wo[(u + 1) & 1], P, l + 1, 4u * lane);
+                        old_layer(S, wo[u & 1], l, lane);
+                    }
+                }
+            }
         } else {
             float skip0 = 0.f, skip1 = 0.f;
             SkipW w[2];
@@ -436,7 +472,7 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
 
 size_t decode_fast_lds_bytes() {
     return (size_t)(256 * 2 * 32 + kMaxFastLayers * 32 + (kMaxFastLayers + 1) * 32 + kMaxFastLayers * 32 + 256 + 256 + 16) * 4 +
-           256 * 8 + (4 + 2 * kMaxFastLayers + 4) * 4;
+           256 * 8 + (4 + 2 * kMaxFastLayers + 4) * 4 + kMaxFastLayers * 64 * 4;
 }
 size_t decode_fast_pack_floats(int nlayers) { return (size_t)nlayers * kLayerFloats + 256 * 256; }
 
