@@ -530,7 +530,7 @@ def test_window_only_forward_at_full_size_changes_nothing_but_the_work():
         net.zero_grads()
         loss.backward()
         res.append((float(loss.detach()), to_np(net._grad_arena).copy()))
-    assert abs(res[0][0] - res[1][0]) < 1e-6
+    assert abs(res[0][0] - res[1][0]) < 1e-5                 # the loss is summed with float atomics: a few ulp of 6.1
     scale = np.abs(res[0][1]).max()
     assert np.isfinite(res[1][1]).all()
     assert np.abs(res[0][1] - res[1][1]).max() <= 2e-5 * scale
