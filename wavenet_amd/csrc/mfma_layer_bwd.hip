@@ -487,11 +487,14 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
         phase_a(first, pbase, dza);
         stores_in_flight = store_vu(first);
     }
+    // Loop over the tiles that have a successor (one basic block: no branch between the MFMAs of the two tiles, and the
+    // accumulators flow through a single path -- an if/else around the weight-gradient MFMAs made the compiler copy all
+    // 80 accumulator registers every iteration); the last tile's weight gradients follow the loop.
     int it = 0;
-    for (int tile = first; tile < last; tile += stride, ++it) {
+    int tile = first;
+    for (; tile + stride < last; tile += stride, ++it) {
         float* grp = pbase + (it & 1) * 4096;          // patches of `tile`
         float* ngrp = pbase + ((it + 1) & 1) * 4096;   // f, g, V, U of tile + stride
-        const bool next = tile + stride < last;
         // what the previous body fetched (this tile's x, the next tile's f, g, V, U, dz) has had a whole body to land;
         // its V/U stores were issued last and may stay in flight
         if (stores_in_flight) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -499,18 +502,21 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
         WOps w;
         take(tile, grp, xc, xo, w);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the patches are in registers: their slots are free
-        if (next) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dza[q] = dzb[q];
-            fetch_x(tile + stride, xc, xo);
-            if (tile + 2 * stride < last) fetch_a(tile + 2 * stride, grp, dzb);
-            // one basic block: 80 weight-gradient MFMAs of `tile` and the first half of the next tile
-            wgrad(w);
-            phase_a(tile + stride, ngrp, dza);
-            stores_in_flight = store_vu(tile + stride);
-        } else {
-            wgrad(w);
-        }
+        for (int q = 0; q < 4; ++q) dza[q] = dzb[q];
+        fetch_x(tile + stride, xc, xo);
+        if (tile + 2 * stride < last) fetch_a(tile + 2 * stride, grp, dzb);
+        // one basic block: 80 weight-gradient MFMAs of `tile` and the first half of the next tile
+        wgrad(w);
+        phase_a(tile + stride, ngrp, dza);
+        stores_in_flight = store_vu(tile + stride);
+    }
+    if (any) {
+        if (stores_in_flight) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        WOps w;
+        take(tile, pbase + (it & 1) * 4096, xc, xo, w);
+        wgrad(w);
     }
 
     // ---- sum the five accumulators over the waves (tree through the slot groups) -----
