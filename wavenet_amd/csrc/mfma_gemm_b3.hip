@@ -84,7 +84,16 @@ __global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __
 __device__ __forceinline__ int b3_ch(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // MT m-tiles per workgroup (one per wave for the LDS-DMA fill: MT == 4 waves)
-template <int MODE>
+// The activation on X is a template parameter: as a runtime switch it put ~80 branches and ~270 scalar instructions (and
+// an inlined expm1f per element) into every 32-deep chunk of the contraction, next to 48 MFMAs.
+template <int ACT>
+__device__ __forceinline__ float act_apply_t(float x) {
+    if (ACT == WN_ACT_RELU) return x > 0.f ? x : 0.f;
+    if (ACT == WN_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    return x;
+}
+
+template <int MODE, int ACT>
 __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* __restrict__ img, int mtiles,
                                                        int nchunks, int chunks_per_src) {
     constexpr int MT = 4;
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 __bf16 hh, mm, ll;
-                split3(act_apply(v[e], a.act) * ms, hh, mm, ll);
+                split3(act_apply_t<ACT>(v[e]) * ms, hh, mm, ll);
                 xh[ks][e] = hh; xm[ks][e] = mm; xl[ks][e] = ll;
             }
         }
@@ -254,10 +263,18 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     if (!img) { wn::set_error("colgemm_b3: cannot allocate %zu bytes of weight scratch", bytes); return WN_EHIP; }
     hipLaunchKernelGGL(k_split_w, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img);
     dim3 grid(cdiv(a.N, 128), cdiv(mtiles, 4));
-    if (mode == 0)
-        hipLaunchKernelGGL(k_colgemm_b3<0>, grid, dim3(256), 0, s, a, (const __bf16*)img, mtiles, nchunks, cps);
-    else
-        hipLaunchKernelGGL(k_colgemm_b3<2>, grid, dim3(256), 0, s, a, (const __bf16*)img, mtiles, nchunks, cps);
+#define CG_LAUNCH(MODE_, ACT_) \
+    hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_>), grid, dim3(256), 0, s, a, (const __bf16*)img, mtiles, nchunks, cps)
+    if (mode == 0) {
+        if (a.act == WN_ACT_RELU) CG_LAUNCH(0, WN_ACT_RELU);
+        else if (a.act == WN_ACT_ELU) CG_LAUNCH(0, WN_ACT_ELU);
+        else if (a.act == WN_ACT_NONE) CG_LAUNCH(0, WN_ACT_NONE);
+        else { wn::set_error("colgemm_b3: unknown activation %d", a.act); return WN_EARG; }
+    } else {
+        if (a.act != WN_ACT_NONE) { wn::set_error("colgemm_b3: multi-problem mode takes no activation"); return WN_EARG; }
+        CG_LAUNCH(2, WN_ACT_NONE);
+    }
+#undef CG_LAUNCH
     WN_LAUNCH_CHECK();
     return WN_OK;
 }
@@ -270,7 +287,7 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
 //     A-operand image layout as above; raw loads of chunk c+1 are in flight during the MFMAs of chunk c;
 //   * B (one 32-channel tile per wave): eight dword loads per lane per k-step, split in registers.
 // =============================================================================================
-template <int MT, bool HAS_B2>
+template <int MT, bool HAS_B2, int ACT>
 __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[MT * kTileBytes];          // one 32-row chunk of A, split
     constexpr int NF = MT / 2 > 0 ? MT / 2 : 1;             // A fragments per thread per chunk (MT*128 / 256)
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                float bv = act_apply(br[ks][e], a.act) * amask;
+                float bv = act_apply_t<ACT>(br[ks][e]) * amask;
                 if (HAS_B2) bv *= b2r[ks][e];
                 if (edge) {
                     const int rb = r0 + 16 * ks + 8 * h + e;
@@ -422,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
 // barrier per chunk), and every wave runs 96 MFMAs per chunk on its own problem's B values.
 // Grid: x = batch * row slabs, y = ceil(nprob / 8); M == 256.
 // ---------------------------------------------------------------------------------------------
-template <bool HAS_B2>
+template <bool HAS_B2, int ACT>
 __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
     constexpr int MT = 8;
     extern __shared__ __attribute__((aligned(16))) char ldsw[];               // 2 x MT x 6 KB
@@ -504,7 +521,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float av = ar[ks][e];
-                float bv = act_apply(br[ks][e], a.act) * amask;
+                float bv = act_apply_t<ACT>(br[ks][e]) * amask;
                 if (HAS_B2) bv *= b2r[ks][e];
                 if (edge) {                              // rows beyond the slab / outside B's clip contribute nothing
                     const int ra = r0 + 16 * ks + 8 * fhh + e;
@@ -557,10 +574,12 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
 int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_b3w<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * kTileBytes));
-        WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_b3w<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * kTileBytes));
+#define W_ATTR(B2_, ACT_)                                                                               \
+    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_b3w<B2_, ACT_>),                    \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * kTileBytes))
+        W_ATTR(false, WN_ACT_NONE); W_ATTR(false, WN_ACT_RELU); W_ATTR(false, WN_ACT_ELU);
+        W_ATTR(true, WN_ACT_NONE); W_ATTR(true, WN_ACT_RELU); W_ATTR(true, WN_ACT_ELU);
+#undef W_ATTR
         attr_set = true;
     }
     const int gy = (a.nprob + 7) / 8;
@@ -576,8 +595,18 @@ int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
     bool any_b2 = false, all_b2 = true;
     for (int q = 0; q < a.nprob; ++q) { any_b2 |= a.B2p[q] != nullptr; all_b2 &= a.B2p[q] != nullptr; }
     if (any_b2 != all_b2) { wn::set_error("wgrad_b3w: the B2 factor must be given for all problems or for none"); return WN_EARG; }
-    if (any_b2) hipLaunchKernelGGL(k_wgrad_b3w<true>, dim3(a.nB * a.wgs_per_b, gy), dim3(512), 2 * 8 * kTileBytes, s, a);
-    else hipLaunchKernelGGL(k_wgrad_b3w<false>, dim3(a.nB * a.wgs_per_b, gy), dim3(512), 2 * 8 * kTileBytes, s, a);
+    const dim3 grid(a.nB * a.wgs_per_b, gy);
+#define W_LAUNCH(B2_, ACT_) hipLaunchKernelGGL((k_wgrad_b3w<B2_, ACT_>), grid, dim3(512), 2 * 8 * kTileBytes, s, a)
+#define W_LAUNCH_A(B2_)                                           \
+    do {                                                          \
+        if (a.act == WN_ACT_RELU) W_LAUNCH(B2_, WN_ACT_RELU);     \
+        else if (a.act == WN_ACT_ELU) W_LAUNCH(B2_, WN_ACT_ELU);  \
+        else W_LAUNCH(B2_, WN_ACT_NONE);                          \
+    } while (0)
+    if (any_b2) W_LAUNCH_A(true);
+    else W_LAUNCH_A(false);
+#undef W_LAUNCH_A
+#undef W_LAUNCH
     WN_LAUNCH_CHECK();
     return WN_OK;
 }
@@ -586,10 +615,16 @@ int launch_wgrad_b3(const WGArgs& a, int mt, dim3 grid, hipStream_t s) {
     bool any_b2 = false, all_b2 = true;
     for (int q = 0; q < a.nprob; ++q) { any_b2 |= a.B2p[q] != nullptr; all_b2 &= a.B2p[q] != nullptr; }
     if (any_b2 != all_b2) { wn::set_error("wgrad_b3: the B2 factor must be given for all problems or for none"); return WN_EARG; }
+#define WG_LAUNCH_A(MT_, B2_)                                                                           \
+    do {                                                                                                \
+        if (a.act == WN_ACT_RELU) hipLaunchKernelGGL((k_wgrad_b3<MT_, B2_, WN_ACT_RELU>), grid, dim3(256), 0, s, a);     \
+        else if (a.act == WN_ACT_ELU) hipLaunchKernelGGL((k_wgrad_b3<MT_, B2_, WN_ACT_ELU>), grid, dim3(256), 0, s, a);  \
+        else hipLaunchKernelGGL((k_wgrad_b3<MT_, B2_, WN_ACT_NONE>), grid, dim3(256), 0, s, a);         \
+    } while (0)
 #define WG_LAUNCH(MT_)                                                                              \
     do {                                                                                            \
-        if (any_b2) hipLaunchKernelGGL((k_wgrad_b3<MT_, true>), grid, dim3(256), 0, s, a);          \
-        else hipLaunchKernelGGL((k_wgrad_b3<MT_, false>), grid, dim3(256), 0, s, a);                \
+        if (any_b2) WG_LAUNCH_A(MT_, true);                                                         \
+        else WG_LAUNCH_A(MT_, false);                                                               \
     } while (0)
     switch (mt) {
         case 8: WG_LAUNCH(8); break;
@@ -597,6 +632,7 @@ int launch_wgrad_b3(const WGArgs& a, int mt, dim3 grid, hipStream_t s) {
         case 2: WG_LAUNCH(2); break;
         default: WG_LAUNCH(1); break;
     }
+#undef WG_LAUNCH_A
 #undef WG_LAUNCH
     WN_LAUNCH_CHECK();
     return WN_OK;
