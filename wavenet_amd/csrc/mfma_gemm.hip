@@ -25,7 +25,15 @@ __device__ __forceinline__ int cg_ch(int s, int h) { return (s & 3) + 8 * (s >> 
 
 // MODE 0: multi-source (sum over sources, one output);  MODE 1: one problem per workgroup (M = MT*32 rows);
 // MODE 2: MT problems of 32 rows each per workgroup (all share X): X is streamed once per MT problems.
-template <int MT, int MODE>
+// activation as a template parameter: a runtime switch per element sits inside the chunk loop (see mfma_gemm_b3.hip)
+template <int ACT>
+__device__ __forceinline__ float cg_act(float x) {
+    if (ACT == WN_ACT_RELU) return x > 0.f ? x : 0.f;
+    if (ACT == WN_ACT_ELU) return x > 0.f ? x : expm1f(x);
+    return x;
+}
+
+template <int MT, int MODE, int ACT>
 __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
     constexpr bool MP = MODE != 0;
     __shared__ __attribute__((aligned(16))) float Alds[MT * 16 * 64];
@@ -106,8 +114,8 @@ __global__ __launch_bounds__(256, 2) void k_colgemm(CGArgs a) {
         float xb[16];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            xb[4 * q + 0] = act_apply(xr[q].x, a.act) * ms; xb[4 * q + 1] = act_apply(xr[q].y, a.act) * ms;
-            xb[4 * q + 2] = act_apply(xr[q].z, a.act) * ms; xb[4 * q + 3] = act_apply(xr[q].w, a.act) * ms;
+            xb[4 * q + 0] = cg_act<ACT>(xr[q].x) * ms; xb[4 * q + 1] = cg_act<ACT>(xr[q].y) * ms;
+            xb[4 * q + 2] = cg_act<ACT>(xr[q].z) * ms; xb[4 * q + 3] = cg_act<ACT>(xr[q].w) * ms;
         }
         __syncthreads();
         k0 += 32;
@@ -167,7 +175,8 @@ static int launch_colgemm(CGArgs& a, int nprob, hipStream_t s) {
     }
     if (MP && M == 32 && nprob > 1) {          // 32-row problems: 8 per workgroup, X streamed once per 8
         dim3 grid(cdiv(a.N, 128), cdiv(nprob, 8));
-        hipLaunchKernelGGL((k_colgemm<8, 2>), grid, dim3(256), 0, s, a);
+        if (a.act != WN_ACT_NONE) { wn::set_error("colgemm: multi-problem mode takes no activation"); return WN_EARG; }
+        hipLaunchKernelGGL((k_colgemm<8, 2, WN_ACT_NONE>), grid, dim3(256), 0, s, a);
         WN_LAUNCH_CHECK();
         return WN_OK;
     }
@@ -175,13 +184,20 @@ static int launch_colgemm(CGArgs& a, int nprob, hipStream_t s) {
     if (MP) mt = M / 32;      // multi-problem: the whole (small) M in one workgroup
     dim3 grid(cdiv(a.N, 128), MP ? nprob : M / (mt * 32));
     constexpr int MODE = MP ? 1 : 0;
+#define CG_LAUNCH(MT_)                                                                                              \
+    do {                                                                                                            \
+        if (a.act == WN_ACT_RELU) hipLaunchKernelGGL((k_colgemm<MT_, MODE, WN_ACT_RELU>), grid, dim3(256), 0, s, a);     \
+        else if (a.act == WN_ACT_ELU) hipLaunchKernelGGL((k_colgemm<MT_, MODE, WN_ACT_ELU>), grid, dim3(256), 0, s, a);  \
+        else hipLaunchKernelGGL((k_colgemm<MT_, MODE, WN_ACT_NONE>), grid, dim3(256), 0, s, a);                     \
+    } while (0)
     switch (mt) {
-        case 8: hipLaunchKernelGGL((k_colgemm<8, MODE>), grid, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((k_colgemm<4, MODE>), grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((k_colgemm<2, MODE>), grid, dim3(256), 0, s, a); break;
-        case 1: hipLaunchKernelGGL((k_colgemm<1, MODE>), grid, dim3(256), 0, s, a); break;
+        case 8: CG_LAUNCH(8); break;
+        case 4: CG_LAUNCH(4); break;
+        case 2: CG_LAUNCH(2); break;
+        case 1: CG_LAUNCH(1); break;
         default: wn::set_error("colgemm: unsupported M=%d", M); return WN_ESHAPE;
     }
+#undef CG_LAUNCH
     WN_LAUNCH_CHECK();
     return WN_OK;
 }
@@ -287,7 +303,7 @@ int mfma_pointwise_bwd_dx(const float* x, const float* W, const float* dout, flo
 namespace wn {
 
 
-template <int MT, bool HAS_B2>
+template <int MT, bool HAS_B2, int ACT>
 __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WGArgs a) {
     __shared__ __attribute__((aligned(16))) float Alds[32 * MT * 32];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -338,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_mfma(WGArgs a) {
             const int r = r0 + 2 * s + h;
             const int rb = r + a.off;
             const bool ok = active && r < r_end && rb >= 0 && rb < a.rows_B_per_b;
-            float v = act_apply(raw[s], a.act);
+            float v = cg_act<ACT>(raw[s]);
             if (HAS_B2) v *= raw2[s];
             br[s] = ok ? v : 0.f;
         }
@@ -399,10 +415,16 @@ int launch_wgrad(WGArgs& a, int M, hipStream_t s) {
     bool any_b2 = false, all_b2 = true;
     for (int q = 0; q < a.nprob; ++q) { any_b2 |= a.B2p[q] != nullptr; all_b2 &= a.B2p[q] != nullptr; }
     if (any_b2 != all_b2) { wn::set_error("wgrad: the B2 factor must be given for all problems or for none"); return WN_EARG; }
+#define WGF_LAUNCH(MT_, B2_)                                                                                       \
+    do {                                                                                                           \
+        if (a.act == WN_ACT_RELU) hipLaunchKernelGGL((k_wgrad_mfma<MT_, B2_, WN_ACT_RELU>), grid, dim3(256), 0, s, a);   \
+        else if (a.act == WN_ACT_ELU) hipLaunchKernelGGL((k_wgrad_mfma<MT_, B2_, WN_ACT_ELU>), grid, dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL((k_wgrad_mfma<MT_, B2_, WN_ACT_NONE>), grid, dim3(256), 0, s, a);                  \
+    } while (0)
 #define WG_LAUNCH(MT_)                                                                               \
     do {                                                                                             \
-        if (any_b2) hipLaunchKernelGGL((k_wgrad_mfma<MT_, true>), grid, dim3(256), 0, s, a);         \
-        else hipLaunchKernelGGL((k_wgrad_mfma<MT_, false>), grid, dim3(256), 0, s, a);               \
+        if (any_b2) WGF_LAUNCH(MT_, true);                                                           \
+        else WGF_LAUNCH(MT_, false);                                                                 \
     } while (0)
     switch (mt) {
         case 8: WG_LAUNCH(8); break;
@@ -411,6 +433,7 @@ int launch_wgrad(WGArgs& a, int M, hipStream_t s) {
         default: WG_LAUNCH(1); break;
     }
 #undef WG_LAUNCH
+#undef WGF_LAUNCH
     WN_LAUNCH_CHECK();
     return WN_OK;
 }
