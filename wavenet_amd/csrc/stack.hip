@@ -149,8 +149,9 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
         }
     }
     if (chain) {
-        // the (da,dg) scratch is not needed: its room holds the partial weight-gradient tiles and, together with the
-        // two ping-pong buffers, the split gradient (V, U) of two consecutive layers
+        // the (da,dg) scratch is not needed: its room (past the per-layer kernel's own partial-tile area) and the two
+        // ping-pong buffers together hold the split gradient (V, U) of two consecutive layers; every layer's partial
+        // weight-gradient tiles go to their own slot behind them
         float* parts = gbuf[1] + n * d->Cr;          // L x mfma_chain_part_floats(): summed once, after the last layer
         float* vu = dab + mfma_layer_bwd_extra_ws_floats();
         std::vector<float*> dWp_eff(L);
