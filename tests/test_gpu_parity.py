@@ -688,7 +688,8 @@ def test_fast_decoder_sampler_boundary_fallback():
         assert t2[step] == want, (step, shift, t2[step], want, j)
 
 
-def test_train_step_graph_replay_equals_eager_steps():
+@pytest.mark.parametrize("window_only", [False, True])
+def test_train_step_graph_replay_equals_eager_steps(window_only):
     """wavenet_amd.TrainStepGraph: the captured-and-replayed step (batch and Adam step size fed through device
     memory) must train exactly like net.backprop() called op by op, including the changing bias correction."""
     from wavenet_amd import TrainStepGraph
@@ -705,7 +706,7 @@ def test_train_step_graph_replay_equals_eager_steps():
     batches = [(dev(rs.randint(0, 256, (B, T)).astype(np.int32)), dev(rs.randint(0, 256, (B, T - iw)).astype(np.int32)))
                for _ in range(4)]
     w0 = to_np(graphed._arena).copy()
-    g = TrainStepGraph(graphed, *batches[0])
+    g = TrainStepGraph(graphed, *batches[0], loss_fn=lambda n, x, t: default_loss(n, x, t, window_only=window_only))
     np.testing.assert_array_equal(to_np(graphed._arena), w0)          # capture + warm-up did not train
     assert graphed.optimizer.t == 0
     for x, tg in batches:

@@ -18,10 +18,11 @@ import torch
 from . import _lib
 
 
-def default_loss(net, x, tgt):
-    """train_audio/train.py:60-75: loss over the last ``tgt.shape[1]`` columns of the window."""
+def default_loss(net, x, tgt, window_only: bool = False):
+    """train_audio/train.py:60-75: loss over the last ``tgt.shape[1]`` columns of the window.  ``window_only`` also skips
+    the columns that window cannot see (WaveNet.forward_residual_block); same loss, same gradients."""
     c = net.forward_causal_block(x)
-    _, s = net.forward_residual_block(c, t_off=x.shape[1] - tgt.shape[1], window_only=True)   # residual output unused
+    _, s = net.forward_residual_block(c, t_off=x.shape[1] - tgt.shape[1], window_only=window_only)
     logits = net.forward_softmax_block(s, apply_softmax=False)
     return net.cross_entropy(logits, tgt)
 
