@@ -200,7 +200,7 @@ __device__ __forceinline__ float chain_layer(const FastLds& S, const ChainW& w, 
     const float acc = (A0.x + A0.y) + (A1.x + A1.y);
     // tanh (lanes 0-31) and sigmoid (lanes 32-63) as one sequence: 1 - 2/(1 + e^{2a})  |  1/(1 + e^{-g})
     const bool lo = lane < 32;
-    const float r = __frcp_rn(1.0f + __expf(lo ? 2.0f * acc : -acc));
+    const float r = __builtin_amdgcn_rcpf(1.0f + __expf(lo ? 2.0f * acc : -acc));
     const float act = lo ? 1.0f - 2.0f * r : r;
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
     const float z = __uint_as_float(sw[0]) * __uint_as_float(sw[1]);          // z[lane % 32] in every lane

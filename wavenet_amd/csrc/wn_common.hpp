@@ -66,17 +66,19 @@ struct ProfGroup {
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // ---- device math shared by the generic and the MFMA kernels ---------------------------------
-// tanh / sigmoid through one v_exp_f32 and one v_rcp_f32 each; absolute error ~1e-7, which is
+// tanh / sigmoid through one v_exp_f32 and one v_rcp_f32 each (__builtin_amdgcn_rcpf: the 1-ulp hardware reciprocal --
+// __frcp_rn expands to the ten-instruction correctly-rounded division sequence, 320 VALU instructions per 32-column tile of
+// the layer forward); absolute error ~1e-7, which is
 // what the 1e-4 logit tolerance of the north star needs (the reference computes them in float32
 // too: F.tanh, and F.sigmoid as tanh(x/2)/2+1/2).
 __device__ __forceinline__ float fast_tanh(float a) {
     // 1 - 2/(1+e^{2a});  e^{2a} -> inf gives 1, -> 0 gives -1
     float e = __expf(2.0f * a);
-    return 1.0f - 2.0f * __frcp_rn(1.0f + e);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float fast_sigmoid(float a) {
     float e = __expf(-a);
-    return __frcp_rn(1.0f + e);
+    return __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float act_apply(float x, int act) {
     if (act == WN_ACT_RELU) return x > 0.f ? x : 0.f;
