@@ -626,11 +626,11 @@ int launch_wgrad_b3(const WGArgs& a, int mt, dim3 grid, hipStream_t s) {
         if (any_b2) WG_LAUNCH_A(MT_, true);                                                         \
         else WG_LAUNCH_A(MT_, false);                                                               \
     } while (0)
-    switch (mt) {
-        case 8: WG_LAUNCH(8); break;
+    switch (mt) {                        // at most 4 row tiles per workgroup here (8 would spill: 128 accumulator registers)
         case 4: WG_LAUNCH(4); break;
         case 2: WG_LAUNCH(2); break;
-        default: WG_LAUNCH(1); break;
+        case 1: WG_LAUNCH(1); break;
+        default: wn::set_error("wgrad_b3: unsupported tile count %d", mt); return WN_ESHAPE;
     }
 #undef WG_LAUNCH_A
 #undef WG_LAUNCH
