@@ -206,6 +206,13 @@ int wn_decoder_run(void* handle, int32_t first_token, const double* uniforms, in
 int wn_sample_categorical(const float* prob, const double* uniforms, int32_t* out, int n, int Q,
                           void* stream);
 
+/* ---- A2 on the device (optional path; data.py:18-23 and 37-43) --------------------------------------
+ * Table lookups: lut65536[v + 32768] is the token of the int16 sample v, table[q] the sample value of token q;
+ * both tables are built on the host with the reference's float64 formulas (wavenet_amd/data.py), so the device
+ * results are the host's bit for bit.  Tokens outside [0, Q) are clamped on decode.                        */
+int wn_mulaw_encode_pcm16(const int16_t* pcm, const int32_t* lut65536, int32_t* tokens, int64_t n, void* stream);
+int wn_mulaw_decode(const int32_t* tokens, const float* table, float* out, int64_t n, int Q, void* stream);
+
 /* ---- the step either side of backward ------------------------- */
 /* *out (device scalar, accumulated) += sum (grad*grad_mult + weight_decay*param)^2: the squared
  * norm GradientClipping sees after the WeightDecay hook (wavenet.py:175-199, 477-480).

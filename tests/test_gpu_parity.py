@@ -362,6 +362,17 @@ def test_chained_backward_live_columns_and_residual_output_gradient(B, T, tw, wi
         assert np.abs(got - want).max() <= 2e-4 * scale + 1e-7, (ln.name, kind, np.abs(got - want).max(), scale)
 
 
+def test_mulaw_device_tables_are_the_hosts_bit_for_bit():
+    pcm = np.arange(-32768, 32768, dtype=np.int16)
+    tok = data.mulaw_encode_pcm16_device(dev(pcm))
+    np.testing.assert_array_equal(to_np(tok), data.mulaw_encode(pcm.astype(np.float64) / 32768.0))
+    np.testing.assert_array_equal(to_np(tok), D.mulaw_quantize_pcm16(pcm))
+    q = np.random.RandomState(0).randint(0, 256, 5000).astype(np.int32)
+    for compat in (True, False):
+        s = data.mulaw_decode_device(dev(q), 256, compat)
+        np.testing.assert_array_equal(to_np(s), data.mulaw_decode(q, 256, compat).astype(np.float32))
+
+
 def test_adam_step_matches_chainer_rule():
     p, w, net = build(CFG1, gradient_clipping=0.05)
     net.params.weight_decay = 0.01

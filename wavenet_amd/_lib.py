@@ -75,6 +75,8 @@ _SIGS = {
     "wn_sqnorm": (_i, [_p, _p, _i64, _f, _f, _p, _p]),
     "wn_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _f, _f, _p]),
     "wn_adam_step_dev": (_i, [_p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _p, _f, _f, _p]),
+    "wn_mulaw_encode_pcm16": (_i, [_p, _p, _p, _i64, _p]),
+    "wn_mulaw_decode": (_i, [_p, _p, _p, _i64, _i, _p]),
     "wn_eve_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _f, _f, _p]),
     "wn_prof_enable": (_i, [_i]),
     "wn_prof_report": (_i, [C.c_char_p, _i]),

@@ -220,6 +220,18 @@ int wn_sample_categorical(const float* prob, const double* uniforms, int32_t* ou
     return generic_sample(prob, uniforms, out, n, Q, as_stream(stream));
 }
 
+int wn_mulaw_encode_pcm16(const int16_t* pcm, const int32_t* lut65536, int32_t* tokens, int64_t n, void* stream) {
+    NN(pcm); NN(lut65536); NN(tokens);
+    WN_CHECK_ARG(n > 0, "wn_mulaw_encode_pcm16: n <= 0");
+    return generic_mulaw_encode_pcm16(pcm, lut65536, tokens, n, as_stream(stream));
+}
+
+int wn_mulaw_decode(const int32_t* tokens, const float* table, float* out, int64_t n, int Q, void* stream) {
+    NN(tokens); NN(table); NN(out);
+    WN_CHECK_ARG(n > 0 && Q > 0, "wn_mulaw_decode: n <= 0 or Q <= 0");
+    return generic_mulaw_decode(tokens, table, out, n, Q, as_stream(stream));
+}
+
 int wn_sqnorm(const float* grad, const float* param, int64_t n, float grad_mult, float weight_decay, float* out,
               void* stream) {
     wn::ProfScope prof__("wn_sqnorm", stream);

@@ -646,6 +646,24 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// A2 on the device: table lookups (the 65,536-entry encode table and the Q-entry decode table are built on the host
+// with the reference's float64 formulas, data.py:18-23 / 37-43, so the device results are theirs bit for bit)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_mulaw_encode_pcm16(const int16_t* __restrict__ pcm, const int32_t* __restrict__ lut,
+                                     int32_t* __restrict__ tok, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        tok[i] = lut[(int)pcm[i] + 32768];
+}
+__global__ void k_mulaw_decode(const int32_t* __restrict__ tok, const float* __restrict__ table, float* __restrict__ out,
+                               long long n, int Q) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        int q = tok[i];
+        q = q < 0 ? 0 : (q >= Q ? Q - 1 : q);
+        out[i] = table[q];
+    }
+}
+
 }  // namespace wn
 
 using namespace wn;
@@ -922,6 +940,21 @@ int generic_transpose(const float* src, float* dst, int batch, int R, int Cc, hi
 
 int generic_sample(const float* prob, const double* u, int32_t* out, int n, int Q, hipStream_t s) {
     hipLaunchKernelGGL(k_sample, dim3(cdiv(n, 64)), dim3(64), 0, s, prob, u, out, n, Q);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int generic_mulaw_encode_pcm16(const int16_t* pcm, const int32_t* lut, int32_t* tok, long long n, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_mulaw_encode_pcm16, dim3(blocks), dim3(256), 0, s, pcm, lut, tok, n);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+int generic_mulaw_decode(const int32_t* tok, const float* table, float* out, long long n, int Q, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_mulaw_decode, dim3(blocks), dim3(256), 0, s, tok, table, out, n, Q);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

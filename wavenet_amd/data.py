@@ -36,6 +36,37 @@ def mulaw_encode_pcm16(pcm, quantization_steps: int = 256) -> np.ndarray:
     return lut[np.asarray(pcm).astype(np.int64) + 32768]
 
 
+def mulaw_encode_pcm16_device(pcm, quantization_steps: int = 256):
+    """int16 PCM device tensor -> int32 token device tensor (``wn_mulaw_encode_pcm16``: the same 65,536-entry table as
+    :func:`mulaw_encode_pcm16`, looked up on the GPU)."""
+    import torch
+    from . import _lib
+    if not (isinstance(pcm, torch.Tensor) and pcm.is_cuda and pcm.dtype == torch.int16):
+        raise _lib.WaveNetHipError("mulaw_encode_pcm16_device needs an int16 tensor on a HIP device")
+    mulaw_encode_pcm16(np.zeros(1, np.int16), quantization_steps)            # builds the table
+    lut = torch.as_tensor(_LUT16[quantization_steps]).to(pcm.device)
+    pcm = pcm.contiguous()
+    out = torch.empty(pcm.shape, dtype=torch.int32, device=pcm.device)
+    _lib.check(_lib.lib().wn_mulaw_encode_pcm16(_lib.ptr(pcm), _lib.ptr(lut), _lib.ptr(out), pcm.numel(), _lib.stream_ptr()),
+               "wn_mulaw_encode_pcm16")
+    return out
+
+
+def mulaw_decode_device(tokens, quantization_steps: int = 256, compat: bool = True):
+    """int32 token device tensor -> float32 signal device tensor (``wn_mulaw_decode``; table from :func:`mulaw_decode`)."""
+    import torch
+    from . import _lib
+    if not (isinstance(tokens, torch.Tensor) and tokens.is_cuda and tokens.dtype == torch.int32):
+        raise _lib.WaveNetHipError("mulaw_decode_device needs an int32 tensor on a HIP device")
+    table = torch.as_tensor(mulaw_decode(np.arange(quantization_steps), quantization_steps, compat).astype(np.float32))
+    table = table.to(tokens.device)
+    tokens = tokens.contiguous()
+    out = torch.empty(tokens.shape, dtype=torch.float32, device=tokens.device)
+    _lib.check(_lib.lib().wn_mulaw_decode(_lib.ptr(tokens), _lib.ptr(table), _lib.ptr(out), tokens.numel(), quantization_steps,
+                                         _lib.stream_ptr()), "wn_mulaw_decode")
+    return out
+
+
 _PCM = {"16bit_pcm": (1 << 15, np.int16), "32bit_pcm": (1 << 31, np.int32), "8bit_pcm": (1 << 7, np.uint8)}
 
 
