@@ -731,7 +731,28 @@ class WaveNet(object):
         np.savez(os.path.join(model_dir, "wavenet.model.npz"), **self.state_dict())
         np.savez(os.path.join(model_dir, "wavenet.opt.npz"), **self.optimizer.state_dict())
 
+    def load_hdf5(self, filename):
+        """Weights saved by the reference itself (``serializers.save_hdf5(model_dir + "/wavenet.model", self.chain)``,
+        wavenet.py:619-625): Chainer writes one dataset per parameter at ``<link name>/W`` and ``<link name>/b`` -- the
+        key names of :meth:`state_dict`.  Needs h5py (not in this image: the import is attempted here, not at module load)."""
+        try:
+            import h5py
+        except ImportError as e:
+            raise ImportError("reading the reference's HDF5 checkpoints needs h5py (%s); convert to .npz with the same "
+                              "keys (%s, ...) instead" % (e, ", ".join(sorted(self.state_dict())[:2])))
+        sd = {}
+        with h5py.File(filename, "r") as f:
+            def visit(name, obj):
+                if isinstance(obj, h5py.Dataset):
+                    sd[name] = np.asarray(obj)
+            f.visititems(visit)
+        self.load_state_dict({k: v for k, v in sd.items() if k in self.state_dict()})
+
     def load(self, model_dir="./"):
+        fn = os.path.join(model_dir, "wavenet.model")              # the reference's own HDF5 file, if h5py can read it
+        if os.path.isfile(fn) and not os.path.isfile(fn + ".npz"):
+            print("loading", fn, "...")
+            self.load_hdf5(fn)
         fn = os.path.join(model_dir, "wavenet.model.npz")
         if os.path.isfile(fn):                                     # silently skipped when absent, like the reference
             print("loading", fn, "...")
