@@ -81,6 +81,8 @@ def test_layer_fwd_generic(Cr, Cd, fw, d, B, T, bias):
     (512, 2, 2048, False, True), (512, 1, 4094, True, True), (256, 1, 31, False, False), (64, 8, 999, False, False)])
 def test_layer_fwd_mfma(d, B, T, bias, save):
     """The fp32-MFMA kernel (Cr=Cd=32, fw=2): ragged T, tiles straddling t<d, zero prefix, biases."""
+    if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1":
+        pytest.skip("the fused MFMA path is switched off (WAVENET_HIP_FORCE_GENERIC=1)")
     assert _lib.lib().wn_layer_fast_path(32, 32, 2) == 1
     x, Wf, Wg, Wp, b, Z, out, z, f_, g_ = _layer_case(32, 32, 2, d, B, T, bias, seed=d + T)
     o, zz, f, g = _run_layer(x, Wf, Wg, Wp, b, Z, 32, 32, 2, d, save)
@@ -99,6 +101,8 @@ def test_layer_fwd_one_tile_per_wave_kernel_is_covered():
     with the threshold forced to 1 so that every 32/32/2 layer launch goes through it."""
     import subprocess
     import sys
+    if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1":
+        pytest.skip("the fused MFMA path is switched off (WAVENET_HIP_FORCE_GENERIC=1)")
     env = dict(os.environ, WAVENET_HIP_FWD_T1_MIN_BLOCKS="1")
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
