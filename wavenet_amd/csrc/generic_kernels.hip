@@ -35,6 +35,30 @@ __global__ void k_embed_fwd(const int32_t* __restrict__ idx, const float* __rest
     out[i] = acc;
 }
 
+// Same gather for the common case C % 4 == 0, fw <= 2: one thread = four channels of one column, 32-bit index maths,
+// the (at most two) tokens read once per column group.  W is (C, Q, fw): the four channels are Q*fw floats apart.
+__global__ void k_embed_fwd4(const int32_t* __restrict__ idx, const float* __restrict__ W,
+                             const float* __restrict__ bias, float* __restrict__ out,
+                             int ncol, int T, int Q, int C, int fw) {
+    const int c4n = C >> 2;
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (unsigned)ncol * c4n) return;
+    const unsigned col = i / c4n;
+    const int c = (int)(i - col * c4n) * 4;
+    const int t = (int)(col % (unsigned)T);
+    const int q1 = idx[col];                                       // tap fw-1 reads the current token
+    const int q0 = (fw == 2 && t > 0) ? idx[col - 1] : -1;         // tap 0 the previous one (nothing before the clip)
+    float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long cs = (long long)Q * fw;
+    const float* w1 = W + (long long)c * cs + (long long)q1 * fw + (fw - 1);
+    acc.x += w1[0]; acc.y += w1[cs]; acc.z += w1[2 * cs]; acc.w += w1[3 * cs];
+    if (q0 >= 0) {
+        const float* w0 = W + (long long)c * cs + (long long)q0 * fw;
+        acc.x += w0[0]; acc.y += w0[cs]; acc.z += w0[2 * cs]; acc.w += w0[3 * cs];
+    }
+    *reinterpret_cast<float4*>(out + (long long)col * C + c) = acc;
+}
+
 // dW accumulated through an LDS table [Q*fw][C] per block, then flushed with global atomics.
 // The block's columns are one contiguous range of dout; a thread takes kEmbU elements per round and issues all of
 // their loads (values and tokens) before the first LDS atomic -- a loop of "load, then atomics on it" runs one
@@ -676,8 +700,13 @@ namespace wn {
 int generic_embed_fwd(const int32_t* idx, const float* W, const float* bias, float* out, int B, int T,
                       int Q, int C, int fw, hipStream_t s) {
     long long total = (long long)B * T * C;
-    hipLaunchKernelGGL(k_embed_fwd, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, s, idx, W, bias, out,
-                       B, T, Q, C, fw);
+    if (C % 4 == 0 && fw <= 2 && total / 4 < (1ll << 31) && (long long)B * T < (1ll << 31)) {
+        const long long n = total / 4;
+        hipLaunchKernelGGL(k_embed_fwd4, dim3(cdiv(n, kThreads)), dim3(kThreads), 0, s, idx, W, bias, out, B * T, T, Q, C, fw);
+    } else {
+        hipLaunchKernelGGL(k_embed_fwd, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, s, idx, W, bias, out,
+                           B, T, Q, C, fw);
+    }
     WN_LAUNCH_CHECK();
     return WN_OK;
 }
