@@ -832,3 +832,67 @@ def test_training_is_reproducible_enough_and_zero_grad_accumulates():
     assert float((g1 - g2).abs().max()) <= 1e-5 * float(g1.abs().max())
     _, g3 = step(zero=False)
     assert float((g3 - 2 * g1).abs().max()) <= 2e-5 * float(g1.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------
+# the command-line callers end to end: wav -> tokens -> graph-replayed updates -> checkpoint -> fast generation -> wav
+# ---------------------------------------------------------------------------------------------
+def _write_cli_fixture(tmp_path, optimizer="adam"):
+    import json
+    from scipy.io import wavfile
+    wav = tmp_path / "wav"; wav.mkdir()
+    model = tmp_path / "model"; model.mkdir()
+    sr = 8000
+    t = np.arange(3 * sr) / sr
+    pcm = (0.5 * np.sin(2 * np.pi * 220 * t) * 32767).astype(np.int16)
+    wavfile.write(str(wav / "tone.wav"), sr, pcm)
+    (wav / "notes.txt").write_text("not audio")                    # train.py:103-106 filters on the extension
+    with open(str(model / "wavenet.json"), "w") as f:
+        json.dump({"quantization_steps": 256, "sampling_rate": sr, "causal_conv_channels": [32],
+                   "residual_conv_channels": [32, 32, 32, 32], "residual_num_blocks": 2,
+                   "softmax_conv_channels": [64, 256], "optimizer": optimizer}, f)
+    return str(wav), str(model)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("no_graph", [False, True])
+def test_cli_train_then_generate(tmp_path, no_graph):
+    from scipy.io import wavfile
+    from wavenet_amd.train_audio import generate as cli_generate
+    from wavenet_amd.train_audio import train as cli_train
+    wav, model = _write_cli_fixture(tmp_path)
+    common = ["-w", wav, "-m", model, "--seed", "1"]
+    extra = ["--no-graph"] if no_graph else []
+    l1 = cli_train.main(common + ["--lr", "0.003", "--batch-size", "4", "--train-width", "256", "--repeat", "30",
+                                  "--max-epoch", "2"] + extra)
+    assert os.path.isfile(os.path.join(model, "wavenet.model.npz")) and os.path.isfile(os.path.join(model, "wavenet.opt.npz"))
+    # a second invocation resumes from the checkpoint (model.py:52) and keeps improving on the tone
+    l2 = cli_train.main(common + ["--lr", "0.003", "--batch-size", "4", "--train-width", "256", "--repeat", "30",
+                                  "--max-epoch", "2"] + extra)
+    assert np.isfinite(l1) and np.isfinite(l2) and l2 < l1, (l1, l2)
+    out = str(tmp_path / "gen")
+    fn, tokens = cli_generate.main(["-m", model, "-o", out, "-s", "0.05", "--fast", "--seed", "2"])
+    assert fn == out + "/generated.wav" and tokens.shape == (int(8000 * 0.05) - 1,)
+    sr, audio = wavfile.read(fn)
+    assert sr == 8000 and audio.shape == (tokens.size, 2) and audio.dtype == np.int16
+    assert tokens.min() >= 0 and tokens.max() < 256
+    # the slow path (full window per sample) draws the same first sample from the same seed and weights
+    fn2, tokens2 = cli_generate.main(["-m", model, "-o", out, "-s", "0.003", "--seed", "2"])
+    assert tokens2.shape == (int(8000 * 0.003) - 1,) and tokens2[0] == tokens[0]
+
+
+@pytest.mark.gpu
+def test_cli_graph_and_eager_training_agree(tmp_path):
+    """Same seed, same file: the graph-replayed loop and the op-by-op loop end at the same weights (to float-atomic noise)."""
+    from wavenet_amd.train_audio import train as cli_train
+    res = []
+    for i, extra in enumerate(([], ["--no-graph"])):
+        d = tmp_path / ("run%d" % i); d.mkdir()
+        wav, model = _write_cli_fixture(d)
+        cli_train.main(["-w", wav, "-m", model, "--seed", "5", "--batch-size", "2", "--train-width", "128", "--repeat", "5",
+                        "--max-epoch", "2"] + extra)
+        with np.load(os.path.join(model, "wavenet.model.npz")) as z:
+            res.append({k: z[k] for k in z.files})
+    assert set(res[0]) == set(res[1])
+    for k in res[0]:
+        np.testing.assert_allclose(res[0][k], res[1][k], rtol=0, atol=2e-5, err_msg=k)
