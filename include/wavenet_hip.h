@@ -237,6 +237,19 @@ int wn_eve_step(float* param, const float* grad, float* m, float* v, int64_t n,
 int wn_adam_step_dev(float* param, const float* grad, float* m, float* v, int64_t n,
                      const float* lr_t_dev, float beta1, float beta2, float eps, float weight_decay,
                      const float* sqnorm, float clip, float grad_mult, void* stream);
+/* The other update rules get_optimizer() names (wavenet.py:81-97; chainer.optimizers.SGD / MomentumSGD / AdaGrad /
+ * AdaDelta / NesterovAG / RMSprop as Chainer publishes them), behind the same hooks as wn_adam_step:
+ *   SGD          p -= lr g                                  MomentumSGD  v = hyper v - lr g; p += v
+ *   AdaGrad      h += g^2; p -= lr g/(sqrt(h)+eps)          NesterovAG   v = hyper v - lr g; p += hyper^2 v - (1+hyper) lr g
+ *   RMSprop      ms += (1-hyper)(g^2-ms); p -= lr g/(sqrt(ms)+eps)
+ *   AdaDelta     msg += (1-hyper)(g^2-msg); dx = sqrt((msdx+eps)/(msg+eps)) g; msdx += (1-hyper)(dx^2-msdx); p -= dx
+ * s1 = v / h / ms / msg, s2 = msdx (AdaDelta only, else NULL); hyper = momentum / alpha / rho.  lr_dev != NULL: the
+ * learning rate is read from device memory at execution time (graph replay), `lr` is ignored.                       */
+enum { WN_RULE_SGD = 0, WN_RULE_MOMENTUM_SGD = 1, WN_RULE_ADAGRAD = 2, WN_RULE_ADADELTA = 3, WN_RULE_NESTEROV = 4,
+       WN_RULE_RMSPROP = 5 };
+int wn_rule_step(int rule, float* param, const float* grad, float* s1, float* s2, int64_t n, float lr,
+                 const float* lr_dev, float hyper, float eps, float weight_decay, const float* sqnorm, float clip,
+                 float grad_mult, void* stream);
 
 /* ---- measurement aid (bench.py): per-entry-point HIP-event timing on the caller's stream ------- */
 int wn_prof_enable(int on);                    /* 1: clear + start recording, 0: stop               */

@@ -529,3 +529,37 @@ class EveRef(object):
             st["m"] += (1. - self.beta1) * (grads[k] - st["m"])
             st["v"] += (1. - self.beta2) * (grads[k] * grads[k] - st["v"])
             params[k] -= self.lr * st["m"] / (st["d"] * np.sqrt(st["v"]) + self.eps)
+
+
+# --------------------------------------------------------------------------
+# the remaining get_optimizer names (wavenet.py:87-96): Chainer's published update rules, float32, hooks excluded
+# (Chainer is a dependency that is absent here: parity unpinned, like the rest of this file)
+# --------------------------------------------------------------------------
+
+def rule_step_ref(name, p, g, s1, s2, lr, hyper):
+    """TEST INFRASTRUCTURE ONLY.  One in-place update of float32 arrays ``p`` with state ``s1`` (v / h / ms / msg) and
+    ``s2`` (AdaDelta's msdx).  ``hyper`` = momentum (MomentumSGD, NesterovAG) / alpha (RMSprop) / rho (AdaDelta)."""
+    f = np.float32
+    lr, hyper = f(lr), f(hyper)
+    name = name.lower()
+    if name == "sgd":                                       # chainer.optimizers.SGD
+        p -= lr * g
+    elif name == "momentumsgd":                             # v = momentum v - lr g; p += v
+        s1[:] = hyper * s1 - lr * g
+        p += s1
+    elif name == "adagrad":                                 # eps = 1e-8
+        s1 += g * g
+        p -= lr * g / (np.sqrt(s1) + f(1e-8))
+    elif name == "adadelta":                                # eps = 1e-6
+        s1 += (f(1) - hyper) * (g * g - s1)
+        dx = np.sqrt((s2 + f(1e-6)) / (s1 + f(1e-6))) * g
+        s2 += (f(1) - hyper) * (dx * dx - s2)
+        p -= dx
+    elif name in ("nesterov", "nesterovag"):                # v = momentum v - lr g; p += momentum^2 v - (1+momentum) lr g
+        s1[:] = hyper * s1 - lr * g
+        p += hyper * hyper * s1 - (f(1) + hyper) * lr * g
+    elif name == "rmsprop":                                 # eps = 1e-8
+        s1 += (f(1) - hyper) * (g * g - s1)
+        p -= lr * g / (np.sqrt(s1) + f(1e-8))
+    else:
+        raise Exception()                                   # wavenet.py:97

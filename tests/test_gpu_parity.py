@@ -419,6 +419,76 @@ def test_eve_step_matches_the_reference_class():
     assert net.optimizer.d != 1.0
 
 
+@pytest.mark.parametrize("name", ["sgd", "momentumsgd", "adagrad", "adadelta", "nesterov", "nesterovag", "rmsprop"])
+@pytest.mark.parametrize("hooks", [(0.0, 0.0), (0.05, 1e-3)])
+def test_rule_steps_match_chainer_rules(name, hooks):
+    """The other get_optimizer names (wavenet.py:87-96): wn_rule_step behind WeightDecay -> GradientClipping vs the
+    published Chainer rules restated in numpy."""
+    clip, wd = hooks
+    p, w, net = build(CFG1, gradient_clipping=clip)
+    net.params.weight_decay = wd
+    net.params.optimizer = name
+    net.setup_optimizer()
+    net.optimizer.to(net.device)
+    net.update_laerning_rate(0.01)
+    net.update_momentum(0.8)
+    opt = net.optimizer
+    assert opt.lr == (0.0001 if name == "adadelta" else 0.01)          # AdaDelta has no learning rate (wavenet.py:489-491)
+    hyper = 0.8 if name not in ("sgd", "adagrad") else 0.0
+    P = to_np(net._arena).copy()
+    s1, s2 = np.zeros_like(P), np.zeros_like(P)
+    rs = np.random.RandomState(11)
+    for it in range(4):
+        g = (rs.standard_normal(P.shape) * 0.02).astype(np.float32)
+        net._grad_arena.copy_(dev(g))
+        opt.update(1.0)
+        gh = g + np.float32(wd) * P if wd else g.copy()
+        if clip:
+            nrm = np.sqrt(np.sum(gh.astype(np.float64) ** 2))
+            if clip / nrm < 1:
+                gh = (gh * np.float32(clip / nrm)).astype(np.float32)
+        R.rule_step_ref(name, P, gh, s1, s2, opt.lr, hyper)
+        np.testing.assert_allclose(to_np(net._arena), P, rtol=0, atol=3e-6)
+    assert opt.t == 4
+    sd = opt.state_dict()
+    opt.load_state_dict(sd)
+    if name != "sgd":
+        np.testing.assert_allclose(sd["m"], s1, rtol=1e-5, atol=1e-9)
+
+
+def test_unknown_optimizer_name_raises():
+    p, w, net = build(CFG1)
+    net.params.optimizer = "lion"
+    with pytest.raises(Exception):
+        net.setup_optimizer()
+
+
+def test_graph_replay_with_a_rule_optimizer_matches_eager():
+    from wavenet_amd import TrainStepGraph
+    from wavenet_amd.graph import default_loss
+    nets = []
+    for _ in range(2):
+        p, w, net = build(CFG1, seed=4)
+        net.params.optimizer = "rmsprop"
+        net.setup_optimizer()
+        net.optimizer.to(net.device)
+        net.update_laerning_rate(0.003)
+        nets.append(net)
+    a, b = nets
+    b._arena.copy_(a._arena)
+    iw = a.input_width
+    rs = np.random.RandomState(0)
+    Q = a.params.quantization_steps
+    tok = rs.randint(0, Q, size=(2, iw + 65)).astype(np.int32)
+    x, tgt = dev(tok[:, :-1]), dev(tok[:, iw + 1:])
+    g = TrainStepGraph(a, x, tgt)
+    for it in range(3):
+        g.step(x, tgt)
+        b.backprop(default_loss(b, x, tgt))
+    np.testing.assert_allclose(to_np(a._arena), to_np(b._arena), rtol=0, atol=2e-5)
+    assert a.optimizer.t == b.optimizer.t == 3
+
+
 def test_backprop_with_eve_learns_the_toy_staircase():
     p, w, net = build(dict(quantization_steps=10, causal_conv_channels=[32], residual_conv_channels=[16, 16],
                            residual_num_blocks=1, softmax_conv_channels=[32, 10]))

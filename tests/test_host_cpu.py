@@ -146,9 +146,9 @@ def test_eve_loss_feedback_scalars_follow_the_reference_recurrence():
         assert net.optimizer.d == float(ref.states["w"]["d"][0])
     with pytest.raises(RuntimeError):
         net.optimizer.update(1.0)                                   # Eve.update requires the loss (wavenet.py:75-76)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(Exception):                                  # get_optimizer's final `raise Exception()` (wavenet.py:97)
         WaveNet(Params(dict(quantization_steps=16, causal_conv_channels=[4], residual_conv_channels=[4], residual_num_blocks=1,
-                            softmax_conv_channels=[8, 16], optimizer="adagrad")))
+                            softmax_conv_channels=[8, 16], optimizer="no-such-rule")))
 
 
 def test_hdf5_checkpoint_import_is_guarded():
@@ -164,3 +164,24 @@ def test_hdf5_checkpoint_import_is_guarded():
             net.load_hdf5("/nonexistent/wavenet.model")
     keys = sorted(net.state_dict())
     assert "causal_0/W" in keys and "residual_0_block_0_wf/W" in keys and "softmax_0/b" in keys     # Chainer's dataset paths
+
+
+def test_get_optimizer_names_and_the_setters():
+    """wavenet.py:81-97 (names), 482-513 (which attribute update_laerning_rate / update_momentum touch)."""
+    from wavenet_amd.wavenet import AdamState, EveState, RuleState
+    base = dict(causal_conv_channels=[8], residual_conv_channels=[8, 8], residual_num_blocks=1, softmax_conv_channels=[8, 256])
+    for name, cls in [("adam", AdamState), ("Adam", AdamState), ("eve", EveState), ("adagrad", RuleState),
+                      ("AdaDelta", RuleState), ("nesterov", RuleState), ("nesterovag", RuleState), ("rmsprop", RuleState),
+                      ("momentumsgd", RuleState), ("sgd", RuleState)]:
+        net = WaveNet(Params(dict(base, optimizer=name, momentum=0.7)))
+        opt = net.optimizer
+        assert type(opt) is cls, name
+        net.update_laerning_rate(0.5)
+        net.update_momentum(0.3)
+        if cls is RuleState:
+            assert opt.lr == (0.0001 if name.lower() == "adadelta" else 0.5)
+            assert opt.hyper == (0.0 if name in ("sgd", "adagrad") else 0.3)
+        else:
+            assert opt.alpha == 0.5 and opt.beta1 == 0.3
+    with pytest.raises(Exception):
+        WaveNet(Params(dict(base, optimizer="lion")))

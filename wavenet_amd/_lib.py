@@ -78,6 +78,7 @@ _SIGS = {
     "wn_mulaw_encode_pcm16": (_i, [_p, _p, _p, _i64, _p]),
     "wn_mulaw_decode": (_i, [_p, _p, _p, _i64, _i, _p]),
     "wn_eve_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _f, _f, _p]),
+    "wn_rule_step": (_i, [_i, _p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _p, _f, _f, _p]),
     "wn_prof_enable": (_i, [_i]),
     "wn_prof_report": (_i, [C.c_char_p, _i]),
 }

@@ -271,4 +271,17 @@ int wn_adam_step_dev(float* param, const float* grad, float* m, float* v, int64_
                         lr_t_dev, 1.f, as_stream(stream));
 }
 
+int wn_rule_step(int rule, float* param, const float* grad, float* s1, float* s2, int64_t n, float lr,
+                 const float* lr_dev, float hyper, float eps, float weight_decay, const float* sqnorm, float clip,
+                 float grad_mult, void* stream) {
+    wn::ProfScope prof__("wn_adam_step", stream);
+    NN(param); NN(grad);
+    WN_CHECK_ARG(n > 0, "wn_rule_step: n <= 0");
+    WN_CHECK_ARG(rule >= WN_RULE_SGD && rule <= WN_RULE_RMSPROP, "wn_rule_step: unknown rule");
+    WN_CHECK_ARG(rule == WN_RULE_SGD || s1, "wn_rule_step: this rule needs s1");
+    WN_CHECK_ARG(rule != WN_RULE_ADADELTA || s2, "wn_rule_step: AdaDelta needs s2");
+    return generic_rule(rule, param, grad, s1, s2, n, lr, hyper, eps, weight_decay, sqnorm, clip, grad_mult, lr_dev,
+                        as_stream(stream));
+}
+
 }  // extern "C"

@@ -670,6 +670,60 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
     }
 }
 
+// The other update rules get_optimizer() names (wavenet.py:81-97), as Chainer publishes them, behind the same two hooks.
+//   0 SGD          p -= lr g
+//   1 MomentumSGD  v = mu v - lr g;  p += v
+//   2 AdaGrad      h += g^2;  p -= lr g / (sqrt(h) + eps)
+//   3 AdaDelta     msg += (1-rho)(g^2 - msg);  dx = sqrt((msdx+eps)/(msg+eps)) g;  msdx += (1-rho)(dx^2 - msdx);  p -= dx
+//   4 NesterovAG   v = mu v - lr g;  p += mu^2 v - (1+mu) lr g
+//   5 RMSprop      ms += (1-alpha)(g^2 - ms);  p -= lr g / (sqrt(ms) + eps)
+template <int RULE>
+__global__ void k_rule(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s1,
+                       float* __restrict__ s2, long long n, float lr, float hy, float eps, float wd,
+                       const float* __restrict__ sqnorm, float clip, float gmult, const float* __restrict__ lr_dev) {
+    if (lr_dev) lr = *lr_dev;
+    float rate = 1.f;
+    if (sqnorm && clip > 0.f) {
+        float nrm = sqrtf(*sqnorm);
+        if (nrm > 0.f && clip / nrm < 1.f) rate = clip / nrm;
+    }
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float gi = g[i] * gmult;
+        float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        gi *= rate;
+        if (RULE == 0) {
+            pi -= lr * gi;
+        } else if (RULE == 1) {
+            const float v = hy * s1[i] - lr * gi;
+            s1[i] = v;
+            pi += v;
+        } else if (RULE == 2) {
+            const float h = s1[i] + gi * gi;
+            s1[i] = h;
+            pi -= lr * gi / (sqrtf(h) + eps);
+        } else if (RULE == 3) {
+            float msg = s1[i], msdx = s2[i];
+            msg += (1.f - hy) * (gi * gi - msg);
+            const float dx = sqrtf((msdx + eps) / (msg + eps)) * gi;
+            msdx += (1.f - hy) * (dx * dx - msdx);
+            s1[i] = msg; s2[i] = msdx;
+            pi -= dx;
+        } else if (RULE == 4) {
+            const float v = hy * s1[i] - lr * gi;
+            s1[i] = v;
+            pi += hy * hy * v - (1.f + hy) * lr * gi;
+        } else {
+            float ms = s1[i];
+            ms += (1.f - hy) * (gi * gi - ms);
+            s1[i] = ms;
+            pi -= lr * gi / (sqrtf(ms) + eps);
+        }
+        p[i] = pi;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // A2 on the device: table lookups (the 65,536-entry encode table and the Q-entry decode table are built on the host
 // with the reference's float64 formulas, data.py:18-23 / 37-43, so the device results are theirs bit for bit)
@@ -1006,6 +1060,26 @@ int generic_adam(float* p, const float* g, float* m, float* v, long long n, floa
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr_t, b1, b2, eps, wd, sqnorm, clip,
                        gmult, lr_dev, dscale);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int generic_rule(int rule, float* p, const float* g, float* s1, float* s2, long long n, float lr, float hy, float eps,
+                 float wd, const float* sqnorm, float clip, float gmult, const float* lr_dev, hipStream_t s) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+#define RULE_LAUNCH(R) hipLaunchKernelGGL(k_rule<R>, dim3(blocks), dim3(256), 0, s, p, g, s1, s2, n, lr, hy, eps, wd, \
+                                          sqnorm, clip, gmult, lr_dev)
+    switch (rule) {
+        case 0: RULE_LAUNCH(0); break;
+        case 1: RULE_LAUNCH(1); break;
+        case 2: RULE_LAUNCH(2); break;
+        case 3: RULE_LAUNCH(3); break;
+        case 4: RULE_LAUNCH(4); break;
+        default: RULE_LAUNCH(5); break;
+    }
+#undef RULE_LAUNCH
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

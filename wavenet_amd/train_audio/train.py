@@ -52,7 +52,7 @@ def train_audio(net, params, path_to_file, batch_size=16, train_width=16, repeat
     name = os.path.basename(path_to_file)
     for batch_index in range(repeat):
         x, tgt = crops.draw(batch_size)
-        if use_graph and str(params.optimizer).lower() == "adam":
+        if use_graph and str(params.optimizer).lower() != "eve":     # Eve needs the loss on the host every update
             key = (batch_size, iw + train_width)
             graph = None if state is None else state.get(key)
             if graph is None:

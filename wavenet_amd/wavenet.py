@@ -568,15 +568,29 @@ class WaveNet(object):
             self.optimizer = AdamState(self, alpha=0.0001, beta1=p.momentum)     # wavenet.py:475, get_optimizer 81-84
         elif name == "eve":
             self.optimizer = EveState(self, alpha=0.0001, beta1=p.momentum)      # wavenet.py:85-86
+        elif name in RuleState.RULES:
+            self.optimizer = RuleState(self, name, lr=0.0001, momentum=p.momentum)   # wavenet.py:87-96
         else:
-            raise NotImplementedError("optimizers built: 'adam' (the reference's default) and 'eve' (its own class); "
-                                      "got %r" % p.optimizer)
+            raise Exception("unknown optimizer %r" % p.optimizer)                # wavenet.py:97
 
     def update_laerning_rate(self, lr):
-        self.optimizer.alpha = lr
+        """wavenet.py:482-493: Adam/Eve take it as alpha, AdaDelta has no learning rate, everything else as lr."""
+        opt = self.optimizer
+        if isinstance(opt, RuleState):
+            if opt.name != "adadelta":
+                opt.lr = lr
+            return
+        opt.alpha = lr
 
     def update_momentum(self, momentum):
-        self.optimizer.beta1 = momentum
+        """wavenet.py:495-513: beta1 / rho / momentum / alpha by optimizer; SGD and AdaGrad have none.  (For MomentumSGD the
+        reference assigns a misspelt attribute, which changes nothing; here the momentum is really updated.)"""
+        opt = self.optimizer
+        if isinstance(opt, RuleState):
+            if opt.name in ("adadelta", "nesterov", "nesterovag", "rmsprop", "momentumsgd"):
+                opt.hyper = momentum
+            return
+        opt.beta1 = momentum
 
     def zero_grads(self):
         self._grad_arena.zero_()
@@ -893,3 +907,51 @@ class EveState(AdamState):
     def load_state_dict(self, sd):
         super().load_state_dict(sd)
         self.d, self.f = float(sd["d"]), float(sd["f"])
+
+
+class RuleState(object):
+    """The other optimizers ``get_optimizer`` names (wavenet.py:87-96): Chainer's SGD, MomentumSGD, AdaGrad, AdaDelta,
+    NesterovAG and RMSprop on the flat arena, behind the same hooks as Adam (``wn_rule_step``).  Constructor arguments
+    follow get_optimizer: ``lr`` where the rule has one, the model's ``momentum`` as momentum / rho (AdaDelta) / alpha
+    (RMSprop).  The reference's "momentumsgd" line misspells two names and raises NameError before it can train; the
+    rule itself is implemented here."""
+
+    #            rule id, uses momentum hyper, eps (Chainer defaults)
+    RULES = {"sgd": (0, False, 0.0), "momentumsgd": (1, True, 0.0), "adagrad": (2, False, 1e-8),
+             "adadelta": (3, True, 1e-6), "nesterov": (4, True, 0.0), "nesterovag": (4, True, 0.0),
+             "rmsprop": (5, True, 1e-8)}
+
+    def __init__(self, net, name: str, lr=0.0001, momentum=0.9):
+        self.net, self.name = net, name.lower()
+        self.rule, uses_hyper, self.eps = self.RULES[self.name]
+        self.lr = lr
+        self.hyper = momentum if uses_hyper else 0.0
+        self.t = 0
+        # m = first state array (v / h / ms / msg), v = second (AdaDelta's msdx): the names TrainStepGraph snapshots
+        self.m = torch.zeros_like(net._arena) if self.rule != 0 else torch.zeros((1,), dtype=torch.float32)
+        self.v = torch.zeros_like(net._arena) if self.rule == 3 else torch.zeros((1,), dtype=torch.float32)
+        self._norm = torch.zeros((1,), dtype=torch.float32)
+
+    def to(self, dev):
+        self.m, self.v, self._norm = self.m.to(dev), self.v.to(dev), self._norm.to(dev)
+
+    _hooks = AdamState._hooks
+
+    def update(self, grad_mult: float = 1.0, lr_dev=None):
+        net = self.net
+        _need_gpu(net._arena)
+        self.t += 1
+        norm_ptr, clip, wd = self._hooks(grad_mult)
+        check(_lib.lib().wn_rule_step(self.rule, ptr(net._arena), ptr(net._grad_arena),
+                                      ptr(self.m) if self.rule != 0 else None, ptr(self.v) if self.rule == 3 else None,
+                                      net._arena.numel(), self.lr, ptr(lr_dev) if lr_dev is not None else None,
+                                      self.hyper, self.eps, wd, norm_ptr, clip, grad_mult, stream_ptr()), "wn_rule_step")
+
+    def state_dict(self):
+        return {"t": np.array(self.t), "lr": np.array(self.lr), "hyper": np.array(self.hyper),
+                "m": self.m.cpu().numpy(), "v": self.v.cpu().numpy()}
+
+    def load_state_dict(self, sd):
+        self.t, self.lr, self.hyper = int(sd["t"]), float(sd["lr"]), float(sd["hyper"])
+        self.m.copy_(torch.from_numpy(np.asarray(sd["m"])))
+        self.v.copy_(torch.from_numpy(np.asarray(sd["v"])))
