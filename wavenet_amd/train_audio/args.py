@@ -1,27 +1,36 @@
-"""Command-line flags of train_audio/args.py:5-18 (same names and defaults), plus the loop sizes the reference hard-codes
-in train.py:112-114 / 121-124 so that a short run does not need an edit."""
+"""Command-line flags of the reference's train_audio scripts (train_audio/args.py:5-18: same spellings and defaults),
+plus the loop sizes train.py:112-114 / 124 hard-codes, so that a short run does not need an edit."""
 from __future__ import annotations
 
 import argparse
 
+# (flags, type, default, help); a bool default makes a store_true switch
+_REFERENCE_FLAGS = (
+    (("-g", "--gpu_device"), int, 0, "HIP device index"),
+    (("-w", "--wav-dir"), str, "wav", "directory of .wav files to train on"),
+    (("-m", "--model-dir"), str, "model", "wavenet.json + checkpoints"),
+    (("-o", "--output_dir"), str, "generated_audio", "where generate writes generated.wav"),
+    (("-s", "--seconds"), float, 1.0, "length of the generated audio"),
+    (("--lr",), float, 0.001, "learning_rate"),
+    (("--fast",), None, False, "FasterWaveNet: queue-cached generation"),
+    (("--seed",), int, None, "numpy seed (crops, sampling)"),
+)
+_LOOP_FLAGS = (
+    (("--batch-size",), int, 16, "train.py:112"),
+    (("--train-width",), int, 500, "train.py:113"),
+    (("--max-epoch",), int, 2000, "train.py:114 (epochs run 1 .. max_epoch - 1)"),
+    (("--repeat",), int, 500, "updates per file per epoch (train.py:124)"),
+    (("--no-graph",), None, False, "launch every update op by op instead of replaying a HIP graph"),
+)
+
 
 def build_parser() -> argparse.ArgumentParser:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("-g", "--gpu_device", type=int, default=0)
-    ap.add_argument("-w", "--wav-dir", type=str, default="wav")
-    ap.add_argument("-m", "--model-dir", type=str, default="model")
-    # generation
-    ap.add_argument("-o", "--output_dir", type=str, default="generated_audio")
-    ap.add_argument("-s", "--seconds", type=float, default=1.0)
-    ap.add_argument("--lr", type=float, default=0.001, help="learning_rate")
-    ap.add_argument("--fast", action="store_true", default=False)
-    ap.add_argument("--seed", type=int, default=None)
-    # the reference's constants (train.py:112-114, 124)
-    ap.add_argument("--batch-size", type=int, default=16)
-    ap.add_argument("--train-width", type=int, default=500)
-    ap.add_argument("--max-epoch", type=int, default=2000)
-    ap.add_argument("--repeat", type=int, default=500, help="updates per file per epoch")
-    ap.add_argument("--no-graph", action="store_true", default=False, help="launch every step op by op (no HIP graph)")
+    ap = argparse.ArgumentParser(description=__doc__)
+    for flags, typ, default, text in _REFERENCE_FLAGS + _LOOP_FLAGS:
+        if typ is None:
+            ap.add_argument(*flags, action="store_true", default=default, help=text)
+        else:
+            ap.add_argument(*flags, type=typ, default=default, help=text)
     return ap
 
 
