@@ -237,6 +237,17 @@ int wn_eve_step(float* param, const float* grad, float* m, float* v, int64_t n,
 int wn_adam_step_dev(float* param, const float* grad, float* m, float* v, int64_t n,
                      const float* lr_t_dev, float beta1, float beta2, float eps, float weight_decay,
                      const float* sqnorm, float clip, float grad_mult, void* stream);
+/* Arithmetic of the channel GEMMs (skip sum, head, the wide-layer path of wn_layer_* / wn_stack_* for widths other
+ * than 32/32/2, and their backward).  The reference computes them in fp32 (cuDNN/cuBLAS); here
+ *   WN_GEMM_FP32    fp32-input MFMA                                        (exact fp32 products)
+ *   WN_GEMM_BF16X3  every operand split into three bf16 parts, six products (fp32-accurate; the default)
+ *   WN_GEMM_BF16    operands rounded to bf16 once, fp32 accumulation       (BASELINE config 5's arithmetic)
+ * Process-wide; the start value can also be set with WAVENET_HIP_GEMM=fp32|bf16x3|bf16.  Storage stays fp32.  The fused
+ * 32-channel layer kernels always multiply in fp32.                                                              */
+enum { WN_GEMM_FP32 = 0, WN_GEMM_BF16X3 = 1, WN_GEMM_BF16 = 2 };
+int wn_set_gemm_precision(int mode);
+int wn_get_gemm_precision(void);
+
 /* The other update rules get_optimizer() names (wavenet.py:81-97; chainer.optimizers.SGD / MomentumSGD / AdaGrad /
  * AdaDelta / NesterovAG / RMSprop as Chainer publishes them), behind the same hooks as wn_adam_step:
  *   SGD          p -= lr g                                  MomentumSGD  v = hyper v - lr g; p += v

@@ -311,11 +311,24 @@ def train_step_grads(p, weights, idx_in, target, dtype=torch.float32):
 # the model, closed form (numpy) -- independent second formulation
 # --------------------------------------------------------------------------
 
+def bf16_round(a: np.ndarray) -> np.ndarray:
+    """float32 -> nearest bfloat16 (ties to even), returned as float32: what a matrix core sees of an operand in
+    BASELINE config 5's arithmetic (bf16 operands, fp32 accumulation)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = ((u >> np.uint32(16)) & np.uint32(1)) + np.uint32(0x7FFF)
+    return ((u + r) & np.uint32(0xFFFF0000)).view(np.float32)
+
+
 def forward_closed(p, weights, x, dtype=np.float32, compat_zero_prefix=True, head_act="relu",
-                   apply_softmax=False, keep=None):
+                   apply_softmax=False, keep=None, round_operands=None):
     """Same maths as RefWaveNet.forward_one_step via the closed form; returns
     (causal_out, residual_out, sum_skip, head_out).  ``keep`` (a list) receives
-    per-layer (out, z) when given."""
+    per-layer (out, z) when given.  ``round_operands`` (e.g. :func:`bf16_round`) is applied to both operands of every
+    channel contraction after the causal embedding (which is a table lookup, not a product); sums stay in ``dtype``."""
+    if round_operands is not None:
+        rq = round_operands
+        ro = dict(compat_zero_prefix=compat_zero_prefix, head_act=head_act, apply_softmax=apply_softmax, keep=keep)
+        return _forward_closed_rounded(p, weights, x, dtype, rq, **ro)
     w = {k: v.astype(dtype) for k, v in weights.items()}
     out = x.astype(dtype)
     fw = p["causal_conv_filter_width"]
@@ -346,6 +359,44 @@ def forward_closed(p, weights, x, dtype=np.float32, compat_zero_prefix=True, hea
     for i in range(len(p["softmax_conv_channels"]) - 1):
         h = np.maximum(h, 0) if head_act == "relu" else _elu_n(h)
         h = np.einsum("oc,bcht->boht", w["softmax_%d/W" % i][:, :, 0, 0], h)
+        if "softmax_%d/b" % i in w:
+            h = h + w["softmax_%d/b" % i].reshape(1, -1, 1, 1)
+    if apply_softmax:
+        h = softmax_axis1(h)
+    return causal, out, total, h
+
+
+def _forward_closed_rounded(p, weights, x, dtype, rq, compat_zero_prefix, head_act, apply_softmax, keep):
+    w = {k: v.astype(dtype) for k, v in weights.items()}
+    out = x.astype(dtype)
+    fw = p["causal_conv_filter_width"]
+    for i in range(len(p["causal_conv_channels"])):
+        out = dilated_conv_closed(out, w["causal_%d/W" % i], w.get("causal_%d/b" % i), 1, fw)
+    causal = out
+    fw = p["residual_conv_filter_width"]
+    total = None
+    for blk in range(p["residual_num_blocks"]):
+        for li in range(len(p["residual_conv_channels"])):
+            pre = "residual_%d_block_%d_" % (blk, li)
+            d = fw ** li
+            xr = rq(out)
+            a = dilated_conv_closed(xr, rq(w[pre + "wf/W"]), w.get(pre + "wf/b"), d, fw, compat_zero_prefix)
+            g = dilated_conv_closed(xr, rq(w[pre + "wg/W"]), w.get(pre + "wg/b"), d, fw, compat_zero_prefix)
+            z = (np.tanh(a) * _sigmoid_n(g)).astype(dtype)
+            zr = rq(z)
+            o = np.einsum("oc,bcht->boht", rq(w[pre + "projection_block/W"][:, :, 0, 0]), zr) + out
+            s = np.einsum("oc,bcht->boht", rq(w[pre + "projection_softmax/W"][:, :, 0, 0]), zr)
+            if pre + "projection_block/b" in w:
+                o = o + w[pre + "projection_block/b"].reshape(1, -1, 1, 1)
+                s = s + w[pre + "projection_softmax/b"].reshape(1, -1, 1, 1)
+            out = o.astype(dtype)
+            total = s if total is None else total + s
+            if keep is not None:
+                keep.append((out, z))
+    h = total
+    for i in range(len(p["softmax_conv_channels"]) - 1):
+        h = np.maximum(h, 0) if head_act == "relu" else _elu_n(h)
+        h = np.einsum("oc,bcht->boht", rq(w["softmax_%d/W" % i][:, :, 0, 0]), rq(h.astype(dtype)))
         if "softmax_%d/b" % i in w:
             h = h + w["softmax_%d/b" % i].reshape(1, -1, 1, 1)
     if apply_softmax:

@@ -7,4 +7,4 @@ from .wavenet import Params, WaveNet, zero_prefix      # noqa: F401
 from .faster_wavenet import FasterWaveNet              # noqa: F401
 from . import data                                     # noqa: F401
 from .graph import TrainStepGraph                      # noqa: F401
-from ._lib import WaveNetHipError                      # noqa: F401
+from ._lib import WaveNetHipError, set_gemm_precision, get_gemm_precision   # noqa: F401

@@ -79,6 +79,8 @@ _SIGS = {
     "wn_mulaw_decode": (_i, [_p, _p, _p, _i64, _i, _p]),
     "wn_eve_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _f, _f, _p]),
     "wn_rule_step": (_i, [_i, _p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _p, _f, _f, _p]),
+    "wn_set_gemm_precision": (_i, [_i]),
+    "wn_get_gemm_precision": (_i, []),
     "wn_prof_enable": (_i, [_i]),
     "wn_prof_report": (_i, [C.c_char_p, _i]),
 }
@@ -161,3 +163,19 @@ def int_array(vals: Sequence[int]) -> "C.Array":
 def stream_ptr() -> Optional[int]:
     import torch
     return torch.cuda.current_stream().cuda_stream or None
+
+
+GEMM_PRECISIONS = ("fp32", "bf16x3", "bf16")
+
+
+def set_gemm_precision(name: str) -> None:
+    """Arithmetic of the channel GEMMs (``wn_set_gemm_precision``): "fp32" (fp32 MFMA), "bf16x3" (three-way bf16 split,
+    fp32-accurate; the default) or "bf16" (operands rounded to bf16, fp32 accumulation: BASELINE config 5's arithmetic).
+    Process-wide; call it before capturing a TrainStepGraph (a captured graph keeps the kernels it was captured with)."""
+    if name not in GEMM_PRECISIONS:
+        raise ValueError("precision must be one of %r" % (GEMM_PRECISIONS,))
+    check(lib().wn_set_gemm_precision(GEMM_PRECISIONS.index(name)), "wn_set_gemm_precision")
+
+
+def get_gemm_precision() -> str:
+    return GEMM_PRECISIONS[lib().wn_get_gemm_precision()]

@@ -284,4 +284,16 @@ int wn_rule_step(int rule, float* param, const float* grad, float* s1, float* s2
                         as_stream(stream));
 }
 
+int wn_set_gemm_precision(int mode) {
+    WN_CHECK_ARG(mode >= WN_GEMM_FP32 && mode <= WN_GEMM_BF16, "wn_set_gemm_precision: mode must be 0, 1 or 2");
+    if (force_generic() && mode != WN_GEMM_FP32) {
+        wn::set_error("wn_set_gemm_precision: WAVENET_HIP_FORCE_GENERIC=1 pins the fp32 kernels");
+        return WN_EARG;
+    }
+    wn::set_gemm_mode(mode);
+    return WN_OK;
+}
+
+int wn_get_gemm_precision(void) { return wn::gemm_mode(); }
+
 }  // extern "C"

@@ -26,15 +26,24 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 static constexpr int kTileElems = 2 * 3 * 64 * 8;          // bf16 elements of one tile image: [ks][comp][lane][8]
 static constexpr int kTileBytes = kTileElems * 2;          // 6144
 
-bool gemm_b3_enabled() {
-    static int v = -1;
-    if (v < 0) {
+// 0 = fp32 MFMA (mfma_gemm.hip), 1 = bf16x3 (six terms: fp32-accurate, the default), 2 = bf16 (one term: operands
+// rounded to bf16, fp32 accumulation -- BASELINE config 5's arithmetic).  WAVENET_HIP_GEMM=fp32|bf16x3|bf16 sets the
+// start value; wn_set_gemm_precision() changes it at run time.
+static int g_gemm_mode = -1;
+int gemm_mode() {
+    if (g_gemm_mode < 0) {
         const char* e = getenv("WAVENET_HIP_GEMM");
         const char* g = getenv("WAVENET_HIP_FORCE_GENERIC");
-        v = ((e && strcmp(e, "fp32") == 0) || (g && g[0] == '1')) ? 0 : 1;
+        int v = 1;
+        if ((e && strcmp(e, "fp32") == 0) || (g && g[0] == '1')) v = 0;
+        else if (e && strcmp(e, "bf16") == 0) v = 2;
+        g_gemm_mode = v;
     }
-    return v == 1;
+    return g_gemm_mode;
 }
+void set_gemm_mode(int m) { g_gemm_mode = m; }
+bool gemm_b3_enabled() { return gemm_mode() >= 1; }
+static bool one_term() { return gemm_mode() == 2; }
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
     h = (__bf16)x;
@@ -93,7 +102,7 @@ __device__ __forceinline__ float act_apply_t(float x) {
     return x;
 }
 
-template <int MODE, int ACT>
+template <int MODE, int ACT, bool ONE>
 __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* __restrict__ img, int mtiles,
                                                        int nchunks, int chunks_per_src) {
     constexpr int MT = 4;
@@ -187,11 +196,13 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
                 const bf16x8 am = *reinterpret_cast<const bf16x8*>(p + 1024);
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(p + 2048);
                 // smallest terms first
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[ks], acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[ks], acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xm[ks], acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xh[ks], acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xm[ks], acc[mt], 0, 0, 0);
+                if (!ONE) {
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[ks], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xl[ks], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xm[ks], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, xh[ks], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xm[ks], acc[mt], 0, 0, 0);
+                }
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[ks], acc[mt], 0, 0, 0);
             }
         }
@@ -263,8 +274,14 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     if (!img) { wn::set_error("colgemm_b3: cannot allocate %zu bytes of weight scratch", bytes); return WN_EHIP; }
     hipLaunchKernelGGL(k_split_w, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img);
     dim3 grid(cdiv(a.N, 128), cdiv(mtiles, 4));
-#define CG_LAUNCH(MODE_, ACT_) \
-    hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_>), grid, dim3(256), 0, s, a, (const __bf16*)img, mtiles, nchunks, cps)
+    const bool one = one_term();
+#define CG_LAUNCH(MODE_, ACT_)                                                                                          \
+    do {                                                                                                                \
+        if (one) hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, true>), grid, dim3(256), 0, s, a, (const __bf16*)img,    \
+                                    mtiles, nchunks, cps);                                                              \
+        else hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, false>), grid, dim3(256), 0, s, a, (const __bf16*)img,       \
+                                mtiles, nchunks, cps);                                                                  \
+    } while (0)
     if (mode == 0) {
         if (a.act == WN_ACT_RELU) CG_LAUNCH(0, WN_ACT_RELU);
         else if (a.act == WN_ACT_ELU) CG_LAUNCH(0, WN_ACT_ELU);
@@ -287,7 +304,7 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
 //     A-operand image layout as above; raw loads of chunk c+1 are in flight during the MFMAs of chunk c;
 //   * B (one 32-channel tile per wave): eight dword loads per lane per k-step, split in registers.
 // =============================================================================================
-template <int MT, bool HAS_B2, int ACT>
+template <int MT, bool HAS_B2, int ACT, bool ONE>
 __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[MT * kTileBytes];          // one 32-row chunk of A, split
     constexpr int NF = MT / 2 > 0 ? MT / 2 : 1;             // A fragments per thread per chunk (MT*128 / 256)
@@ -413,11 +430,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
                 const bf16x8 xh = *reinterpret_cast<const bf16x8*>(q);
                 const bf16x8 xm = *reinterpret_cast<const bf16x8*>(q + 1024);
                 const bf16x8 xl = *reinterpret_cast<const bf16x8*>(q + 2048);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh[ks], acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl[ks], acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm[ks], acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh[ks], acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm[ks], acc[mt], 0, 0, 0);
+                if (!ONE) {
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh[ks], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl[ks], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm[ks], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh[ks], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm[ks], acc[mt], 0, 0, 0);
+                }
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh[ks], acc[mt], 0, 0, 0);
             }
         }
@@ -439,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
 // barrier per chunk), and every wave runs 96 MFMAs per chunk on its own problem's B values.
 // Grid: x = batch * row slabs, y = ceil(nprob / 8); M == 256.
 // ---------------------------------------------------------------------------------------------
-template <bool HAS_B2, int ACT>
+template <bool HAS_B2, int ACT, bool ONE>
 __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
     constexpr int MT = 8;
     extern __shared__ __attribute__((aligned(16))) char ldsw[];               // 2 x MT x 6 KB
@@ -552,11 +571,13 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
                 const bf16x8 xh = *reinterpret_cast<const bf16x8*>(q);
                 const bf16x8 xm = *reinterpret_cast<const bf16x8*>(q + 1024);
                 const bf16x8 xl = *reinterpret_cast<const bf16x8*>(q + 2048);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh[ks], acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl[ks], acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm[ks], acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh[ks], acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm[ks], acc[mt], 0, 0, 0);
+                if (!ONE) {
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh[ks], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl[ks], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bm[ks], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, bh[ks], acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bm[ks], acc[mt], 0, 0, 0);
+                }
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh[ks], acc[mt], 0, 0, 0);
             }
         }
@@ -575,7 +596,9 @@ int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
 #define W_ATTR(B2_, ACT_)                                                                               \
-    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_b3w<B2_, ACT_>),                    \
+    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_b3w<B2_, ACT_, false>),             \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * kTileBytes));        \
+    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_b3w<B2_, ACT_, true>),              \
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * kTileBytes))
         W_ATTR(false, WN_ACT_NONE); W_ATTR(false, WN_ACT_RELU); W_ATTR(false, WN_ACT_ELU);
         W_ATTR(true, WN_ACT_NONE); W_ATTR(true, WN_ACT_RELU); W_ATTR(true, WN_ACT_ELU);
@@ -596,7 +619,12 @@ int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
     for (int q = 0; q < a.nprob; ++q) { any_b2 |= a.B2p[q] != nullptr; all_b2 &= a.B2p[q] != nullptr; }
     if (any_b2 != all_b2) { wn::set_error("wgrad_b3w: the B2 factor must be given for all problems or for none"); return WN_EARG; }
     const dim3 grid(a.nB * a.wgs_per_b, gy);
-#define W_LAUNCH(B2_, ACT_) hipLaunchKernelGGL((k_wgrad_b3w<B2_, ACT_>), grid, dim3(512), 2 * 8 * kTileBytes, s, a)
+    const bool one = one_term();
+#define W_LAUNCH(B2_, ACT_)                                                                                     \
+    do {                                                                                                        \
+        if (one) hipLaunchKernelGGL((k_wgrad_b3w<B2_, ACT_, true>), grid, dim3(512), 2 * 8 * kTileBytes, s, a);  \
+        else hipLaunchKernelGGL((k_wgrad_b3w<B2_, ACT_, false>), grid, dim3(512), 2 * 8 * kTileBytes, s, a);     \
+    } while (0)
 #define W_LAUNCH_A(B2_)                                           \
     do {                                                          \
         if (a.act == WN_ACT_RELU) W_LAUNCH(B2_, WN_ACT_RELU);     \
@@ -615,11 +643,17 @@ int launch_wgrad_b3(const WGArgs& a, int mt, dim3 grid, hipStream_t s) {
     bool any_b2 = false, all_b2 = true;
     for (int q = 0; q < a.nprob; ++q) { any_b2 |= a.B2p[q] != nullptr; all_b2 &= a.B2p[q] != nullptr; }
     if (any_b2 != all_b2) { wn::set_error("wgrad_b3: the B2 factor must be given for all problems or for none"); return WN_EARG; }
+    const bool one = one_term();
+#define WG_LAUNCH_T(MT_, B2_, ACT_)                                                                     \
+    do {                                                                                                \
+        if (one) hipLaunchKernelGGL((k_wgrad_b3<MT_, B2_, ACT_, true>), grid, dim3(256), 0, s, a);      \
+        else hipLaunchKernelGGL((k_wgrad_b3<MT_, B2_, ACT_, false>), grid, dim3(256), 0, s, a);         \
+    } while (0)
 #define WG_LAUNCH_A(MT_, B2_)                                                                           \
     do {                                                                                                \
-        if (a.act == WN_ACT_RELU) hipLaunchKernelGGL((k_wgrad_b3<MT_, B2_, WN_ACT_RELU>), grid, dim3(256), 0, s, a);     \
-        else if (a.act == WN_ACT_ELU) hipLaunchKernelGGL((k_wgrad_b3<MT_, B2_, WN_ACT_ELU>), grid, dim3(256), 0, s, a);  \
-        else hipLaunchKernelGGL((k_wgrad_b3<MT_, B2_, WN_ACT_NONE>), grid, dim3(256), 0, s, a);         \
+        if (a.act == WN_ACT_RELU) WG_LAUNCH_T(MT_, B2_, WN_ACT_RELU);                                   \
+        else if (a.act == WN_ACT_ELU) WG_LAUNCH_T(MT_, B2_, WN_ACT_ELU);                                \
+        else WG_LAUNCH_T(MT_, B2_, WN_ACT_NONE);                                                        \
     } while (0)
 #define WG_LAUNCH(MT_)                                                                              \
     do {                                                                                            \
@@ -632,6 +666,7 @@ int launch_wgrad_b3(const WGArgs& a, int mt, dim3 grid, hipStream_t s) {
         case 1: WG_LAUNCH(1); break;
         default: wn::set_error("wgrad_b3: unsupported tile count %d", mt); return WN_ESHAPE;
     }
+#undef WG_LAUNCH_T
 #undef WG_LAUNCH_A
 #undef WG_LAUNCH
     WN_LAUNCH_CHECK();
