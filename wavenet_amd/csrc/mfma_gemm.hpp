@@ -22,6 +22,13 @@ struct CGArgs {
     const float* gate_x; int gate_act;         // out *= act'(gate_x[n][m])   (dx of a pre-activated conv)
     const float* residual;           // out += residual[n][m] (row stride ldo), may be NULL
     int accumulate;
+    // gate mode (bf16x3/bf16 kernel, mode 3): rows of W (filter) and W2 (gate) are interleaved tile by tile, the epilogue
+    // writes f = tanh(a), s = sigmoid(g), z = f s (row stride M) and zeroes columns with t < gate_Z (the reference's zero
+    // prefix: a = g = 0 there).  gate_f / gate_s may be NULL (inference).
+    const float* W2[WN_MAX_SRC];
+    const float* bias2[WN_MAX_SRC];
+    float* gate_z; float* gate_f; float* gate_s;
+    int gate_Z;
 };
 
 

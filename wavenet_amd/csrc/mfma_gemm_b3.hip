@@ -67,6 +67,11 @@ __global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __
         k0 = (c - src * chunks_per_src) * 32;
         W = a.W[src] + (long long)(t * 32) * a.wsm[src];
         wsm = a.wsm[src];
+    } else if (mode == 3) {            // m-tile 2i = filter rows 32i.., m-tile 2i+1 = gate rows 32i..
+        const int src = c / chunks_per_src;
+        k0 = (c - src * chunks_per_src) * 32;
+        W = ((t & 1) ? a.W2[src] : a.W[src]) + (long long)((t >> 1) * 32) * a.wsm[src];
+        wsm = a.wsm[src];
     } else {
         k0 = c * 32;
         W = a.W[t];
@@ -128,6 +133,17 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    if (MODE == 3) {
+        for (int src = 0; src < a.nsrc; ++src)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float* bb = (mt & 1) ? a.bias2[src] : a.bias[src];
+                if (bb && t0 + mt < mtiles) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][r] += bb[((t0 + mt) >> 1) * 32 + b3_ch(r, h)];
+                }
+            }
+    }
     if (MODE == 0) {
         for (int src = 0; src < a.nsrc; ++src)
             if (a.bias[src]) {
@@ -152,8 +168,8 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
     };
     float4 xr[4];
     auto load_x = [&](int c) {
-        const int src = MODE == 0 ? c / chunks_per_src : 0;
-        const int k0 = (MODE == 0 ? c - src * chunks_per_src : c) * 32;
+        const int src = (MODE == 0 || MODE == 3) ? c / chunks_per_src : 0;
+        const int k0 = ((MODE == 0 || MODE == 3) ? c - src * chunks_per_src : c) * 32;
         const int rs = rbase + a.soff[src];
         const bool rv = rs >= 0 && rs < a.rows_src_per_b;
         ms_next = rv ? 1.f : 0.f;
@@ -208,6 +224,30 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
         }
     }
     if (!nvalid) return;
+    if (MODE == 3) {
+        const bool live = rbase - a.off >= a.gate_Z;               // rbase - off = t of this column
+#pragma unroll
+        for (int pr = 0; pr < MT / 2; ++pr) {
+            if (t0 + 2 * pr >= mtiles) break;
+            const long long o = no * a.M + ((t0 >> 1) + pr) * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float f4[4], s4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f4[e] = fast_tanh(live ? acc[2 * pr][4 * q + e] : 0.f);
+                    s4[e] = fast_sigmoid(live ? acc[2 * pr + 1][4 * q + e] : 0.f);
+                }
+                *reinterpret_cast<float4*>(a.gate_z + o + 8 * q) =
+                    make_float4(f4[0] * s4[0], f4[1] * s4[1], f4[2] * s4[2], f4[3] * s4[3]);
+                if (a.gate_f) {
+                    *reinterpret_cast<float4*>(a.gate_f + o + 8 * q) = make_float4(f4[0], f4[1], f4[2], f4[3]);
+                    *reinterpret_cast<float4*>(a.gate_s + o + 8 * q) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (t0 + mt >= mtiles) break;
@@ -254,13 +294,13 @@ static void* scratch_for(hipStream_t s, size_t bytes) {
 }
 
 int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
-    if (mode != 0 && mode != 2) return WN_ESHAPE;
+    if (mode != 0 && mode != 2 && mode != 3) return WN_ESHAPE;
     int mtiles, nchunks, cps;
-    if (mode == 0) {
+    if (mode == 0 || mode == 3) {
         if (a.M % 32) return WN_ESHAPE;
         for (int i = 0; i < a.nsrc; ++i)
             if (a.K[i] != a.K[0] || a.K[i] % 32) return WN_ESHAPE;
-        mtiles = a.M / 32;
+        mtiles = (mode == 3 ? 2 : 1) * a.M / 32;
         cps = a.K[0] / 32;
         nchunks = a.nsrc * cps;
     } else {
@@ -282,7 +322,10 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
         else hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, false>), grid, dim3(256), 0, s, a, (const __bf16*)img,       \
                                 mtiles, nchunks, cps);                                                                  \
     } while (0)
-    if (mode == 0) {
+    if (mode == 3) {
+        if (a.act != WN_ACT_NONE || !a.gate_z) { wn::set_error("colgemm_b3: gate mode takes no activation and needs gate_z"); return WN_EARG; }
+        CG_LAUNCH(3, WN_ACT_NONE);
+    } else if (mode == 0) {
         if (a.act == WN_ACT_RELU) CG_LAUNCH(0, WN_ACT_RELU);
         else if (a.act == WN_ACT_ELU) CG_LAUNCH(0, WN_ACT_ELU);
         else if (a.act == WN_ACT_NONE) CG_LAUNCH(0, WN_ACT_NONE);

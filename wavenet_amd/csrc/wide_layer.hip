@@ -67,10 +67,30 @@ int wide_layer_fwd(const float* x, const float* Wf, const float* bf, const float
                    const float* bp, float* out, float* z, float* fs, float* gs, int B, int T, int Cr, int Cd, int fw,
                    int d, int Z, hipStream_t s) {
     // pre-activations go where f / sigmoid(g) will live (training) or into z / out (inference, needs Cd <= Cr)
+    int rc;
+    if (gemm_b3_enabled() && Cd % 64 == 0) {
+        // one launch for both convolutions and the gate: the rows of Wf and Wg interleaved tile by tile, tanh / sigmoid /
+        // product in the epilogue -- x is read once per tap, the pre-activations never reach memory
+        CGArgs a{};
+        base_args(a, B, T);
+        a.nsrc = fw;
+        for (int k = 0; k < fw; ++k) {
+            a.X[k] = x; a.K[k] = Cr; a.W[k] = Wf + k; a.W2[k] = Wg + k; a.wsm[k] = Cr * fw; a.soff[k] = -(fw - 1 - k) * d;
+            a.bias[k] = k == 0 ? bf : nullptr; a.bias2[k] = k == 0 ? bg : nullptr;
+        }
+        a.wsk = fw; a.M = Cd; a.ldo = Cd; a.out[0] = z;
+        a.gate_z = z; a.gate_f = fs; a.gate_s = gs; a.gate_Z = Z;
+        if ((rc = launch_colgemm_b3(a, 3, 1, s))) return rc;
+        CGArgs b{};
+        base_args(b, B, T);
+        b.nsrc = 1; b.X[0] = z; b.K[0] = Cd; b.W[0] = Wp; b.wsm[0] = Cd; b.wsk = 1; b.bias[0] = bp;
+        b.M = Cr; b.ldo = Cr; b.out[0] = out; b.residual = x;
+        return launch_colgemm_multi(b, s);
+    }
     float* abuf = fs ? fs : z;
     float* gbuf = gs ? gs : out;
     if (!gs && Cd > Cr) { wn::set_error("wide_layer_fwd: inference needs Cd <= Cr"); return WN_ESHAPE; }
-    int rc = conv_gemm(x, Wf, bf, abuf, B, T, Cr, Cd, fw, d, s);
+    rc = conv_gemm(x, Wf, bf, abuf, B, T, Cr, Cd, fw, d, s);
     if (rc) return rc;
     rc = conv_gemm(x, Wg, bg, gbuf, B, T, Cr, Cd, fw, d, s);
     if (rc) return rc;
