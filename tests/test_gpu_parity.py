@@ -60,7 +60,8 @@ def _run_layer(x, Wf, Wg, Wp, b, Z, Cr, Cd, fw, d, save):
 @pytest.mark.parametrize("Cr,Cd,fw,d,B,T,bias", [
     (16, 16, 2, 1, 1, 50, False), (16, 16, 2, 8, 2, 100, True), (8, 12, 3, 9, 2, 77, True), (5, 3, 2, 4, 1, 7, False),
     (128, 32, 2, 16, 1, 300, False), (24, 24, 2, 512, 1, 600, True), (6, 6, 4, 4, 1, 10, False),
-    (64, 32, 3, 9, 2, 211, True), (128, 128, 2, 64, 1, 333, False), (32, 64, 2, 4, 2, 100, True), (32, 32, 3, 3, 1, 65, False)])
+    (64, 32, 3, 9, 2, 211, True), (128, 128, 2, 64, 1, 333, False), (32, 64, 2, 4, 2, 100, True), (32, 32, 3, 3, 1, 65, False),
+    (128, 128, 2, 8, 2, 300, True), (64, 128, 3, 9, 2, 211, True), (32, 192, 2, 4, 1, 90, False)])
 def test_layer_fwd_generic(Cr, Cd, fw, d, B, T, bias):
     """Shapes outside the fused 32/32/2 kernel: the generic kernels, and (widths multiple of 32) the composite
     matrix-core path of wide_layer.hip; inference (no f/g) and training (f/g saved) variants."""
@@ -691,7 +692,10 @@ def _layer_bwd_ref(x, Wf, Wg, Wp, b, Z, d, fw, dout, dzs):
     (32, 32, 2, 64, 1, 31, True, True), (32, 32, 2, 256, 1, 2048, False, True),
     (16, 12, 3, 9, 2, 77, True, True), (8, 8, 2, 4, 1, 40, False, False),
     (64, 32, 3, 9, 2, 211, True, True), (128, 128, 2, 64, 1, 333, False, True), (32, 64, 2, 4, 2, 100, True, False),
-    (32, 32, 3, 3, 1, 65, False, True)])
+    (32, 32, 3, 3, 1, 65, False, True),
+    # Cd = 128: [da | dg] in one array, gate-backward epilogue, all tap gradients in one wide launch
+    (128, 128, 2, 8, 2, 300, True, True), (128, 128, 2, 512, 3, 700, False, False), (64, 128, 3, 9, 2, 211, True, True),
+    (256, 128, 2, 2, 1, 97, False, True)])
 def test_layer_bwd(Cr, Cd, fw, d, B, T, bias, with_dout):
     """wn_layer_bwd: MFMA path (32/32/2) and generic path against float64 autograd."""
     rs = np.random.RandomState(T + d)

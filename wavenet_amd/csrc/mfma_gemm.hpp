@@ -5,6 +5,8 @@
 
 namespace wn {
 
+static constexpr int WN_GATE_TAPS = 8;      // taps of a gate-mode launch (nsrc <= this)
+
 struct CGArgs {
     const float* X[WN_MAX_SRC];      // per source
     const float* W[WN_MAX_SRC];      // per source (multi-source) or per problem (multi-problem)
@@ -25,10 +27,14 @@ struct CGArgs {
     // gate mode (bf16x3/bf16 kernel, mode 3): rows of W (filter) and W2 (gate) are interleaved tile by tile, the epilogue
     // writes f = tanh(a), s = sigmoid(g), z = f s (row stride M) and zeroes columns with t < gate_Z (the reference's zero
     // prefix: a = g = 0 there).  gate_f / gate_s may be NULL (inference).
-    const float* W2[WN_MAX_SRC];
-    const float* bias2[WN_MAX_SRC];
+    // gate-backward mode (mode 4): the GEMM result is dz (+ residual = dz_skip); the epilogue reads f = gate_f, s = gate_s
+    // (row stride M) and writes da = dz s (1 - f^2) | dg = dz f s (1 - s) side by side into gate_z (row stride 2 M),
+    // zero for t < gate_Z.
+    const float* W2[WN_GATE_TAPS];
+    const float* bias2[WN_GATE_TAPS];
     float* gate_z; float* gate_f; float* gate_s;
     int gate_Z;
+    int ldx;                         // row stride of every X source when != 0 (default: K[src])
 };
 
 
@@ -42,6 +48,11 @@ struct WGArgs {
     int nB, rows_A_per_b, rows_B_per_b, off;   // B row = b*rows_B_per_b + r + off for A row b*rows_A_per_b + r
     int act;
     int rows_per_wg, wgs_per_b;
+    // wide block only: per-problem extra row shift of B, and a second output for the rows m >= m_split of A
+    // (A = [da | dg]: rows below m_split accumulate into out[p], the others into out2[p] at row m - m_split)
+    int offp[WN_MAX_SRC];
+    float* out2[WN_MAX_SRC];
+    int m_split;
 };
 
 // 1 unless WAVENET_HIP_GEMM=fp32: contractions use three-way bf16 splits (6 bf16 MFMAs per product term)

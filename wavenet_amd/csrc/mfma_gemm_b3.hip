@@ -62,7 +62,7 @@ __global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __
     const int i = threadIdx.x & 31, c4 = threadIdx.x >> 5;           // row, group of 4 consecutive k
     const float* W;
     int wsm, k0;
-    if (mode == 0) {
+    if (mode == 0 || mode == 4) {
         const int src = c / chunks_per_src;
         k0 = (c - src * chunks_per_src) * 32;
         W = a.W[src] + (long long)(t * 32) * a.wsm[src];
@@ -168,12 +168,12 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
     };
     float4 xr[4];
     auto load_x = [&](int c) {
-        const int src = (MODE == 0 || MODE == 3) ? c / chunks_per_src : 0;
-        const int k0 = ((MODE == 0 || MODE == 3) ? c - src * chunks_per_src : c) * 32;
+        const int src = (MODE == 0 || MODE >= 3) ? c / chunks_per_src : 0;
+        const int k0 = ((MODE == 0 || MODE >= 3) ? c - src * chunks_per_src : c) * 32;
         const int rs = rbase + a.soff[src];
         const bool rv = rs >= 0 && rs < a.rows_src_per_b;
         ms_next = rv ? 1.f : 0.f;
-        const float* __restrict__ Xb = a.X[src] + (rb0 + (rv ? rs : 0)) * a.K[src] + k0 + 8 * h;
+        const float* __restrict__ Xb = a.X[src] + (rb0 + (rv ? rs : 0)) * (a.ldx ? a.ldx : a.K[src]) + k0 + 8 * h;
         xr[0] = *reinterpret_cast<const float4*>(Xb);             // k-step 0: channels 8h .. 8h+7
         xr[1] = *reinterpret_cast<const float4*>(Xb + 4);
         xr[2] = *reinterpret_cast<const float4*>(Xb + 16);        // k-step 1: channels 16+8h .. 16+8h+7
@@ -248,6 +248,33 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
         }
         return;
     }
+    if (MODE == 4) {
+        const bool live = rbase - a.off >= a.gate_Z;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            if (t0 + mt >= mtiles) break;
+            const long long ci = no * a.M + (t0 + mt) * 32 + 4 * h;            // f, s, dz_skip: row stride M
+            const long long co = no * 2 * a.M + (t0 + mt) * 32 + 4 * h;        // [da | dg]: row stride 2 M
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 f4 = *reinterpret_cast<const float4*>(a.gate_f + ci + 8 * q);
+                const float4 s4 = *reinterpret_cast<const float4*>(a.gate_s + ci + 8 * q);
+                float4 dz = make_float4(acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
+                if (a.residual) {
+                    const float4 rr = *reinterpret_cast<const float4*>(a.residual + ci + 8 * q);
+                    dz.x += rr.x; dz.y += rr.y; dz.z += rr.z; dz.w += rr.w;
+                }
+                if (!live) dz = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(a.gate_z + co + 8 * q) =
+                    make_float4(dz.x * s4.x * (1.f - f4.x * f4.x), dz.y * s4.y * (1.f - f4.y * f4.y),
+                                dz.z * s4.z * (1.f - f4.z * f4.z), dz.w * s4.w * (1.f - f4.w * f4.w));
+                *reinterpret_cast<float4*>(a.gate_z + co + a.M + 8 * q) =
+                    make_float4(dz.x * f4.x * s4.x * (1.f - s4.x), dz.y * f4.y * s4.y * (1.f - s4.y),
+                                dz.z * f4.z * s4.z * (1.f - s4.z), dz.w * f4.w * s4.w * (1.f - s4.w));
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (t0 + mt >= mtiles) break;
@@ -294,10 +321,11 @@ static void* scratch_for(hipStream_t s, size_t bytes) {
 }
 
 int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
-    if (mode != 0 && mode != 2 && mode != 3) return WN_ESHAPE;
+    if (mode != 0 && mode != 2 && mode != 3 && mode != 4) return WN_ESHAPE;
     int mtiles, nchunks, cps;
-    if (mode == 0 || mode == 3) {
+    if (mode == 0 || mode == 3 || mode == 4) {
         if (a.M % 32) return WN_ESHAPE;
+        if (mode == 3 && a.nsrc > WN_GATE_TAPS) return WN_ESHAPE;
         for (int i = 0; i < a.nsrc; ++i)
             if (a.K[i] != a.K[0] || a.K[i] % 32) return WN_ESHAPE;
         mtiles = (mode == 3 ? 2 : 1) * a.M / 32;
@@ -325,6 +353,9 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     if (mode == 3) {
         if (a.act != WN_ACT_NONE || !a.gate_z) { wn::set_error("colgemm_b3: gate mode takes no activation and needs gate_z"); return WN_EARG; }
         CG_LAUNCH(3, WN_ACT_NONE);
+    } else if (mode == 4) {
+        if (a.act != WN_ACT_NONE || !a.gate_z || !a.gate_f || !a.gate_s) { wn::set_error("colgemm_b3: gate-backward mode needs f, s and the output"); return WN_EARG; }
+        CG_LAUNCH(4, WN_ACT_NONE);
     } else if (mode == 0) {
         if (a.act == WN_ACT_RELU) CG_LAUNCH(0, WN_ACT_RELU);
         else if (a.act == WN_ACT_ELU) CG_LAUNCH(0, WN_ACT_ELU);
@@ -509,12 +540,13 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
     const int j = lane & 31, h = lane >> 5;
     const int p = blockIdx.y * 8 + wv;
     const bool active = p < a.nprob;
+    const int off = a.off + a.offp[active ? p : 0];            // this wave's problem may carry its own tap shift
     const int b = blockIdx.x / a.wgs_per_b;
     const int r_begin = (blockIdx.x - b * a.wgs_per_b) * a.rows_per_wg;
     const int r_end = min(a.rows_A_per_b, r_begin + a.rows_per_wg);
     const float* __restrict__ Ab = a.A + ((long long)b * a.rows_A_per_b) * a.lda;
-    const float* __restrict__ Bb = a.Bp[active ? p : 0] + ((long long)b * a.rows_B_per_b + a.off) * a.ldb + j;
-    const float* __restrict__ B2b = a.B2p[active ? p : 0] ? a.B2p[active ? p : 0] + ((long long)b * a.rows_B_per_b + a.off) * a.ldb + j : nullptr;
+    const float* __restrict__ Bb = a.Bp[active ? p : 0] + ((long long)b * a.rows_B_per_b + off) * a.ldb + j;
+    const float* __restrict__ B2b = a.B2p[active ? p : 0] ? a.B2p[active ? p : 0] + ((long long)b * a.rows_B_per_b + off) * a.ldb + j : nullptr;
     f32x16 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -531,7 +563,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
     float ar[2][8], br[2][8], b2r[2][8];
     const float* __restrict__ B2s = HAS_B2 ? B2b : Bb;
     auto issue = [&](int r0) {
-        const bool full = r0 + 32 <= r_end && r0 + a.off >= 0 && r0 + 31 + a.off < a.rows_B_per_b;
+        const bool full = r0 + 32 <= r_end && r0 + off >= 0 && r0 + 31 + off < a.rows_B_per_b;
         if (full) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -564,8 +596,8 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
             for (int jj = 0; jj < 8; ++jj) {
                 const int r = r0 + 16 * ks + 8 * h + jj;
                 int rc = r < r_end ? r : r_end - 1;
-                if (rc + a.off < 0) rc = -a.off;
-                if (rc + a.off >= a.rows_B_per_b) rc = a.rows_B_per_b - 1 - a.off;
+                if (rc + off < 0) rc = -off;
+                if (rc + off >= a.rows_B_per_b) rc = a.rows_B_per_b - 1 - off;
                 br[ks][jj] = Bb[(long long)rc * a.ldb];
                 if (HAS_B2) b2r[ks][jj] = B2s[(long long)rc * a.ldb];
             }
@@ -576,7 +608,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
     for (int r0 = r_begin; r0 < r_end; r0 += 32, ++c) {
         char* buf = ldsw + (c & 1) * (MT * kTileBytes);
         bf16x8 bh[2], bm[2], bl[2];
-        const bool edge = !(r0 + 32 <= r_end && r0 + a.off >= 0 && r0 + 31 + a.off < a.rows_B_per_b);
+        const bool edge = !(r0 + 32 <= r_end && r0 + off >= 0 && r0 + 31 + off < a.rows_B_per_b);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 ah, am, al;
@@ -589,7 +621,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
                     const int ra = r0 + 16 * ks + 8 * fhh + e;
                     const int rb = r0 + 16 * ks + 8 * h + e;
                     av *= ra < r_end ? 1.f : 0.f;
-                    bv *= (rb < r_end && rb + a.off >= 0 && rb + a.off < a.rows_B_per_b) ? 1.f : 0.f;
+                    bv *= (rb < r_end && rb + off >= 0 && rb + off < a.rows_B_per_b) ? 1.f : 0.f;
                 }
                 __bf16 x0, x1, x2;
                 split3(av, x0, x1, x2);
@@ -626,12 +658,15 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
         }
     }
     if (!active) return;
-    float* __restrict__ o = a.out[p];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt) {
+        const bool second = a.m_split > 0 && mt * 32 >= a.m_split;
+        float* __restrict__ o = second ? a.out2[p] : a.out[p];
+        const int mrow = mt * 32 - (second ? a.m_split : 0);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-            atomicAdd(o + (long long)(mt * 32 + b3_ch(r, h)) * a.ldo + (long long)j * (a.osk ? a.osk : 1), acc[mt][r]);
+            atomicAdd(o + (long long)(mrow + b3_ch(r, h)) * a.ldo + (long long)j * (a.osk ? a.osk : 1), acc[mt][r]);
+    }
 }
 
 // M == 256 and at least 8 problems: the wide block.  Picks its own row slabs (one workgroup per CU).

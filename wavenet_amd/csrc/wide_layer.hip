@@ -28,17 +28,22 @@ __global__ void k_wide_gate(float* __restrict__ a, float* __restrict__ g, float*
     if (fs) { reinterpret_cast<float4*>(fs)[i] = f; reinterpret_cast<float4*>(gs)[i] = s; }
 }
 
+// ldo4 = output row stride in float4 (Cd/4: da and dg are separate (n, Cd) arrays; Cd/2: they are the two halves of one
+// (n, 2 Cd) array and dg = da + Cd)
 __global__ void k_wide_gate_bwd(const float* __restrict__ dz, const float* __restrict__ f, const float* __restrict__ g,
-                                float* __restrict__ da, float* __restrict__ dg, long long n4, int T, int Cd, int Z) {
+                                float* __restrict__ da, float* __restrict__ dg, long long n4, int T, int Cd, int Z,
+                                int ldo4) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
-    const int t = (int)((i * 4 / Cd) % T);
+    const long long row = i * 4 / Cd;
+    const long long io = row * ldo4 + (i - row * (Cd / 4));
+    const int t = (int)(row % T);
     float4 d = reinterpret_cast<const float4*>(dz)[i];
     if (t < Z) d = make_float4(0, 0, 0, 0);
     const float4 fv = reinterpret_cast<const float4*>(f)[i], gv = reinterpret_cast<const float4*>(g)[i];
-    reinterpret_cast<float4*>(da)[i] = make_float4(d.x * gv.x * (1.f - fv.x * fv.x), d.y * gv.y * (1.f - fv.y * fv.y),
+    reinterpret_cast<float4*>(da)[io] = make_float4(d.x * gv.x * (1.f - fv.x * fv.x), d.y * gv.y * (1.f - fv.y * fv.y),
                                                    d.z * gv.z * (1.f - fv.z * fv.z), d.w * gv.w * (1.f - fv.w * fv.w));
-    reinterpret_cast<float4*>(dg)[i] = make_float4(d.x * fv.x * gv.x * (1.f - gv.x), d.y * fv.y * gv.y * (1.f - gv.y),
+    reinterpret_cast<float4*>(dg)[io] = make_float4(d.x * fv.x * gv.x * (1.f - gv.x), d.y * fv.y * gv.y * (1.f - gv.y),
                                                    d.z * fv.z * gv.z * (1.f - gv.z), d.w * fv.w * gv.w * (1.f - gv.w));
 }
 
@@ -122,11 +127,82 @@ static int conv_wgrad(const float* A, const float* x, float* dW, int B, int T, i
     return WN_OK;
 }
 
+// Cd == 128 (config 5): da and dg live side by side in ONE (n, 256) array, so that
+//   * dz = Wp^T dout + dz_skip and the gate derivative are one launch (GEMM with the gate-backward epilogue),
+//   * all 2 fw weight-gradient contractions of the layer (dWf_k, dWg_k: 256 rows of [da | dg] against the 32-channel
+//     slices of x at fw tap shifts) are ONE launch of the wide 256-row block, which reads [da | dg] once instead of
+//     2 fw times.
+static int wide_layer_bwd_256(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
+                              const float* Wp, const float* dout, const float* dzs, float* dx, float* dWf, float* dbf,
+                              float* dWg, float* dbg, float* dWp, float* dbp, float* ws, int B, int T, int Cr, int Cd,
+                              int fw, int d, int Z, hipStream_t s) {
+    const long long n = (long long)B * T;
+    float* dadg = ws;                // (B,T,2 Cd)
+    int rc;
+    if (dout) {
+        CGArgs a{};
+        base_args(a, B, T);
+        a.nsrc = 1; a.X[0] = dout; a.K[0] = Cr; a.W[0] = Wp; a.wsm[0] = 1; a.wsk = Cd; a.bias[0] = nullptr;
+        a.M = Cd; a.ldo = Cd; a.out[0] = dadg; a.residual = dzs;
+        a.gate_f = const_cast<float*>(f); a.gate_s = const_cast<float*>(g); a.gate_z = dadg; a.gate_Z = Z;
+        if ((rc = launch_colgemm_b3(a, 4, 1, s))) return rc;
+    } else {
+        const long long n4 = n * Cd / 4;
+        hipLaunchKernelGGL(k_wide_gate_bwd, dim3(cdiv(n4, 256)), dim3(256), 0, s, dzs, f, g, dadg, dadg + Cd, n4, T, Cd, Z,
+                           Cd / 2);
+        WN_LAUNCH_CHECK();
+    }
+    if (dx) {                        // dx = dout + sum_k Wf_k^T da[t+(fw-1-k)d] + Wg_k^T dg[t+(fw-1-k)d]
+        CGArgs a{};
+        base_args(a, B, T);
+        a.nsrc = 2 * fw;
+        a.ldx = 2 * Cd;
+        for (int k = 0; k < fw; ++k)
+            for (int w = 0; w < 2; ++w) {
+                const int i = 2 * k + w;
+                a.X[i] = dadg + w * Cd; a.K[i] = Cd; a.W[i] = (w ? Wg : Wf) + k; a.wsm[i] = fw;
+                a.soff[i] = (fw - 1 - k) * d; a.bias[i] = nullptr;
+            }
+        a.wsk = Cr * fw; a.M = Cr; a.ldo = Cr; a.out[0] = dx; a.residual = dout;
+        if ((rc = launch_colgemm_multi(a, s))) return rc;
+    }
+    {                                // dWf[o][c][k] += sum da[n][o] x[n-(fw-1-k)d][c];  dWg likewise from the dg half
+        WGArgs a{};
+        a.A = dadg; a.lda = 2 * Cd; a.nprob = 0; a.m_split = Cd;
+        for (int k = 0; k < fw; ++k)
+            for (int c = 0; c < Cr; c += 32) {
+                const int q = a.nprob++;
+                a.Bp[q] = x + c; a.B2p[q] = nullptr; a.offp[q] = -(fw - 1 - k) * d;
+                a.out[q] = dWf + (long long)c * fw + k; a.out2[q] = dWg + (long long)c * fw + k;
+            }
+        a.ldb = Cr; a.ldo = Cr * fw; a.osk = fw;
+        a.nB = B; a.rows_A_per_b = T; a.rows_B_per_b = T; a.off = 0; a.act = WN_ACT_NONE;
+        if ((rc = launch_wgrad_b3w(a, s))) return rc;
+    }
+    if (dWp && dout) {               // dWp[cr][cd] += sum dout[n][cr] * (f g)[n][cd]
+        WGArgs a{};
+        a.A = dout; a.lda = Cr; a.nprob = 0;
+        for (int c = 0; c < Cd; c += 32) {
+            a.Bp[a.nprob] = f + c; a.B2p[a.nprob] = g + c; a.out[a.nprob] = dWp + c; ++a.nprob;
+        }
+        a.ldb = Cd; a.ldo = Cd; a.osk = 1;
+        a.nB = B; a.rows_A_per_b = T; a.rows_B_per_b = T; a.off = 0; a.act = WN_ACT_NONE;
+        if ((rc = launch_wgrad(a, Cr, s))) return rc;
+    }
+    if (dbf && (rc = generic_colsum(dadg, B, T, 0, 2 * Cd, Cd, dbf, s))) return rc;
+    if (dbg && (rc = generic_colsum(dadg + Cd, B, T, 0, 2 * Cd, Cd, dbg, s))) return rc;
+    if (dbp && dout && (rc = generic_colsum(dout, B, T, 0, Cr, Cr, dbp, s))) return rc;
+    return WN_OK;
+}
+
 int wide_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg, const float* Wp,
                    const float* dout, const float* dzs, float* dx, float* dWf, float* dbf, float* dWg, float* dbg,
                    float* dWp, float* dbp, float* ws, int B, int T, int Cr, int Cd, int fw, int d, int Z,
                    hipStream_t s) {
     const long long n = (long long)B * T;
+    if (gemm_b3_enabled() && 2 * Cd == 256 && Cr % 32 == 0 && (Cr / 32) * fw <= 8 && dWf && dWg)
+        return wide_layer_bwd_256(x, f, g, Wf, Wg, Wp, dout, dzs, dx, dWf, dbf, dWg, dbg, dWp, dbp, ws, B, T, Cr, Cd, fw, d,
+                                  Z, s);
     float* da = ws;                  // (B,T,Cd): dz first, then da in place
     float* dg = ws + n * Cd;         // (B,T,Cd)
     int rc;
@@ -140,7 +216,7 @@ int wide_layer_bwd(const float* x, const float* f, const float* g, const float* 
         dz = da;
     }
     const long long n4 = n * Cd / 4;
-    hipLaunchKernelGGL(k_wide_gate_bwd, dim3(cdiv(n4, 256)), dim3(256), 0, s, dz, f, g, da, dg, n4, T, Cd, Z);
+    hipLaunchKernelGGL(k_wide_gate_bwd, dim3(cdiv(n4, 256)), dim3(256), 0, s, dz, f, g, da, dg, n4, T, Cd, Z, Cd / 4);
     WN_LAUNCH_CHECK();
     if (dx) {                        // dx = dout + sum_k Wf_k^T da[t+(fw-1-k)d] + Wg_k^T dg[t+(fw-1-k)d]
         CGArgs a{};
