@@ -55,6 +55,47 @@ def train_step(net, x, tgt, iw):
     return loss
 
 
+def wide_channel_step(rank, world, steps=5, warmup=2):
+    """BASELINE config 5 as a side measurement (never the headline value): config 2's topology and batch at 128 residual /
+    dilation channels and 512 skip channels, channel GEMMs on bf16 operands with fp32 accumulation
+    (wn_set_gemm_precision(WN_GEMM_BF16); storage is fp32).  Reports the matrix-core rate against the dense bf16 peak."""
+    import wavenet_amd
+    cfg = dict(CFG2)
+    cfg.update(causal_conv_channels=[128], residual_conv_channels=[128] * 10, softmax_conv_channels=[512, 256])
+    before = wavenet_amd.get_gemm_precision()
+    wavenet_amd.set_gemm_precision("bf16")
+    try:
+        net = FasterWaveNet(Params(cfg), seed=1)
+        net.to_gpu()
+        net.update_laerning_rate(1e-3)
+        iw = net.input_width
+        x, tgt = make_batch(rank, world, iw)
+        for _ in range(warmup):
+            train_step(net, x, tgt, iw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = train_step(net, x, tgt, iw)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        nl, n = 40, B_PER_GPU * T
+        # SURVEY 8d: 2 (2 fw Cr Cd + Cd Cr + Cd Cs) flop per sample-layer forward, backward = 2x forward
+        flop = 3 * 2 * (2 * 2 * 128 * 128 + 128 * 128 + 128 * 512) * nl * n
+        res = {"workload": "cfg5: 4x10 layers, 128 residual/dilation + 512 skip channels, batch %d x %d, train fwd+bwd+Adam, "
+                           "op-by-op launches" % (B_PER_GPU, T),
+               "dtype": "bf16 GEMM operands, f32 accumulate, f32 storage", "ms_per_step": dt * 1e3,
+               "samples_per_s": n / dt, "loss": float(loss.detach()),
+               "mfma": {"flop_per_step": flop, "achieved": flop / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": flop / dt / 1e12 / 2500.0,
+                        "note": "memory bound as built: the layer is composed of channel-GEMM launches with fp32 "
+                                "activations in HBM between them"}}
+        del net
+        torch.cuda.empty_cache()
+        return res
+    finally:
+        wavenet_amd.set_gemm_precision(before)
+
+
 def stack_forward(net, c):
     with torch.no_grad():
         return net.forward_residual_block(c)
@@ -125,6 +166,7 @@ def main():
     ap.add_argument("--decode-samples", type=int, default=16000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-wide", action="store_true", help="skip the config-5 (128/512 channels, bf16 operands) side measurement")
     ap.add_argument("--no-graph", action="store_true", help="time op-by-op launches instead of hipGraph replays")
     args = ap.parse_args()
 
@@ -298,6 +340,8 @@ def main():
             out["ar_generate"] = {"samples_per_s": n / ddt, "seconds": ddt, "samples": n,
                                   "workload": "cfg4: faster_wavenet queue-cached decode, window 4094, 1 GPU",
                                   "token_checksum": int(toks.sum().item())}
+        if not args.no_wide:
+            out["wide_channel"] = wide_channel_step(rank, world)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             if "ar_generate" in out:

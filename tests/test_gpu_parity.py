@@ -151,6 +151,30 @@ def test_embed_equals_dense_onehot_conv():
     np.testing.assert_allclose(to_np(b), ref, atol=ATOL)
 
 
+@pytest.mark.parametrize("B,T,Q,C,fw,bias", [(2, 300, 256, 32, 2, False), (3, 257, 256, 128, 2, True), (2, 90, 256, 128, 3, True),
+                                             (1, 50, 64, 24, 3, True), (2, 2000, 256, 256, 2, False), (1, 40, 300, 200, 2, True)])
+def test_embed_bwd_scatter(B, T, Q, C, fw, bias):
+    """wn_embed_bwd against a numpy scatter-add: one LDS table per block, in 32..64-channel slices when the table for all
+    channels does not fit (config 5's 128), global atomics otherwise (the last case)."""
+    rs = np.random.RandomState(C + fw)
+    idx = rs.randint(0, Q, (B, T)).astype(np.int32)
+    dout = rs.standard_normal((B, T, C)).astype(np.float32)
+    want = np.zeros((C, Q, fw), np.float64)
+    for k in range(fw):
+        sh = fw - 1 - k
+        for b in range(B):
+            np.add.at(want[:, :, k].T, idx[b, :T - sh] if sh else idx[b], dout[b, sh:].astype(np.float64))
+    dW = torch.zeros((C, Q, fw), device="cuda")
+    db = torch.zeros((C,), device="cuda") if bias else None
+    idx_d, dout_d = dev(idx), dev(dout)
+    for _ in range(2):                                             # accumulates: two calls = twice the gradient
+        check(_lib.lib().wn_embed_bwd(ptr(idx_d), ptr(dout_d), ptr(dW), ptr(db), B, T, Q, C, fw, None), "wn_embed_bwd")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(to_np(dW), 2 * want, atol=2e-4 * max(1.0, np.abs(want).max()))
+    if bias:
+        np.testing.assert_allclose(to_np(db), 2 * dout.astype(np.float64).sum((0, 1)), atol=1e-3)
+
+
 def _full_forward_check(over, B, T, bias_scale=0.0, seed=1234, **kw):
     p, w, net = build(over, seed=seed, bias_scale=bias_scale, **kw)
     Q = p["quantization_steps"]

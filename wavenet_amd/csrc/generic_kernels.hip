@@ -67,7 +67,9 @@ static constexpr int kEmbU = 8;
 template <int FW>
 __global__ void k_embed_bwd_lds(const int32_t* __restrict__ idx, const float* __restrict__ dout,
                                 float* __restrict__ ws, int has_bias,
-                                int B, int T, int Q, int C, int fw_rt, int cols_per_block) {
+                                int B, int T, int Q, int C, int fw_rt, int cols_per_block, int ldc) {
+    // C is the width of this block's channel slice (blockIdx.y selects it), ldc the row stride of dout: a table for all
+    // 128 channels of config 5 (256 KB) does not fit in LDS, four 32-channel slices do
     extern __shared__ __attribute__((aligned(16))) float tab[];   // [(q*fw+k)][c], then [C] bias
     const int fw = FW > 0 ? FW : fw_rt;
     const int ntab = Q * fw * C;
@@ -78,7 +80,7 @@ __global__ void k_embed_bwd_lds(const int32_t* __restrict__ idx, const float* __
     const long long ncol = (long long)B * T;
     const int ncb = (int)(ncol - col0 < cols_per_block ? ncol - col0 : cols_per_block);
     const int work = ncb * C;
-    const float* __restrict__ src = dout + col0 * C;
+    const float* __restrict__ src = dout + col0 * ldc + (long long)blockIdx.y * C;
     const int b0 = (int)(col0 / T), t00 = (int)(col0 - (long long)b0 * T);
     for (int base = threadIdx.x; base < work; base += blockDim.x * kEmbU) {
         float g[kEmbU];
@@ -89,7 +91,7 @@ __global__ void k_embed_bwd_lds(const int32_t* __restrict__ idx, const float* __
             const int ec = e < work ? e : work - 1;                // clamped load, masked value
             const int colr = ec / C;
             cc[u] = ec - colr * C;
-            g[u] = e < work ? src[ec] : 0.f;
+            g[u] = e < work ? src[(long long)colr * ldc + cc[u]] : 0.f;
             const int tt = t00 + colr;
             const int b = b0 + tt / T, t = tt - (tt / T) * T;
             if (FW > 0) {
@@ -122,7 +124,7 @@ __global__ void k_embed_bwd_lds(const int32_t* __restrict__ idx, const float* __
     __syncthreads();
     // the block's table leaves with plain coalesced stores; k_embed_bwd_reduce sums the tables (256 blocks adding
     // 16k entries each into the same 64 KB with global atomics took 0.2 ms)
-    float* __restrict__ o = ws + (long long)blockIdx.x * (ntab + C);
+    float* __restrict__ o = ws + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (ntab + C);
     for (int i = threadIdx.x; i < ntab + C; i += blockDim.x) o[i] = tab[i];
 }
 
@@ -784,15 +786,19 @@ static void* embed_scratch_for(hipStream_t s, size_t bytes) {
 
 int generic_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* dbias, int B, int T,
                       int Q, int C, int fw, hipStream_t s) {
-    size_t lds = ((size_t)Q * fw * C + C) * sizeof(float);
+    int Cs = C;                                            // channel slice whose table fits in LDS
+    while (((size_t)Q * fw * Cs + Cs) * sizeof(float) > 150 * 1024 && Cs % 2 == 0 && Cs > 8) Cs /= 2;
+    size_t lds = ((size_t)Q * fw * Cs + Cs) * sizeof(float);
     long long ncol = (long long)B * T;
-    if (lds <= 150 * 1024) {
+    if (lds <= 150 * 1024 && C % Cs == 0) {
+        const int nsl = C / Cs;
         long long nb = ncol < 256 * 64 ? (ncol + 63) / 64 : 256;
-        while ((ncol + nb - 1) / nb * C >= (1ll << 30)) nb *= 2;          // 32-bit element indices inside a block
+        if (nsl > 1 && nb > 64) nb = nb / nsl < 64 ? 64 : nb / nsl;       // about one block per CU over all slices
+        while ((ncol + nb - 1) / nb * Cs >= (1ll << 30)) nb *= 2;         // 32-bit element indices inside a block
         int cpb = (int)((ncol + nb - 1) / nb);
         int nblk = (int)((ncol + cpb - 1) / cpb);
-        const int nent = Q * fw * C + C;
-        float* ws = reinterpret_cast<float*>(embed_scratch_for(s, (size_t)nblk * nent * sizeof(float)));
+        const int nent = Q * fw * Cs + Cs;
+        float* ws = reinterpret_cast<float*>(embed_scratch_for(s, (size_t)nsl * nblk * nent * sizeof(float)));
         if (!ws) { wn::set_error("embed_bwd: cannot allocate the per-block table scratch"); return WN_EHIP; }
 #define EMB_LAUNCH(FW)                                                                                        \
     do {                                                                                                      \
@@ -802,8 +808,8 @@ int generic_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* d
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));              \
             attr_set = true;                                                                                  \
         }                                                                                                     \
-        hipLaunchKernelGGL(k_embed_bwd_lds<FW>, dim3(nblk), dim3(kThreads), lds, s, idx, dout, ws, dbias ? 1 : 0, B, T, \
-                           Q, C, fw, cpb);                                                                    \
+        hipLaunchKernelGGL(k_embed_bwd_lds<FW>, dim3(nblk, nsl), dim3(kThreads), lds, s, idx, dout, ws, dbias ? 1 : 0, B, T, \
+                           Q, Cs, fw, cpb, C);                                                                \
     } while (0)
         if (fw == 1) EMB_LAUNCH(1);
         else if (fw == 2) EMB_LAUNCH(2);
@@ -811,8 +817,10 @@ int generic_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* d
         else EMB_LAUNCH(0);
 #undef EMB_LAUNCH
         WN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_embed_bwd_reduce, dim3(cdiv(nent, kThreads)), dim3(kThreads), 0, s, ws, nblk, Q, C, fw, dW,
-                           dbias);
+        for (int sl = 0; sl < nsl; ++sl)
+            hipLaunchKernelGGL(k_embed_bwd_reduce, dim3(cdiv(nent, kThreads)), dim3(kThreads), 0, s,
+                               ws + (size_t)sl * nblk * nent, nblk, Q, Cs, fw, dW + (size_t)sl * Cs * Q * fw,
+                               dbias ? dbias + sl * Cs : nullptr);
     } else {
         long long total = ncol * C;
         hipLaunchKernelGGL(k_embed_bwd_atomic, dim3(cdiv(total, kThreads)), dim3(kThreads), 0, s, idx, dout,
