@@ -658,6 +658,17 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
         }
     }
     if (!active) return;
+    if (a.part) {
+        // [workgroup][wave = problem][mt][r][lane]: whole 256-byte rows per store instruction, no atomics.  (With 256
+        // workgroups adding 64 K values each into the SAME 64 K addresses, the atomics were 98 of this kernel's 155 us at
+        // config 5's layer shapes.)
+        float* __restrict__ o = a.part + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv) * (MT * 16 * 64) + lane;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(mt * 16 + r) * 64] = acc[mt][r];
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const bool second = a.m_split > 0 && mt * 32 >= a.m_split;
@@ -667,6 +678,28 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
         for (int r = 0; r < 16; ++r)
             atomicAdd(o + (long long)(mrow + b3_ch(r, h)) * a.ldo + (long long)j * (a.osk ? a.osk : 1), acc[mt][r]);
     }
+}
+
+// Sum of the partial tiles of k_wgrad_b3w: one thread per output element, the workgroups' tiles of one (problem, mt, r)
+// are 256-byte rows `stride` floats apart.  dW += sum (sole writer of its element).
+__global__ void k_wgrad_b3w_reduce(WGArgs a, int nwg_x) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // (mt, r) of this wave: 0 .. 127
+    const int p = blockIdx.y;                                              // problem
+    const int y = p >> 3, wv = p & 7;
+    const long long stride = 8ll * 8 * 16 * 64;                             // one workgroup's tiles
+    const float* __restrict__ src = a.part + (((long long)y * nwg_x) * 8 + wv) * (8 * 16 * 64) + e * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = 0;
+    for (; w + 4 <= nwg_x; w += 4) {
+        s0 += src[(w + 0) * stride]; s1 += src[(w + 1) * stride]; s2 += src[(w + 2) * stride]; s3 += src[(w + 3) * stride];
+    }
+    for (; w < nwg_x; ++w) s0 += src[w * stride];
+    const int mt = e >> 4, r = e & 15, j = lane & 31, h = lane >> 5;
+    const bool second = a.m_split > 0 && mt * 32 >= a.m_split;
+    float* __restrict__ o = second ? a.out2[p] : a.out[p];
+    const int mrow = mt * 32 - (second ? a.m_split : 0);
+    o[(long long)(mrow + b3_ch(r, h)) * a.ldo + (long long)j * (a.osk ? a.osk : 1)] += (s0 + s1) + (s2 + s3);
 }
 
 // M == 256 and at least 8 problems: the wide block.  Picks its own row slabs (one workgroup per CU).
@@ -697,6 +730,15 @@ int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
     for (int q = 0; q < a.nprob; ++q) { any_b2 |= a.B2p[q] != nullptr; all_b2 &= a.B2p[q] != nullptr; }
     if (any_b2 != all_b2) { wn::set_error("wgrad_b3w: the B2 factor must be given for all problems or for none"); return WN_EARG; }
     const dim3 grid(a.nB * a.wgs_per_b, gy);
+    // Few 32-row chunks per workgroup (config 5's per-layer gradients: 16): the 64 K atomics every workgroup ends with cost
+    // more than its contraction -- partial tiles + one reduction instead.  Long slabs (config 2's dWs: 85 chunks) keep the
+    // atomics: there the two cost the same and the partial tiles would be 60 MB of extra traffic.
+    a.part = nullptr;
+    if (rows / 32 < 48) {
+        const size_t bytes = (size_t)grid.x * grid.y * 8 * (8 * 16 * 64) * sizeof(float);
+        a.part = reinterpret_cast<float*>(scratch_for(s, bytes));
+        if (!a.part) { wn::set_error("wgrad_b3w: cannot allocate %zu bytes of partial-tile scratch", bytes); return WN_EHIP; }
+    }
     const bool one = one_term();
 #define W_LAUNCH(B2_, ACT_)                                                                                     \
     do {                                                                                                        \
@@ -714,6 +756,10 @@ int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
 #undef W_LAUNCH_A
 #undef W_LAUNCH
     WN_LAUNCH_CHECK();
+    if (a.part) {
+        hipLaunchKernelGGL(k_wgrad_b3w_reduce, dim3(128 / 4, a.nprob), dim3(256), 0, s, a, (int)grid.x);
+        WN_LAUNCH_CHECK();
+    }
     return WN_OK;
 }
 
