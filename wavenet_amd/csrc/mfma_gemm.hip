@@ -407,6 +407,16 @@ int launch_wgrad(WGArgs& a, int M, hipStream_t s) {
     a.wgs_per_b = cdiv(a.rows_A_per_b, rows);
     dim3 grid(a.nB * a.wgs_per_b, cdiv(a.nprob, 4), M / (mt * 32));
     if (gemm_b3_enabled() && M == 256 && a.nprob >= 8) return launch_wgrad_b3w(a, s);
+    if (gemm_b3_enabled() && M % 256 == 0 && a.nprob >= 8) {      // config 5's 512 skip channels: one wide launch per 256 rows of A
+        for (int m0 = 0; m0 < M; m0 += 256) {
+            WGArgs h = a;
+            h.A = a.A + m0;
+            for (int q = 0; q < a.nprob; ++q) h.out[q] = a.out[q] + (long long)m0 * a.ldo;
+            int rc = launch_wgrad_b3w(h, s);
+            if (rc) return rc;
+        }
+        return WN_OK;
+    }
     if (gemm_b3_enabled()) {          // bf16x3: at most 4 row tiles per workgroup (register budget), more groups in z
         const int mt3 = mt > 4 ? 4 : mt;
         grid.z = M / (mt3 * 32);
