@@ -159,6 +159,10 @@ int wn_softmax_fwd(const float* logits, float* prob, int N, int Q, void* stream)
 int wn_softmax_xent(const float* logits, const int32_t* target, float* loss, float* dlogits,
                     int N, int Q, void* stream);
 
+/* x[i] *= *scale_dev (a device scalar), and nothing at all when *scale_dev == 1: the backward of the loss node
+ * (chainer's softmax_cross_entropy backward multiplies by the upstream gradient, which is 1 for `loss.backward()`).  */
+int wn_scale_by_dev(float* x, const float* scale_dev, int64_t n, void* stream);
+
 /* ---- layout conversion at the boundary: (B,C,1,T) T-contiguous <-> (B,T,C) ------------------ */
 int wn_nchw_to_btc(const float* src, float* dst, int B, int C, int T, void* stream);
 int wn_btc_to_nchw(const float* src, float* dst, int B, int C, int T, void* stream);

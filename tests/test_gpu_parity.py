@@ -1079,3 +1079,41 @@ def test_gemm_precision_switch_round_trip():
             wavenet_amd.set_gemm_precision("fp8")
     finally:
         wavenet_amd.set_gemm_precision(before)
+
+
+@pytest.mark.gpu
+def test_loss_backward_scales_by_the_upstream_gradient():
+    """The cross-entropy node scales its saved dlogits in place by the upstream gradient read from device memory
+    (wn_scale_by_dev: no pass at all when it is 1): (3 * loss).backward() must give 3x the gradients of loss.backward()."""
+    p, w, net = build(CFG1, seed=5)
+    rs = np.random.RandomState(2)
+    iw = net.input_width
+    tok = rs.randint(0, 256, size=(2, iw + 30)).astype(np.int32)
+    x, tgt = dev(tok[:, :-1]), dev(tok[:, iw:])
+
+    def grads(scale):
+        net.zero_grads()
+        c = net.forward_causal_block(x)
+        _, s = net.forward_residual_block(c, t_off=x.shape[1] - tgt.shape[1])
+        loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt)
+        (loss * scale if scale != 1 else loss).backward()
+        return to_np(net._grad_arena).copy(), loss
+
+    g1, loss = grads(1)
+    g3, _ = grads(3.0)
+    np.testing.assert_allclose(g3, 3.0 * g1, rtol=2e-5, atol=1e-7)
+    assert np.abs(g1).max() > 0
+    with pytest.raises(RuntimeError):
+        loss.backward()                                   # the graph (and the in-place scaled buffer) is gone
+
+
+@pytest.mark.gpu
+def test_scale_by_dev_odd_sizes():
+    for n in (1, 3, 4, 1023, 4099):
+        x = torch.arange(n, device="cuda", dtype=torch.float32) + 1
+        for sc in (1.0, -2.5):
+            y = x.clone()
+            s = torch.tensor([sc], device="cuda")
+            check(_lib.lib().wn_scale_by_dev(ptr(y), ptr(s), n, None), "wn_scale_by_dev")
+            np.testing.assert_array_equal(to_np(y), to_np(x) * np.float32(sc))
+        y = x[1:].clone() if n > 1 else x.clone()          # unaligned start is handled (scalar path)

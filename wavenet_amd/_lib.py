@@ -79,6 +79,7 @@ _SIGS = {
     "wn_mulaw_decode": (_i, [_p, _p, _p, _i64, _i, _p]),
     "wn_eve_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _f, _f, _p]),
     "wn_rule_step": (_i, [_i, _p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _p, _f, _f, _p]),
+    "wn_scale_by_dev": (_i, [_p, _p, _i64, _p]),
     "wn_set_gemm_precision": (_i, [_i]),
     "wn_get_gemm_precision": (_i, []),
     "wn_prof_enable": (_i, [_i]),

@@ -284,6 +284,13 @@ int wn_rule_step(int rule, float* param, const float* grad, float* s1, float* s2
                         as_stream(stream));
 }
 
+int wn_scale_by_dev(float* x, const float* scale_dev, int64_t n, void* stream) {
+    wn::ProfScope prof__("wn_softmax_xent", stream);
+    NN(x); NN(scale_dev);
+    WN_CHECK_ARG(n > 0, "wn_scale_by_dev: n <= 0");
+    return generic_scale_by_dev(x, scale_dev, n, as_stream(stream));
+}
+
 int wn_set_gemm_precision(int mode) {
     WN_CHECK_ARG(mode >= WN_GEMM_FP32 && mode <= WN_GEMM_BF16, "wn_set_gemm_precision: mode must be 0, 1 or 2");
     if (force_generic() && mode != WN_GEMM_FP32) {

@@ -585,6 +585,20 @@ __global__ void k_softmax_xent(const float* __restrict__ logits, const int32_t* 
     }
 }
 
+// x *= *s, skipped entirely when *s == 1 (every block reads the scalar and leaves): the upstream gradient of a loss is 1
+// unless the caller scaled the loss, and multiplying 8.4 M dlogits by it cost a 33 us pass per step.
+__global__ void k_scale_by_dev(float* __restrict__ x, const float* __restrict__ s, long long n4, long long n) {
+    const float v = *s;
+    if (v == 1.f) return;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        float4 t = reinterpret_cast<float4*>(x)[i];
+        t.x *= v; t.y *= v; t.z *= v; t.w *= v;
+        reinterpret_cast<float4*>(x)[i] = t;
+    }
+    if (blockIdx.x == 0)
+        for (long long i = n4 * 4 + threadIdx.x; i < n; i += blockDim.x) x[i] *= v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // layout conversion (B,C,T) <-> (B,T,C) through a padded 32x32 LDS tile
 // ---------------------------------------------------------------------------------------------
@@ -1088,6 +1102,16 @@ int generic_rule(int rule, float* p, const float* g, float* s1, float* s2, long 
         default: RULE_LAUNCH(5); break;
     }
 #undef RULE_LAUNCH
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int generic_scale_by_dev(float* x, const float* sdev, long long n, hipStream_t s) {
+    const long long n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n / 4 : 0;
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_scale_by_dev, dim3(blocks), dim3(256), 0, s, x, sdev, n4, n);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

@@ -39,6 +39,7 @@ int generic_mulaw_decode(const int32_t* tok, const float* table, float* out, lon
 int generic_sqnorm(const float* g, const float* p, long long n, float gmult, float wd, float* out, hipStream_t s);
 int gemm_mode();            // mfma_gemm_b3.hip: 0 fp32 MFMA, 1 bf16x3 (default), 2 bf16 (one term)
 void set_gemm_mode(int m);
+int generic_scale_by_dev(float* x, const float* sdev, long long n, hipStream_t s);
 int generic_rule(int rule, float* p, const float* g, float* s1, float* s2, long long n, float lr, float hy, float eps,
                  float wd, const float* sqnorm, float clip, float gmult, const float* lr_dev, hipStream_t s);
 int generic_adam(float* p, const float* g, float* m, float* v, long long n, float lr_t, float b1, float b2,
