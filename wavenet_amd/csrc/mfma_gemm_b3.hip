@@ -56,7 +56,8 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
 //   element [ks][comp][lane = i + 32*hh][j]  =  comp-part of  W_tile[i][16*ks + 8*hh + j]
 // mode 0: chunk c = (source, 32-wide k slice), m-tile t = rows 32t.. of that source's W[m][k]
 // mode 2: m-tile t = problem t (32 rows), chunk c = k slice of W[t]
-__global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __bf16* __restrict__ img) {
+// one != 0 (one-term products): only the h parts are stored, 2 KB per tile instead of 6
+__global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __bf16* __restrict__ img, int one) {
     const int tile = blockIdx.x;
     const int c = tile / mtiles, t = tile - c * mtiles;
     const int i = threadIdx.x & 31, c4 = threadIdx.x >> 5;           // row, group of 4 consecutive k
@@ -89,6 +90,11 @@ __global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __
         h[e] = hh; m[e] = mm; l[e] = ll;
     }
     const int ks = c4 >> 2, hh = (c4 >> 1) & 1, jo = 4 * (c4 & 1);
+    if (one) {
+        __bf16* d = img + (long long)tile * (kTileElems / 3) + (i + 32 * hh) * 8 + jo;
+        *reinterpret_cast<bf16x4*>(d + ks * 512) = h;
+        return;
+    }
     __bf16* d = img + (long long)tile * kTileElems + (i + 32 * hh) * 8 + jo;
     *reinterpret_cast<bf16x4*>(d + (ks * 3 + 0) * 512) = h;
     *reinterpret_cast<bf16x4*>(d + (ks * 3 + 1) * 512) = m;
@@ -111,7 +117,8 @@ template <int MODE, int ACT, bool ONE>
 __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* __restrict__ img, int mtiles,
                                                        int nchunks, int chunks_per_src) {
     constexpr int MT = 4;
-    __shared__ __attribute__((aligned(16))) char lds[2 * MT * kTileBytes];      // double-buffered tile images
+    constexpr int TB = ONE ? kTileBytes / 3 : kTileBytes;                       // bytes of one tile image (h only / h, m, l)
+    __shared__ __attribute__((aligned(16))) char lds[2 * MT * TB];              // double-buffered tile images
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int t0 = blockIdx.y * MT;                        // first m-tile (mode 2: first problem) of this workgroup
@@ -159,10 +166,10 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
     // this wave copies m-tile (t0 + wave) of a chunk: 6 KB = six 1 KB LDS-DMA pieces
     const int my_tile = (t0 + wave < mtiles) ? t0 + wave : mtiles - 1;
     auto dma_chunk = [&](int c, int buf) {
-        const char* src = reinterpret_cast<const char*>(img) + ((long long)c * mtiles + my_tile) * kTileBytes + lane * 16;
-        char* dst = lds + (buf * MT + wave) * kTileBytes;
+        const char* src = reinterpret_cast<const char*>(img) + ((long long)c * mtiles + my_tile) * TB + lane * 16;
+        char* dst = lds + (buf * MT + wave) * TB;
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int q = 0; q < TB / 1024; ++q)
             __builtin_amdgcn_global_load_lds(src + q * 1024, (__attribute__((address_space(3))) void*)(dst + q * 1024), 16,
                                              0, 0);
     };
@@ -202,15 +209,15 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
             dma_chunk(c + 1, (c + 1) & 1);
             load_x(c + 1);
         }
-        const char* Ab = lds + ((c & 1) * MT) * kTileBytes + lane * 16;
+        const char* Ab = lds + ((c & 1) * MT) * TB + lane * 16;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const char* p = Ab + mt * kTileBytes + ks * 3 * 1024;
+                const char* p = Ab + mt * TB + ks * (TB / 2);
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(p);
-                const bf16x8 am = *reinterpret_cast<const bf16x8*>(p + 1024);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(p + 2048);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(p + (ONE ? 0 : 1024));
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(p + (ONE ? 0 : 2048));
                 // smallest terms first
                 if (!ONE) {
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[ks], acc[mt], 0, 0, 0);
@@ -337,12 +344,12 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
         cps = a.K[0] / 32;
         nchunks = cps;
     }
-    const size_t bytes = (size_t)nchunks * mtiles * kTileBytes;
+    const bool one = one_term();
+    const size_t bytes = (size_t)nchunks * mtiles * (one ? kTileBytes / 3 : kTileBytes);
     __bf16* img = reinterpret_cast<__bf16*>(scratch_for(s, bytes));
     if (!img) { wn::set_error("colgemm_b3: cannot allocate %zu bytes of weight scratch", bytes); return WN_EHIP; }
-    hipLaunchKernelGGL(k_split_w, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img);
+    hipLaunchKernelGGL(k_split_w, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img, one ? 1 : 0);
     dim3 grid(cdiv(a.N, 128), cdiv(mtiles, 4));
-    const bool one = one_term();
 #define CG_LAUNCH(MODE_, ACT_)                                                                                          \
     do {                                                                                                                \
         if (one) hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, true>), grid, dim3(256), 0, s, a, (const __bf16*)img,    \
