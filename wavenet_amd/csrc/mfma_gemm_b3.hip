@@ -113,10 +113,12 @@ __device__ __forceinline__ float act_apply_t(float x) {
     return x;
 }
 
-template <int MODE, int ACT, bool ONE>
-__global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* __restrict__ img, int mtiles,
-                                                       int nchunks, int chunks_per_src) {
-    constexpr int MT = 4;
+// MT = 8 (one-term mode only: 128 accumulator registers, 16 KB of LDS per buffer) halves the number of times X is
+// re-read when there are 8 or more m-tiles (skip sum, dz, the gate-mode layer GEMM).
+template <int MODE, int ACT, bool ONE, int MT>
+__global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, const __bf16* __restrict__ img, int mtiles,
+                                                                     int nchunks, int chunks_per_src) {
+    static_assert(MT == 4 || (MT == 8 && ONE), "8 m-tiles per workgroup only with one-term products");
     constexpr int TB = ONE ? kTileBytes / 3 : kTileBytes;                       // bytes of one tile image (h only / h, m, l)
     __shared__ __attribute__((aligned(16))) char lds[2 * MT * TB];              // double-buffered tile images
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -163,15 +165,19 @@ __global__ __launch_bounds__(256, 3) void k_colgemm_b3(CGArgs a, const __bf16* _
             }
     }
 
-    // this wave copies m-tile (t0 + wave) of a chunk: 6 KB = six 1 KB LDS-DMA pieces
-    const int my_tile = (t0 + wave < mtiles) ? t0 + wave : mtiles - 1;
+    // this wave copies m-tiles t0 + wave (+ 4) of a chunk: 1 KB LDS-DMA pieces
     auto dma_chunk = [&](int c, int buf) {
-        const char* src = reinterpret_cast<const char*>(img) + ((long long)c * mtiles + my_tile) * TB + lane * 16;
-        char* dst = lds + (buf * MT + wave) * TB;
 #pragma unroll
-        for (int q = 0; q < TB / 1024; ++q)
-            __builtin_amdgcn_global_load_lds(src + q * 1024, (__attribute__((address_space(3))) void*)(dst + q * 1024), 16,
-                                             0, 0);
+        for (int tt = 0; tt < MT / 4; ++tt) {
+            const int tl = wave + 4 * tt;
+            const int my_tile = (t0 + tl < mtiles) ? t0 + tl : mtiles - 1;
+            const char* src = reinterpret_cast<const char*>(img) + ((long long)c * mtiles + my_tile) * TB + lane * 16;
+            char* dst = lds + (buf * MT + tl) * TB;
+#pragma unroll
+            for (int q = 0; q < TB / 1024; ++q)
+                __builtin_amdgcn_global_load_lds(src + q * 1024, (__attribute__((address_space(3))) void*)(dst + q * 1024),
+                                                 16, 0, 0);
+        }
     };
     float4 xr[4];
     auto load_x = [&](int c) {
@@ -349,12 +355,15 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     __bf16* img = reinterpret_cast<__bf16*>(scratch_for(s, bytes));
     if (!img) { wn::set_error("colgemm_b3: cannot allocate %zu bytes of weight scratch", bytes); return WN_EHIP; }
     hipLaunchKernelGGL(k_split_w, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img, one ? 1 : 0);
-    dim3 grid(cdiv(a.N, 128), cdiv(mtiles, 4));
+    const bool mt8 = one && mtiles >= 8;
+    dim3 grid(cdiv(a.N, 128), cdiv(mtiles, mt8 ? 8 : 4));
 #define CG_LAUNCH(MODE_, ACT_)                                                                                          \
     do {                                                                                                                \
-        if (one) hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, true>), grid, dim3(256), 0, s, a, (const __bf16*)img,    \
+        if (mt8) hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, true, 8>), grid, dim3(256), 0, s, a, (const __bf16*)img, \
                                     mtiles, nchunks, cps);                                                              \
-        else hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, false>), grid, dim3(256), 0, s, a, (const __bf16*)img,       \
+        else if (one) hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, true, 4>), grid, dim3(256), 0, s, a,                \
+                                         (const __bf16*)img, mtiles, nchunks, cps);                                     \
+        else hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, false, 4>), grid, dim3(256), 0, s, a, (const __bf16*)img,    \
                                 mtiles, nchunks, cps);                                                                  \
     } while (0)
     if (mode == 3) {
