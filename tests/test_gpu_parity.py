@@ -1018,23 +1018,45 @@ def bf16_gemms():
 
 
 @pytest.mark.gpu
-def test_bf16_gemm_forward_matches_the_bf16_rounded_oracle(bf16_gemms):
-    p, w, net = build(CFG5S, seed=9)
+@pytest.mark.parametrize("width,bias", [(64, 0.0), (128, 0.0), (128, 0.3)])
+def test_bf16_gemm_forward_matches_the_bf16_rounded_oracle(bf16_gemms, width, bias):
+    """width 128 = config 5's layer shape: one fused kernel per layer (gate GEMM, gate, residual projection on z kept in
+    registers); other widths: gate GEMM + projection GEMM."""
+    over = dict(CFG5S, causal_conv_channels=[width], residual_conv_channels=[width] * 3)
+    if bias:
+        over.update(residual_conv_dilation_no_bias=False, residual_conv_projection_no_bias=False)
+    p, w, net = build(over, seed=9, bias_scale=bias)
     rs = np.random.RandomState(0)
-    tok = rs.randint(0, 256, size=(2, 150)).astype(np.int32)
+    tok = rs.randint(0, 256, size=(2, 150 if width == 64 else 333)).astype(np.int32)
     with torch.no_grad():
         logits = to_np(net.forward_one_step(dev(tok), apply_softmax=False))
     x = D.onehot_pixel_image(tok)
     _, _, _, want = R.forward_closed(p, w, x, round_operands=R.bf16_round)
     _, _, _, fp32 = R.forward_closed(p, w, x)
     err = np.abs(logits - want)
-    # operands are rounded exactly as the oracle rounds them; what is left is fp32 summation order plus the rare element
-    # whose tanh/sigmoid differs in the last bit and lands on the other side of a bf16 tie
-    assert err.max() < 5e-3 and err.mean() < 2e-4, (err.max(), err.mean())
-    # and bf16 it is: visibly away from the fp32 answer, by about 2^-9 of the logit scale
     d32 = np.abs(logits - fp32)
-    assert 1e-4 < d32.mean() < 3e-2 * max(1.0, np.abs(fp32).mean()), d32.mean()
-    assert d32.mean() > 5 * err.mean()
+    # operands are rounded exactly as the oracle rounds them; what is left is fp32 summation order plus the elements whose
+    # tanh/sigmoid differs in the last bit and lands on the other side of a bf16 tie (more of them with more channels).
+    # And bf16 it is: the distance to the fp32 answer (about 2^-9 of the logit scale) is several times larger.
+    scale = max(1.0, float(np.abs(fp32).max()))
+    assert err.max() < 2e-2 * scale and err.mean() < 0.5 * d32.mean(), (err.max(), err.mean(), d32.mean())
+    assert 1e-4 < d32.mean() < 3e-2 * scale, d32.mean()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,B,T,bias", [(8, 2, 300, True), (512, 1, 1100, False), (1, 3, 130, True)])
+def test_fused_wide_layer_projection_uses_its_own_z(bf16_gemms, d, B, T, bias):
+    """Config 5's layer kernel keeps z in registers for the residual projection (accumulator layout -> B-operand layout by
+    v_permlane32_swap).  Check that half on its own: out must equal x + bp + bf16(Wp) . bf16(z) for the z the kernel wrote."""
+    Cr = Cd = 128
+    x, Wf, Wg, Wp, b, Z, _, _, _, _ = _layer_case(Cr, Cd, 2, d, B, T, bias, seed=T + d)
+    out, z, f, g = _run_layer(x, Wf, Wg, Wp, b, Z, Cr, Cd, 2, d, True)
+    zq = R.bf16_round(to_np(z)).astype(np.float64)                     # (B, T, Cd)
+    wq = R.bf16_round(Wp.reshape(Cr, Cd)).astype(np.float64)
+    want = btc(x).astype(np.float64) + zq @ wq.T + (b[2].astype(np.float64) if bias else 0.0)
+    np.testing.assert_allclose(to_np(out), want, atol=2e-5)
+    np.testing.assert_allclose(to_np(z), to_np(f) * to_np(g), atol=1e-7)
+    assert np.abs(to_np(z)).max() > 0.05
 
 
 @pytest.mark.gpu

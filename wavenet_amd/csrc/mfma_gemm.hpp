@@ -35,6 +35,10 @@ struct CGArgs {
     float* gate_z; float* gate_f; float* gate_s;
     int gate_Z;
     int ldx;                         // row stride of every X source when != 0 (default: K[src])
+    // fused-layer mode (mode 5 = gate mode + the residual projection, 128/128 channels, one-term products): out[0] (row
+    // stride ldo = 128) = Wp z + proj_bias + residual, Wp's image is the kernel's second image argument
+    const float* proj_W;             // Wp[128][128], row-major
+    const float* proj_bias;
 };
 
 

@@ -68,7 +68,7 @@ __global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __
         k0 = (c - src * chunks_per_src) * 32;
         W = a.W[src] + (long long)(t * 32) * a.wsm[src];
         wsm = a.wsm[src];
-    } else if (mode == 3) {            // m-tile 2i = filter rows 32i.., m-tile 2i+1 = gate rows 32i..
+    } else if (mode == 3 || mode == 5) {   // m-tile 2i = filter rows 32i.., m-tile 2i+1 = gate rows 32i..
         const int src = c / chunks_per_src;
         k0 = (c - src * chunks_per_src) * 32;
         W = ((t & 1) ? a.W2[src] : a.W[src]) + (long long)((t >> 1) * 32) * a.wsm[src];
@@ -117,7 +117,8 @@ __device__ __forceinline__ float act_apply_t(float x) {
 // re-read when there are 8 or more m-tiles (skip sum, dz, the gate-mode layer GEMM).
 template <int MODE, int ACT, bool ONE, int MT>
 __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, const __bf16* __restrict__ img, int mtiles,
-                                                                     int nchunks, int chunks_per_src) {
+                                                                     int nchunks, int chunks_per_src,
+                                                                     const __bf16* __restrict__ img2) {
     static_assert(MT == 4 || (MT == 8 && ONE), "8 m-tiles per workgroup only with one-term products");
     constexpr int TB = ONE ? kTileBytes / 3 : kTileBytes;                       // bytes of one tile image (h only / h, m, l)
     __shared__ __attribute__((aligned(16))) char lds[2 * MT * TB];              // double-buffered tile images
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-    if (MODE == 3) {
+    if (MODE == 3 || MODE == 5) {
         for (int src = 0; src < a.nsrc; ++src)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -235,6 +236,91 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[ks], acc[mt], 0, 0, 0);
             }
         }
+    }
+    if constexpr (MODE == 5 && MT == 8) {
+        // ---- the whole 128/128 layer: gate epilogue, then out = Wp z + bp + x with z taken from registers --------------
+        // z leaves phase 1 in accumulator layout (lane (j, h): channels (r & 3) + 8 (r >> 2) + 4 h of each 32-channel tile);
+        // the second contraction wants it as B operands (lane (j, h2): 8 consecutive channels 16 ks + 8 h2 ..).  Packed to
+        // bf16 pairs, one v_permlane32_swap per dword pair does that exchange between lanes j and j + 32 -- no LDS.
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const bool live = nvalid && (rbase - a.off >= a.gate_Z);
+        bf16x8 zb[4][2];
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            const long long o = no * a.M + pr * 32 + 4 * h;
+            unsigned pk[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float f4[4], s4[4], z4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f4[e] = fast_tanh(live ? acc[2 * pr][4 * q + e] : 0.f);
+                    s4[e] = fast_sigmoid(live ? acc[2 * pr + 1][4 * q + e] : 0.f);
+                    z4[e] = f4[e] * s4[e];
+                }
+                if (nvalid) {
+                    *reinterpret_cast<float4*>(a.gate_z + o + 8 * q) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+                    if (a.gate_f) {
+                        *reinterpret_cast<float4*>(a.gate_f + o + 8 * q) = make_float4(f4[0], f4[1], f4[2], f4[3]);
+                        *reinterpret_cast<float4*>(a.gate_s + o + 8 * q) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+                    }
+                }
+                bf16x2 p0, p1;
+                p0[0] = (__bf16)z4[0]; p0[1] = (__bf16)z4[1]; p1[0] = (__bf16)z4[2]; p1[1] = (__bf16)z4[3];
+                pk[2 * q] = __builtin_bit_cast(unsigned, p0);
+                pk[2 * q + 1] = __builtin_bit_cast(unsigned, p1);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const auto s0 = __builtin_amdgcn_permlane32_swap(pk[4 * ks], pk[4 * ks + 2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(pk[4 * ks + 1], pk[4 * ks + 3], false, false);
+                u32x4 v;
+                v[0] = s0[0]; v[1] = s1[0]; v[2] = s0[1]; v[3] = s1[1];
+                zb[pr][ks] = __builtin_bit_cast(bf16x8, v);
+            }
+        }
+        __syncthreads();                                            // every wave is done with the last gate chunk
+        {   // Wp's image: 16 tiles of 2 KB (chunk-major), four per wave
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const int tile = wave * 4 + tt;
+                const char* src = reinterpret_cast<const char*>(img2) + tile * TB + lane * 16;
+                char* dst = lds + tile * TB;
+#pragma unroll
+                for (int q = 0; q < TB / 1024; ++q)
+                    __builtin_amdgcn_global_load_lds(src + q * 1024, (__attribute__((address_space(3))) void*)(dst + q * 1024),
+                                                     16, 0, 0);
+            }
+        }
+        f32x16 acc2[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mt][r] = a.proj_bias ? a.proj_bias[mt * 32 + b3_ch(r, h)] : 0.f;
+        __syncthreads();                                            // (drains vmcnt) the image has landed
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 aw = *reinterpret_cast<const bf16x8*>(lds + (c * 4 + mt) * TB + ks * (TB / 2) + lane * 16);
+                    acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw, zb[c][ks], acc2[mt], 0, 0, 0);
+                }
+        if (!nvalid) return;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const long long o = no * a.ldo + mt * 32 + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 rr = *reinterpret_cast<const float4*>(a.residual + o + 8 * q);
+                *reinterpret_cast<float4*>(a.out[0] + o + 8 * q) =
+                    make_float4(acc2[mt][4 * q] + rr.x, acc2[mt][4 * q + 1] + rr.y, acc2[mt][4 * q + 2] + rr.z,
+                                acc2[mt][4 * q + 3] + rr.w);
+            }
+        }
+        return;
     }
     if (!nvalid) return;
     if (MODE == 3) {
@@ -334,14 +420,15 @@ static void* scratch_for(hipStream_t s, size_t bytes) {
 }
 
 int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
-    if (mode != 0 && mode != 2 && mode != 3 && mode != 4) return WN_ESHAPE;
+    if (mode != 0 && mode != 2 && mode != 3 && mode != 4 && mode != 5) return WN_ESHAPE;
     int mtiles, nchunks, cps;
-    if (mode == 0 || mode == 3 || mode == 4) {
+    if (mode == 0 || mode >= 3) {
         if (a.M % 32) return WN_ESHAPE;
-        if (mode == 3 && a.nsrc > WN_GATE_TAPS) return WN_ESHAPE;
+        if ((mode == 3 || mode == 5) && a.nsrc > WN_GATE_TAPS) return WN_ESHAPE;
+        if (mode == 5 && !(one_term() && a.M == 128 && a.ldo == 128)) return WN_ESHAPE;
         for (int i = 0; i < a.nsrc; ++i)
             if (a.K[i] != a.K[0] || a.K[i] % 32) return WN_ESHAPE;
-        mtiles = (mode == 3 ? 2 : 1) * a.M / 32;
+        mtiles = ((mode == 3 || mode == 5) ? 2 : 1) * a.M / 32;
         cps = a.K[0] / 32;
         nchunks = a.nsrc * cps;
     } else {
@@ -352,19 +439,34 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     }
     const bool one = one_term();
     const size_t bytes = (size_t)nchunks * mtiles * (one ? kTileBytes / 3 : kTileBytes);
-    __bf16* img = reinterpret_cast<__bf16*>(scratch_for(s, bytes));
-    if (!img) { wn::set_error("colgemm_b3: cannot allocate %zu bytes of weight scratch", bytes); return WN_EHIP; }
+    const size_t bytes2 = mode == 5 ? (size_t)16 * (kTileBytes / 3) : 0;        // Wp's image behind the gate image
+    __bf16* img = reinterpret_cast<__bf16*>(scratch_for(s, bytes + bytes2));
+    if (!img) { wn::set_error("colgemm_b3: cannot allocate %zu bytes of weight scratch", bytes + bytes2); return WN_EHIP; }
     hipLaunchKernelGGL(k_split_w, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img, one ? 1 : 0);
+    if (mode == 5) {
+        if (!a.proj_W || !a.residual || !a.gate_z || a.act != WN_ACT_NONE || mtiles != 8) {
+            wn::set_error("colgemm_b3: fused-layer mode needs Wp, the residual input, z and 128 gate channels");
+            return WN_EARG;
+        }
+        CGArgs b{};
+        b.nsrc = 1; b.W[0] = a.proj_W; b.wsm[0] = 128; b.wsk = 1; b.K[0] = 128; b.M = 128;
+        __bf16* img2 = reinterpret_cast<__bf16*>(reinterpret_cast<char*>(img) + bytes);
+        hipLaunchKernelGGL(k_split_w, dim3(16), dim3(256), 0, s, b, 0, 4, 4, img2, 1);
+        hipLaunchKernelGGL((k_colgemm_b3<5, WN_ACT_NONE, true, 8>), dim3(cdiv(a.N, 128), 1), dim3(256), 0, s, a,
+                           (const __bf16*)img, mtiles, nchunks, cps, (const __bf16*)img2);
+        WN_LAUNCH_CHECK();
+        return WN_OK;
+    }
     const bool mt8 = one && mtiles >= 8;
     dim3 grid(cdiv(a.N, 128), cdiv(mtiles, mt8 ? 8 : 4));
 #define CG_LAUNCH(MODE_, ACT_)                                                                                          \
     do {                                                                                                                \
         if (mt8) hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, true, 8>), grid, dim3(256), 0, s, a, (const __bf16*)img, \
-                                    mtiles, nchunks, cps);                                                              \
+                                    mtiles, nchunks, cps, (const __bf16*)nullptr);                                      \
         else if (one) hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, true, 4>), grid, dim3(256), 0, s, a,                \
-                                         (const __bf16*)img, mtiles, nchunks, cps);                                     \
+                                         (const __bf16*)img, mtiles, nchunks, cps, (const __bf16*)nullptr);             \
         else hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, false, 4>), grid, dim3(256), 0, s, a, (const __bf16*)img,    \
-                                mtiles, nchunks, cps);                                                                  \
+                                mtiles, nchunks, cps, (const __bf16*)nullptr);                                          \
     } while (0)
     if (mode == 3) {
         if (a.act != WN_ACT_NONE || !a.gate_z) { wn::set_error("colgemm_b3: gate mode takes no activation and needs gate_z"); return WN_EARG; }

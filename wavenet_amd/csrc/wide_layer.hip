@@ -11,6 +11,8 @@
 //             dx = dout + sum_k Wf_k^T da[t+(fw-1-k)d] + Wg_k^T dg[..]  multi-source GEMM, 2 fw sources
 //             dWp, dWf_k, dWg_k                                         weight-gradient GEMMs (contraction over time)
 //             biases                                                    column sums
+#include <stdlib.h>
+
 #include "mfma_gemm.hpp"
 
 namespace wn {
@@ -85,6 +87,13 @@ int wide_layer_fwd(const float* x, const float* Wf, const float* bf, const float
         }
         a.wsk = fw; a.M = Cd; a.ldo = Cd; a.out[0] = z;
         a.gate_z = z; a.gate_f = fs; a.gate_s = gs; a.gate_Z = Z;
+        static const bool no_fused = getenv("WAVENET_HIP_NO_FUSED_WIDE") != nullptr;     // diagnostic switch
+        if (!no_fused && gemm_mode() == 2 && Cr == 128 && Cd == 128) {
+            // bf16 operands, 128/128 channels (config 5): the residual projection runs in the same kernel, on z taken from
+            // registers -- one launch per layer, z is written but never read back
+            a.ldo = Cr; a.out[0] = out; a.residual = x; a.proj_W = Wp; a.proj_bias = bp;
+            return launch_colgemm_b3(a, 5, 1, s);
+        }
         if ((rc = launch_colgemm_b3(a, 3, 1, s))) return rc;
         CGArgs b{};
         base_args(b, B, T);
