@@ -103,6 +103,58 @@ __global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __
 
 __device__ __forceinline__ int b3_ch(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// ---- whole-row global access for tiles in accumulator layout ------------------------------------------------------
+// A wave's 32-column x 32-channel tile sits in registers as four float4 per lane: lane (j, h), piece q = channels
+// 8q + 4h .. +3 of column j, i.e. 16-byte chunk 2q + h of that column's 128-byte row.  Moved straight between registers and
+// memory, one instruction touches 32 bytes of each of 32 rows (measured: 2.7 TB/s for the stores and 3.1 TB/s for the
+// loads of the gate-backward epilogue).  Through a 4 KB per-wave LDS patch (chunk c of row r in slot c ^ (r & 7):
+// conflict-free in both directions) one instruction moves eight whole 128-byte rows.
+struct RowMap { long long row[4]; bool ok[4]; };          // global row / validity of tile row 8 it + lane / 8
+
+__device__ __forceinline__ RowMap row_map(long long no, bool nvalid, int lane) {
+    RowMap m;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int src = it * 8 + (lane >> 3);
+        const int lo = __shfl((int)(no & 0xffffffffll), src), hi = __shfl((int)(no >> 32), src);
+        m.row[it] = ((long long)hi << 32) | (unsigned)lo;
+        m.ok[it] = __shfl(nvalid ? 1 : 0, src) != 0;
+    }
+    return m;
+}
+__device__ __forceinline__ float* patch_tile(float* patch, int j, int h, int q) {
+    return patch + j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
+}
+__device__ __forceinline__ float* patch_rows(float* patch, int lane, int it) {
+    const int r = it * 8 + (lane >> 3), c = lane & 7;
+    return patch + r * 32 + ((c ^ (r & 7)) << 2);
+}
+// global (whole rows) -> registers in tile layout; `stride` floats between rows, `col` = first channel of the tile
+__device__ __forceinline__ void rows_load(const float* __restrict__ g, long long stride, int col, const RowMap& m, int lane,
+                                          float4 (&v)[4]) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+        v[it] = *reinterpret_cast<const float4*>(g + (m.ok[it] ? m.row[it] : 0) * stride + col + ((lane & 7) << 2));
+}
+__device__ __forceinline__ void rows_to_tile(float* patch, int lane, const float4 (&v)[4], float4 (&t)[4]) {
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) *reinterpret_cast<float4*>(patch_rows(patch, lane, it)) = v[it];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] = *reinterpret_cast<const float4*>(patch_tile(patch, j, h, q));
+}
+__device__ __forceinline__ void tile_store_rows(float* patch, int lane, const float4 (&t)[4], float* __restrict__ g,
+                                                long long stride, int col, const RowMap& m) {
+    const int j = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(patch_tile(patch, j, h, q)) = t[q];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const float4 v = *reinterpret_cast<const float4*>(patch_rows(patch, lane, it));
+        if (m.ok[it]) *reinterpret_cast<float4*>(g + m.row[it] * stride + col + ((lane & 7) << 2)) = v;
+    }
+}
+
 // MT m-tiles per workgroup (one per wave for the LDS-DMA fill: MT == 4 waves)
 // The activation on X is a template parameter: as a runtime switch it put ~80 branches and ~270 scalar instructions (and
 // an inlined expm1f per element) into every 32-deep chunk of the contraction, next to 48 MFMAs.
@@ -245,11 +297,14 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
         typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const bool live = nvalid && (rbase - a.off >= a.gate_Z);
+        __syncthreads();                                            // every wave is done with the last gate chunk
+        float* patch5 = reinterpret_cast<float*>(lds) + wave * 1024;
+        const RowMap rm5 = row_map(no, nvalid, lane);
         bf16x8 zb[4][2];
 #pragma unroll
         for (int pr = 0; pr < 4; ++pr) {
-            const long long o = no * a.M + pr * 32 + 4 * h;
             unsigned pk[8];
+            float4 tz[4], tf[4], ts[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float f4[4], s4[4], z4[4];
@@ -259,13 +314,9 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
                     s4[e] = fast_sigmoid(live ? acc[2 * pr + 1][4 * q + e] : 0.f);
                     z4[e] = f4[e] * s4[e];
                 }
-                if (nvalid) {
-                    *reinterpret_cast<float4*>(a.gate_z + o + 8 * q) = make_float4(z4[0], z4[1], z4[2], z4[3]);
-                    if (a.gate_f) {
-                        *reinterpret_cast<float4*>(a.gate_f + o + 8 * q) = make_float4(f4[0], f4[1], f4[2], f4[3]);
-                        *reinterpret_cast<float4*>(a.gate_s + o + 8 * q) = make_float4(s4[0], s4[1], s4[2], s4[3]);
-                    }
-                }
+                tz[q] = make_float4(z4[0], z4[1], z4[2], z4[3]);
+                tf[q] = make_float4(f4[0], f4[1], f4[2], f4[3]);
+                ts[q] = make_float4(s4[0], s4[1], s4[2], s4[3]);
                 bf16x2 p0, p1;
                 p0[0] = (__bf16)z4[0]; p0[1] = (__bf16)z4[1]; p1[0] = (__bf16)z4[2]; p1[1] = (__bf16)z4[3];
                 pk[2 * q] = __builtin_bit_cast(unsigned, p0);
@@ -279,8 +330,14 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
                 v[0] = s0[0]; v[1] = s1[0]; v[2] = s0[1]; v[3] = s1[1];
                 zb[pr][ks] = __builtin_bit_cast(bf16x8, v);
             }
+            // z, f, s leave as whole rows through this wave's patch (in the image buffers, free since the barrier above)
+            tile_store_rows(patch5, lane, tz, a.gate_z, a.M, pr * 32, rm5);
+            if (a.gate_f) {
+                tile_store_rows(patch5, lane, tf, a.gate_f, a.M, pr * 32, rm5);
+                tile_store_rows(patch5, lane, ts, a.gate_s, a.M, pr * 32, rm5);
+            }
         }
-        __syncthreads();                                            // every wave is done with the last gate chunk
+        __syncthreads();                                            // every wave is done with its patch
         {   // Wp's image: 16 tiles of 2 KB (chunk-major), four per wave
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) {
@@ -308,27 +365,30 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
                     const bf16x8 aw = *reinterpret_cast<const bf16x8*>(lds + (c * 4 + mt) * TB + ks * (TB / 2) + lane * 16);
                     acc2[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw, zb[c][ks], acc2[mt], 0, 0, 0);
                 }
-        if (!nvalid) return;
+        __syncthreads();                                            // every wave is done with Wp's image: patches again
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const long long o = no * a.ldo + mt * 32 + 4 * h;
+            float4 t[4], v[4], u[4];
+            rows_load(a.residual, a.ldo, mt * 32, rm5, lane, v);
+            rows_to_tile(patch5, lane, v, u);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 rr = *reinterpret_cast<const float4*>(a.residual + o + 8 * q);
-                *reinterpret_cast<float4*>(a.out[0] + o + 8 * q) =
-                    make_float4(acc2[mt][4 * q] + rr.x, acc2[mt][4 * q + 1] + rr.y, acc2[mt][4 * q + 2] + rr.z,
-                                acc2[mt][4 * q + 3] + rr.w);
-            }
+            for (int q = 0; q < 4; ++q)
+                t[q] = make_float4(acc2[mt][4 * q] + u[q].x, acc2[mt][4 * q + 1] + u[q].y, acc2[mt][4 * q + 2] + u[q].z,
+                                   acc2[mt][4 * q + 3] + u[q].w);
+            tile_store_rows(patch5, lane, t, a.out[0], a.ldo, mt * 32, rm5);
         }
         return;
     }
-    if (!nvalid) return;
+    __syncthreads();                                               // the image buffers become the waves' 4 KB row patches
+    float* patch = reinterpret_cast<float*>(lds) + wave * 1024;
+    const RowMap rm = row_map(no, nvalid, lane);
     if (MODE == 3) {
         const bool live = rbase - a.off >= a.gate_Z;               // rbase - off = t of this column
 #pragma unroll
         for (int pr = 0; pr < MT / 2; ++pr) {
             if (t0 + 2 * pr >= mtiles) break;
-            const long long o = no * a.M + ((t0 >> 1) + pr) * 32 + 4 * h;
+            const int col = ((t0 >> 1) + pr) * 32;
+            float4 tf[4], ts[4], tz[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float f4[4], s4[4];
@@ -337,12 +397,14 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
                     f4[e] = fast_tanh(live ? acc[2 * pr][4 * q + e] : 0.f);
                     s4[e] = fast_sigmoid(live ? acc[2 * pr + 1][4 * q + e] : 0.f);
                 }
-                *reinterpret_cast<float4*>(a.gate_z + o + 8 * q) =
-                    make_float4(f4[0] * s4[0], f4[1] * s4[1], f4[2] * s4[2], f4[3] * s4[3]);
-                if (a.gate_f) {
-                    *reinterpret_cast<float4*>(a.gate_f + o + 8 * q) = make_float4(f4[0], f4[1], f4[2], f4[3]);
-                    *reinterpret_cast<float4*>(a.gate_s + o + 8 * q) = make_float4(s4[0], s4[1], s4[2], s4[3]);
-                }
+                tf[q] = make_float4(f4[0], f4[1], f4[2], f4[3]);
+                ts[q] = make_float4(s4[0], s4[1], s4[2], s4[3]);
+                tz[q] = make_float4(f4[0] * s4[0], f4[1] * s4[1], f4[2] * s4[2], f4[3] * s4[3]);
+            }
+            tile_store_rows(patch, lane, tz, a.gate_z, a.M, col, rm);
+            if (a.gate_f) {
+                tile_store_rows(patch, lane, tf, a.gate_f, a.M, col, rm);
+                tile_store_rows(patch, lane, ts, a.gate_s, a.M, col, rm);
             }
         }
         return;
@@ -352,52 +414,60 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             if (t0 + mt >= mtiles) break;
-            const long long ci = no * a.M + (t0 + mt) * 32 + 4 * h;            // f, s, dz_skip: row stride M
-            const long long co = no * 2 * a.M + (t0 + mt) * 32 + 4 * h;        // [da | dg]: row stride 2 M
+            const int col = (t0 + mt) * 32;
+            float4 vf[4], vs[4], vr[4], tf[4], ts[4], tr[4], da[4], dg[4];
+            rows_load(a.gate_f, a.M, col, rm, lane, vf);                // f, s, dz_skip: row stride M
+            rows_load(a.gate_s, a.M, col, rm, lane, vs);
+            if (a.residual) rows_load(a.residual, a.M, col, rm, lane, vr);
+            rows_to_tile(patch, lane, vf, tf);
+            rows_to_tile(patch, lane, vs, ts);
+            if (a.residual) rows_to_tile(patch, lane, vr, tr);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 f4 = *reinterpret_cast<const float4*>(a.gate_f + ci + 8 * q);
-                const float4 s4 = *reinterpret_cast<const float4*>(a.gate_s + ci + 8 * q);
                 float4 dz = make_float4(acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
-                if (a.residual) {
-                    const float4 rr = *reinterpret_cast<const float4*>(a.residual + ci + 8 * q);
-                    dz.x += rr.x; dz.y += rr.y; dz.z += rr.z; dz.w += rr.w;
-                }
+                if (a.residual) { dz.x += tr[q].x; dz.y += tr[q].y; dz.z += tr[q].z; dz.w += tr[q].w; }
                 if (!live) dz = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(a.gate_z + co + 8 * q) =
-                    make_float4(dz.x * s4.x * (1.f - f4.x * f4.x), dz.y * s4.y * (1.f - f4.y * f4.y),
-                                dz.z * s4.z * (1.f - f4.z * f4.z), dz.w * s4.w * (1.f - f4.w * f4.w));
-                *reinterpret_cast<float4*>(a.gate_z + co + a.M + 8 * q) =
-                    make_float4(dz.x * f4.x * s4.x * (1.f - s4.x), dz.y * f4.y * s4.y * (1.f - s4.y),
-                                dz.z * f4.z * s4.z * (1.f - s4.z), dz.w * f4.w * s4.w * (1.f - s4.w));
+                const float4 f4 = tf[q], s4 = ts[q];
+                da[q] = make_float4(dz.x * s4.x * (1.f - f4.x * f4.x), dz.y * s4.y * (1.f - f4.y * f4.y),
+                                    dz.z * s4.z * (1.f - f4.z * f4.z), dz.w * s4.w * (1.f - f4.w * f4.w));
+                dg[q] = make_float4(dz.x * f4.x * s4.x * (1.f - s4.x), dz.y * f4.y * s4.y * (1.f - s4.y),
+                                    dz.z * f4.z * s4.z * (1.f - s4.z), dz.w * f4.w * s4.w * (1.f - s4.w));
             }
+            tile_store_rows(patch, lane, da, a.gate_z, 2 * a.M, col, rm);            // [da | dg]: row stride 2 M
+            tile_store_rows(patch, lane, dg, a.gate_z, 2 * a.M, a.M + col, rm);
         }
         return;
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (t0 + mt >= mtiles) break;
-        float* __restrict__ orow = (MODE == 2) ? a.out[t0 + mt] + no * a.ldo + 4 * h
-                                               : a.out[0] + no * a.ldo + (t0 + mt) * 32 + 4 * h;
+        float* __restrict__ og = (MODE == 2) ? a.out[t0 + mt] : a.out[0];
+        const int col = (MODE == 2) ? 0 : (t0 + mt) * 32;
+        float4 t[4], v[4], u[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 v = make_float4(acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
-            float* p = orow + 8 * q;
-            if (MODE == 0 && a.gate_x) {
-                const float4 gx = *reinterpret_cast<const float4*>(a.gate_x + no * a.ldo + (t0 + mt) * 32 + 4 * h + 8 * q);
-                v.x *= act_grad(gx.x, a.gate_act); v.y *= act_grad(gx.y, a.gate_act);
-                v.z *= act_grad(gx.z, a.gate_act); v.w *= act_grad(gx.w, a.gate_act);
+        for (int q = 0; q < 4; ++q) t[q] = make_float4(acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
+        if (MODE == 0 && a.gate_x) {
+            rows_load(a.gate_x, a.ldo, col, rm, lane, v);
+            rows_to_tile(patch, lane, v, u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                t[q].x *= act_grad(u[q].x, a.gate_act); t[q].y *= act_grad(u[q].y, a.gate_act);
+                t[q].z *= act_grad(u[q].z, a.gate_act); t[q].w *= act_grad(u[q].w, a.gate_act);
             }
-            if (MODE == 0 && a.residual) {
-                const float4 rr = *reinterpret_cast<const float4*>(a.residual + no * a.ldo + (t0 + mt) * 32 + 4 * h + 8 * q);
-                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-            }
-            if (a.accumulate) {
-                const float4 o = *reinterpret_cast<const float4*>(p);
-                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-            }
-            *reinterpret_cast<float4*>(p) = v;
         }
+        if (MODE == 0 && a.residual) {
+            rows_load(a.residual, a.ldo, col, rm, lane, v);
+            rows_to_tile(patch, lane, v, u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { t[q].x += u[q].x; t[q].y += u[q].y; t[q].z += u[q].z; t[q].w += u[q].w; }
+        }
+        if (a.accumulate) {
+            rows_load(og, a.ldo, col, rm, lane, v);
+            rows_to_tile(patch, lane, v, u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { t[q].x += u[q].x; t[q].y += u[q].y; t[q].z += u[q].z; t[q].w += u[q].w; }
+        }
+        tile_store_rows(patch, lane, t, og, a.ldo, col, rm);
     }
 }
 
