@@ -813,6 +813,10 @@ def test_train_step_graph_replay_equals_eager_steps(window_only):
     _, _, graphed = build(over, seed=21)
     for n in (eager, graphed):
         n.update_laerning_rate(0.01)
+        # Adam divides by sqrt(v) + eps: with the default eps = 1e-8 an element whose gradient sits at the float-atomic noise
+        # floor moves by a visible fraction of lr in a noise-dependent direction (3 % of the weights differ by up to 2.5e-3
+        # between two EAGER runs with the exact-fp32 GEMM kernels).  A larger eps keeps the comparison about graph vs eager.
+        n.optimizer.eps = 1e-3
     B, T = 2, 700
     iw = eager.input_width
     rs = np.random.RandomState(0)
@@ -832,10 +836,7 @@ def test_train_step_graph_replay_equals_eager_steps(window_only):
     assert graphed.optimizer.t == eager.optimizer.t == 4
     a, b = to_np(eager._arena), to_np(graphed._arena)
     assert np.abs(a - w0).max() > 1e-3                                # the weights did move
-    # Adam divides by sqrt(v): an element whose gradient is at the float-atomic noise floor can move by a visible fraction
-    # of lr on either side, so the bar is "all but a handful of elements to 2e-5, none further than lr / 2"
-    diff = np.abs(b - a)
-    assert np.mean(diff > 2e-5) < 1e-3 and diff.max() < 5e-3, (np.mean(diff > 2e-5), diff.max())
+    np.testing.assert_allclose(b, a, atol=2e-5)
 
 
 def test_config5_topology_fp32_forward_and_grads():
