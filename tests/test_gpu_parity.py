@@ -494,10 +494,10 @@ def test_graph_replay_with_a_rule_optimizer_matches_eager():
     nets = []
     for _ in range(2):
         p, w, net = build(CFG1, seed=4)
-        net.params.optimizer = "rmsprop"
+        net.params.optimizer = "nesterov"           # linear in the gradient: atomic-order noise is not amplified
         net.setup_optimizer()
         net.optimizer.to(net.device)
-        net.update_laerning_rate(0.003)
+        net.update_laerning_rate(0.05)
         nets.append(net)
     a, b = nets
     b._arena.copy_(a._arena)
