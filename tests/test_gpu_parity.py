@@ -1061,8 +1061,10 @@ def test_fused_wide_layer_projection_uses_its_own_z(bf16_gemms, d, B, T, bias):
 
 
 @pytest.mark.gpu
-def test_bf16_gemm_gradients_stay_close_to_fp32(bf16_gemms):
-    p, w, net = build(CFG5S, seed=9)
+@pytest.mark.parametrize("width", [64, 128])
+def test_bf16_gemm_gradients_stay_close_to_fp32(bf16_gemms, width):
+    """width 128 runs config 5's layer kernels (fused forward, gate-backward epilogue, one wide weight-gradient launch)."""
+    p, w, net = build(dict(CFG5S, causal_conv_channels=[width], residual_conv_channels=[width] * 3), seed=9)
     rs = np.random.RandomState(1)
     iw = R.input_width(p)
     tok = rs.randint(0, 256, size=(2, iw + 40)).astype(np.int32)
