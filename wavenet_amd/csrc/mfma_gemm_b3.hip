@@ -918,11 +918,12 @@ int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
     for (int q = 0; q < a.nprob; ++q) { any_b2 |= a.B2p[q] != nullptr; all_b2 &= a.B2p[q] != nullptr; }
     if (any_b2 != all_b2) { wn::set_error("wgrad_b3w: the B2 factor must be given for all problems or for none"); return WN_EARG; }
     const dim3 grid(a.nB * a.wgs_per_b, gy);
-    // Few 32-row chunks per workgroup (config 5's per-layer gradients: 16): the 64 K atomics every workgroup ends with cost
-    // more than its contraction -- partial tiles + one reduction instead.  Long slabs (config 2's dWs: 85 chunks) keep the
-    // atomics: there the two cost the same and the partial tiles would be 60 MB of extra traffic.
+    // The result leaves as per-workgroup partial tiles (plain coalesced stores) that k_wgrad_b3w_reduce sums in a fixed
+    // order.  With few 32-row chunks per workgroup (config 5's per-layer gradients: 16) the alternative -- 64 K float
+    // atomics per workgroup into the same addresses -- cost more than the contraction; with long slabs (config 2's dWs: 85
+    // chunks) the two cost the same (the partial tiles are ~60 MB of extra traffic) and this form is deterministic.
     a.part = nullptr;
-    if (rows / 32 < 48) {
+    {
         const size_t bytes = (size_t)grid.x * grid.y * 8 * (8 * 16 * 64) * sizeof(float);
         a.part = reinterpret_cast<float*>(scratch_for(s, bytes));
         if (!a.part) { wn::set_error("wgrad_b3w: cannot allocate %zu bytes of partial-tile scratch", bytes); return WN_EHIP; }

@@ -598,25 +598,35 @@ __global__ void k_layer_bwd_reduce(const float* __restrict__ part, int nwg, floa
 // every layer's partial tiles and reduces them all at the end, instead of 40 small launches between the layer kernels.
 static constexpr int kRedAllMax = 64;
 struct RedAllArgs { float* dWf[kRedAllMax]; float* dWg[kRedAllMax]; float* dWp[kRedAllMax]; int nwg[kRedAllMax]; };
+// Deterministic: a block owns 64 elements; its four waves each sum a quarter of the workgroups' tiles (whole 256-byte rows
+// per load), the quarters are added in a fixed order through LDS, and the owner adds the total to dW without an atomic.
 __global__ void k_layer_bwd_reduce_all(const float* __restrict__ part, long long layer_stride, RedAllArgs a) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= kPartFloats) return;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, sp = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;                    // kPartFloats is a multiple of 64
     const int l = blockIdx.z;
     const int nwg = a.nwg[l];
-    const float* __restrict__ p = part + (long long)l * layer_stride;
-    const int per = (nwg + kRedParts - 1) / kRedParts;
-    const int w0 = blockIdx.y * per, w1 = min(nwg, w0 + per);
-    if (w1 <= w0) return;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int w = w0; w < w1; ++w) acc += p[(long long)w * kPartFloats + e];
-    const int tile = e >> 10, r = (e >> 6) & 15, lane = e & 63;
-    const int j = lane & 31, i = bch(r, lane >> 5);
+    const float* __restrict__ p = part + (long long)l * layer_stride + e;
+    const int per = (nwg + 3) / 4;
+    const int w0 = sp * per, w1 = min(nwg, w0 + per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int w = w0;
+    for (; w + 4 <= w1; w += 4) {
+        s0 += p[(long long)(w + 0) * kPartFloats]; s1 += p[(long long)(w + 1) * kPartFloats];
+        s2 += p[(long long)(w + 2) * kPartFloats]; s3 += p[(long long)(w + 3) * kPartFloats];
+    }
+    for (; w < w1; ++w) s0 += p[(long long)w * kPartFloats];
+    red[sp][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sp != 0) return;
+    const float acc = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const int tile = e >> 10, r = (e >> 6) & 15, ln = e & 63;
+    const int j = ln & 31, i = bch(r, ln >> 5);
     if (tile < 4) {
         float* dW = tile < 2 ? a.dWf[l] : a.dWg[l];
-        if (dW) atomicAdd(dW + (i * 32 + j) * 2 + (tile & 1), acc);
+        if (dW) dW[(i * 32 + j) * 2 + (tile & 1)] += acc;
     } else if (a.dWp[l]) {
-        atomicAdd(a.dWp[l] + i * 32 + j, acc);
+        a.dWp[l][i * 32 + j] += acc;
     }
 }
 
@@ -768,7 +778,7 @@ int mfma_chain_reduce_all(const float* part, int L, const int* nwg, float* const
         for (int l = 0; l < n; ++l) {
             a.dWf[l] = dWf[l0 + l]; a.dWg[l] = dWg[l0 + l]; a.dWp[l] = dWp[l0 + l]; a.nwg[l] = nwg[l0 + l];
         }
-        hipLaunchKernelGGL(k_layer_bwd_reduce_all, dim3(kPartFloats / 256, kRedParts, n), dim3(256), 0, s,
+        hipLaunchKernelGGL(k_layer_bwd_reduce_all, dim3(kPartFloats / 64, 1, n), dim3(256), 0, s,
                            part + (size_t)l0 * mfma_chain_part_floats(), (long long)mfma_chain_part_floats(), a);
         WN_LAUNCH_CHECK();
     }
