@@ -57,7 +57,7 @@ struct WGArgs {
     int offp[WN_MAX_SRC];
     float* out2[WN_MAX_SRC];
     int m_split;
-    float* part;                     // when set: per-workgroup partial tiles go here (plain stores) and a second kernel sums them
+    float* part;                     // wide block: per-workgroup partial tiles go here (plain stores), a second kernel sums them
 };
 
 // 1 unless WAVENET_HIP_GEMM=fp32: contractions use three-way bf16 splits (6 bf16 MFMAs per product term)

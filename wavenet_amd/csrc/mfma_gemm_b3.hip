@@ -846,26 +846,14 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
         }
     }
     if (!active) return;
-    if (a.part) {
-        // [workgroup][wave = problem][mt][r][lane]: whole 256-byte rows per store instruction, no atomics.  (With 256
-        // workgroups adding 64 K values each into the SAME 64 K addresses, the atomics were 98 of this kernel's 155 us at
-        // config 5's layer shapes.)
-        float* __restrict__ o = a.part + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv) * (MT * 16 * 64) + lane;
+    // [workgroup][wave = problem][mt][r][lane]: whole 256-byte rows per store instruction, no atomics; k_wgrad_b3w_reduce
+    // sums the workgroups' tiles.  (256 workgroups adding 64 K values each into the SAME 64 K addresses with float atomics
+    // were 98 of this kernel's 155 us at config 5's layer shapes.)
+    float* __restrict__ o = a.part + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv) * (MT * 16 * 64) + lane;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[(mt * 16 + r) * 64] = acc[mt][r];
-        return;
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const bool second = a.m_split > 0 && mt * 32 >= a.m_split;
-        float* __restrict__ o = second ? a.out2[p] : a.out[p];
-        const int mrow = mt * 32 - (second ? a.m_split : 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            atomicAdd(o + (long long)(mrow + b3_ch(r, h)) * a.ldo + (long long)j * (a.osk ? a.osk : 1), acc[mt][r]);
-    }
+        for (int r = 0; r < 16; ++r) o[(mt * 16 + r) * 64] = acc[mt][r];
 }
 
 // Sum of the partial tiles of k_wgrad_b3w: one thread per output element, the workgroups' tiles of one (problem, mt, r)
@@ -922,12 +910,9 @@ int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
     // order.  With few 32-row chunks per workgroup (config 5's per-layer gradients: 16) the alternative -- 64 K float
     // atomics per workgroup into the same addresses -- cost more than the contraction; with long slabs (config 2's dWs: 85
     // chunks) the two cost the same (the partial tiles are ~60 MB of extra traffic) and this form is deterministic.
-    a.part = nullptr;
-    {
-        const size_t bytes = (size_t)grid.x * grid.y * 8 * (8 * 16 * 64) * sizeof(float);
-        a.part = reinterpret_cast<float*>(scratch_for(s, bytes));
-        if (!a.part) { wn::set_error("wgrad_b3w: cannot allocate %zu bytes of partial-tile scratch", bytes); return WN_EHIP; }
-    }
+    const size_t part_bytes = (size_t)grid.x * grid.y * 8 * (8 * 16 * 64) * sizeof(float);
+    a.part = reinterpret_cast<float*>(scratch_for(s, part_bytes));
+    if (!a.part) { wn::set_error("wgrad_b3w: cannot allocate %zu bytes of partial-tile scratch", part_bytes); return WN_EHIP; }
     const bool one = one_term();
 #define W_LAUNCH(B2_, ACT_)                                                                                     \
     do {                                                                                                        \
@@ -945,10 +930,8 @@ int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
 #undef W_LAUNCH_A
 #undef W_LAUNCH
     WN_LAUNCH_CHECK();
-    if (a.part) {
-        hipLaunchKernelGGL(k_wgrad_b3w_reduce, dim3(128 / 4, a.nprob), dim3(256), 0, s, a, (int)grid.x);
-        WN_LAUNCH_CHECK();
-    }
+    hipLaunchKernelGGL(k_wgrad_b3w_reduce, dim3(128 / 4, a.nprob), dim3(256), 0, s, a, (int)grid.x);
+    WN_LAUNCH_CHECK();
     return WN_OK;
 }
 
