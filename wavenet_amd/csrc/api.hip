@@ -92,6 +92,14 @@ size_t wn_layer_bwd_workspace_floats(int B, int T, int Cr, int Cd, int fw) {
     return n;
 }
 
+}  // extern "C"
+namespace wn {
+bool wide_layer_in_use(int Cr, int Cd, int fw) {
+    return !wn_layer_fast_path(Cr, Cd, fw) && !force_generic() && wide_layer_supported(Cr, Cd, fw);
+}
+}  // namespace wn
+extern "C" {
+
 int wn_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
                  const float* Wp, const float* dout, const float* dz_skip, float* dx, float* dWf, float* dbf,
                  float* dWg, float* dbg, float* dWp, float* dbp, float* dab_ws, int B, int T, int Cr, int Cd,

@@ -192,6 +192,13 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
         const float* in = l == 0 ? x : xs + (size_t)(l - 1) * n * d->Cr;
         float* gin = (l == 0) ? dx : gbuf[l & 1];
         int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
+        if (wide_layer_in_use(d->Cr, d->cd[l], d->fw)) {      // the stack still holds z = f g: the projection gradient reads it
+            wn::ProfScope prof__("wn_layer_bwd", stream);
+            rc = wide_layer_bwd(in, f + off[l], g + off[l], d->Wf[l], d->Wg[l], d->Wp[l], gout, dskip ? dzp[l] : nullptr,
+                                gin, dWf[l], dbf ? dbf[l] : nullptr, dWg[l], dbg ? dbg[l] : nullptr,
+                                gout ? dWp[l] : nullptr, (gout && dbp) ? dbp[l] : nullptr, dab, B, T, d->Cr, d->cd[l],
+                                d->fw, d->dilation[l], Z, as_stream(stream), z + off[l]);
+        } else
         rc = wn_layer_bwd(in, f + off[l], g + off[l], d->Wf[l], d->Wg[l], d->Wp[l], gout, dskip ? dzp[l] : nullptr, gin,
                           dWf[l], dbf ? dbf[l] : nullptr, dWg[l], dbg ? dbg[l] : nullptr, gout ? dWp[l] : nullptr,
                           (gout && dbp) ? dbp[l] : nullptr, dab, B, T, d->Cr, d->cd[l], d->fw, d->dilation[l], Z, stream);

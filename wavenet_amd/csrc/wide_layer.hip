@@ -144,7 +144,7 @@ static int conv_wgrad(const float* A, const float* x, float* dW, int B, int T, i
 static int wide_layer_bwd_256(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
                               const float* Wp, const float* dout, const float* dzs, float* dx, float* dWf, float* dbf,
                               float* dWg, float* dbg, float* dWp, float* dbp, float* ws, int B, int T, int Cr, int Cd,
-                              int fw, int d, int Z, hipStream_t s) {
+                              int fw, int d, int Z, const float* z, hipStream_t s) {
     const long long n = (long long)B * T;
     float* dadg = ws;                // (B,T,2 Cd)
     int rc;
@@ -191,8 +191,8 @@ static int wide_layer_bwd_256(const float* x, const float* f, const float* g, co
     if (dWp && dout) {               // dWp[cr][cd] += sum dout[n][cr] * (f g)[n][cd]
         WGArgs a{};
         a.A = dout; a.lda = Cr; a.nprob = 0;
-        for (int c = 0; c < Cd; c += 32) {
-            a.Bp[a.nprob] = f + c; a.B2p[a.nprob] = g + c; a.out[a.nprob] = dWp + c; ++a.nprob;
+        for (int c = 0; c < Cd; c += 32) {       // z itself when the caller still has it (one tensor instead of f and g)
+            a.Bp[a.nprob] = (z ? z : f) + c; a.B2p[a.nprob] = z ? nullptr : g + c; a.out[a.nprob] = dWp + c; ++a.nprob;
         }
         a.ldb = Cd; a.ldo = Cd; a.osk = 1;
         a.nB = B; a.rows_A_per_b = T; a.rows_B_per_b = T; a.off = 0; a.act = WN_ACT_NONE;
@@ -207,11 +207,11 @@ static int wide_layer_bwd_256(const float* x, const float* f, const float* g, co
 int wide_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg, const float* Wp,
                    const float* dout, const float* dzs, float* dx, float* dWf, float* dbf, float* dWg, float* dbg,
                    float* dWp, float* dbp, float* ws, int B, int T, int Cr, int Cd, int fw, int d, int Z,
-                   hipStream_t s) {
+                   hipStream_t s, const float* z) {
     const long long n = (long long)B * T;
     if (gemm_b3_enabled() && 2 * Cd == 256 && Cr % 32 == 0 && (Cr / 32) * fw <= 8 && dWf && dWg)
         return wide_layer_bwd_256(x, f, g, Wf, Wg, Wp, dout, dzs, dx, dWf, dbf, dWg, dbg, dWp, dbp, ws, B, T, Cr, Cd, fw, d,
-                                  Z, s);
+                                  Z, z, s);
     float* da = ws;                  // (B,T,Cd): dz first, then da in place
     float* dg = ws + n * Cd;         // (B,T,Cd)
     int rc;
@@ -247,7 +247,7 @@ int wide_layer_bwd(const float* x, const float* f, const float* g, const float* 
             WGArgs a{};
             a.A = dout; a.lda = Cr; a.nprob = 0;
             for (int c = c0; c < Cd && a.nprob < WN_MAX_SRC; c += 32) {
-                a.Bp[a.nprob] = f + c; a.B2p[a.nprob] = g + c; a.out[a.nprob] = dWp + c; ++a.nprob;
+                a.Bp[a.nprob] = (z ? z : f) + c; a.B2p[a.nprob] = z ? nullptr : g + c; a.out[a.nprob] = dWp + c; ++a.nprob;
             }
             a.ldb = Cd; a.ldo = Cd; a.osk = 1;
             a.nB = B; a.rows_A_per_b = T; a.rows_B_per_b = T; a.off = 0; a.act = WN_ACT_NONE;

@@ -78,7 +78,8 @@ int wide_layer_fwd(const float* x, const float* Wf, const float* bf, const float
 int wide_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg, const float* Wp,
                    const float* dout, const float* dzs, float* dx, float* dWf, float* dbf, float* dWg, float* dbg,
                    float* dWp, float* dbp, float* ws, int B, int T, int Cr, int Cd, int fw, int d, int Z,
-                   hipStream_t s);
+                   hipStream_t s, const float* z = nullptr);   // z = f g when the caller still has it (dWp reads one tensor)
+bool wide_layer_in_use(int Cr, int Cd, int fw);               // api.hip: the per-layer entry points route this shape to wide_layer_*
 
 // ---- mfma_gemm.hip: fp32-MFMA channel GEMMs over time columns (all widths multiples of 32) ---
 bool mfma_skip_supported(int L, const int* cd, int Cs);
