@@ -204,9 +204,10 @@ def main():
     # backward, clip + Adam; with N > 1 the RCCL all-reduce runs between a forward/backward graph and an optimiser
     # graph) and each timed step is one replay.  --no-graph times the same step launched op by op.
     graph = None
-    # N > 1: op-by-op launches by default (the gain of a replayed step is ~3 % and the two-graph data-parallel form has only
-    # been exercised with two ranks sharing one GPU); WAVENET_BENCH_GRAPH_DP=1 turns it on
-    use_graph = not args.no_graph and (world == 1 or os.environ.get("WAVENET_BENCH_GRAPH_DP") == "1")
+    # N > 1: forward/backward graph -> RCCL all-reduce (launched normally, never captured) -> optimiser graph, so that every N
+    # is measured in the same launch form (WAVENET_BENCH_GRAPH_DP=0 or --no-graph: op-by-op launches).  The graphs hold only
+    # this library's kernels; the communicator is created by the first eager all-reduce, outside any capture.
+    use_graph = not args.no_graph and (world == 1 or os.environ.get("WAVENET_BENCH_GRAPH_DP", "1") != "0")
     if use_graph:
         try:
             graph = TrainStepGraph(net, x, tgt)
