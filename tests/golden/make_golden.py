@@ -76,13 +76,53 @@ def fastgen_trace():
                             probs=np.array(tr, np.float32), uniforms=u)
 
 
+CFG2 = dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 10,
+            residual_num_blocks=4, softmax_conv_channels=[256, 256])
+
+
+def cfg4_decode_trace(n=256, margin=2e-5):
+    """BASELINE config 4 (train_audio/generate.py:24-43 with --fast at config 2's 4 x 10 topology, window 4094): the
+    oracle's literal queue-cached generation for 256 steps.  Weights: the product's own seeded initialisation
+    (``WaveNet(Params, seed=1234)``, CPU only -- identical to the oracle's ``init_weights(p, 1234)``, asserted) so that
+    bench.py can reproduce them without importing the oracle.  Uniforms start as ``RandomState(7).random_sample``; a draw
+    that lands within ``margin`` of a boundary of the step's cumulative distribution is replaced by the next draw of a
+    second stream, so that the committed token sequence does not hinge on the last bit of a probability."""
+    from wavenet_amd import Params, WaveNet
+    p = R.make_params(**CFG2)
+    w = WaveNet(Params(p), seed=1234).state_dict()
+    w0 = R.init_weights(p, 1234)
+    assert all(np.array_equal(w[k], w0[k]) for k in w0) and len(w) == len(w0)
+    iw = R.input_width(p)
+    u = np.random.RandomState(7).random_sample(n)
+    spare = np.random.RandomState(8)
+    model = R.RefFasterWaveNet(p, w, "elu")
+    buf = np.full((iw,), 127, dtype=np.int32)
+    probs, replaced = [], 0
+    for step in range(n):
+        x = D.onehot_pixel_image(buf[-iw:].reshape(1, -1), 256)
+        prob = model._forward_one_step(x, apply_softmax=True)[0, :, 0, -1]
+        cdf = np.cumsum(prob.astype(np.float64)); cdf /= cdf[-1]
+        while np.abs(cdf - u[step]).min() < margin:
+            u[step] = spare.random_sample(); replaced += 1
+        probs.append(prob.copy())
+        buf = np.append(buf, [R.choice_from_uniform(prob, u[step])]).astype(np.int32)
+    toks = buf[iw:]
+    np.savez_compressed(os.path.join(OUT, "cfg4_decode_trace.npz"), tokens=toks.astype(np.uint8), uniforms=u,
+                        probs_every8=np.array(probs[::8], np.float32), margin=np.array(margin),
+                        replaced=np.array(replaced))
+    print("cfg4 trace: %d draws replaced, token sum %d" % (replaced, int(toks.sum())))
+
+
 def mulaw_table():
     q = D.mulaw_quantize_pcm16(np.arange(-32768, 32768))
     np.savez_compressed(os.path.join(OUT, "mulaw_pcm16.npz"), table=q.astype(np.uint8))
 
 
 if __name__ == "__main__":
-    kat1(); cfg1_forward(); cfg1_train_step(); fastgen_trace(); mulaw_table()
+    only = sys.argv[1:]
+    for fn in (kat1, cfg1_forward, cfg1_train_step, fastgen_trace, mulaw_table, cfg4_decode_trace):
+        if not only or fn.__name__ in only:
+            fn()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

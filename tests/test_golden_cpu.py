@@ -63,3 +63,22 @@ def test_fastgen_fixture():
 def test_mulaw_fixture():
     z = np.load(os.path.join(G, "mulaw_pcm16.npz"))
     np.testing.assert_array_equal(D.mulaw_quantize_pcm16(np.arange(-32768, 32768)), z["table"].astype(np.int32))
+
+
+def test_cfg4_decode_fixture_first_steps_and_weights():
+    """The 256-step config-4 trace (4 x 10 layers, window 4094): its weights are the product's seeded CPU initialisation,
+    equal to the oracle's; the oracle reproduces its first tokens; every stored uniform keeps the stated margin."""
+    from wavenet_amd import Params, WaveNet
+    z = np.load(os.path.join(G, "cfg4_decode_trace.npz"))
+    p = R.make_params(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 10,
+                      residual_num_blocks=4, softmax_conv_channels=[256, 256])
+    w = R.init_weights(p, 1234)
+    sd = WaveNet(Params(p), seed=1234).state_dict()
+    assert set(sd) == set(w) and all(np.array_equal(sd[k], w[k]) for k in w)
+    tr = []
+    toks = R.generate(p, w, 3, z["uniforms"], fast=True, fast_head_act="elu", trace=tr)
+    np.testing.assert_array_equal(toks, z["tokens"][:3].astype(np.int32))
+    np.testing.assert_allclose(tr[0], z["probs_every8"][0], atol=1e-6)
+    assert z["tokens"].shape == (256,) and z["uniforms"].shape == (256,)
+    cdf = np.cumsum(tr[2].astype(np.float64)); cdf /= cdf[-1]
+    assert np.abs(cdf - z["uniforms"][2]).min() >= float(z["margin"])

@@ -21,12 +21,30 @@ class DataParallel(object):
         self.broadcast_weights()
 
     def broadcast_weights(self, src: int = 0):
-        """Every replica starts from rank ``src``'s weights and optimiser state."""
+        """Every replica starts from rank ``src``'s weights and optimiser state: the moment arrays, the step counter
+        (Adam's bias correction depends on it: a rank that resumed a checkpoint must not run ahead of the others) and the
+        host scalars of the rule in use (alpha / lr / momentum, Eve's loss-feedback pair d, f)."""
+        opt = self.net.optimizer
         with torch.no_grad():
             dist.broadcast(self.net._arena, src, group=self.group)
-            dist.broadcast(self.net.optimizer.m, src, group=self.group)
-            dist.broadcast(self.net.optimizer.v, src, group=self.group)
+            dist.broadcast(opt.m, src, group=self.group)
+            dist.broadcast(opt.v, src, group=self.group)
+        names = [k for k in ("t", "alpha", "beta1", "beta2", "beta3", "eps", "lr", "hyper", "d", "f")
+                 if k in vars(opt)]                        # instance attributes only (Adam's `lr` is a derived property)
+        vals = torch.tensor([float(getattr(opt, k)) for k in names], dtype=torch.float64, device=self.net._arena.device)
+        dist.broadcast(vals, src, group=self.group)
+        for k, v in zip(names, vals.tolist()):
+            setattr(opt, k, int(round(v)) if k == "t" else v)
         self.net._weights_changed()
+
+    def mean_loss(self, loss: float) -> float:
+        """The global-batch loss (mean over ranks of the equal-shard means): what Eve's feedback term must see on every rank
+        (wavenet.py:73-79 feeds it the loss of the whole minibatch)."""
+        if self.world == 1:
+            return float(loss)
+        t = torch.tensor([float(loss)], dtype=torch.float64, device=self.net._arena.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return float(t.item()) / self.world
 
     def all_reduce_grads(self, flat_grad: torch.Tensor) -> float:
         """Sum the flat gradient buffer over ranks in place; returns the multiplier (1/world) that

@@ -45,28 +45,44 @@ class TrainStepGraph(object):
         # training state back: the warm-up steps are not training steps
         keep = (net._arena.clone(), opt.m.clone(), opt.v.clone(), opt.t)
         self._stream = torch.cuda.Stream(device=x.device)
-        self._stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self._stream):
-            for _ in range(max(1, warmup)):
-                self._fwd_bwd()
-                self._opt()
-        torch.cuda.current_stream().wait_stream(self._stream)
-        torch.cuda.synchronize()
-        with torch.no_grad():
-            net._arena.copy_(keep[0]); opt.m.copy_(keep[1]); opt.v.copy_(keep[2])
         self._g1 = torch.cuda.CUDAGraph()
         self._g2 = None
-        # thread_local: API calls of other threads (an RCCL watchdog, a data loader) must not invalidate the capture
-        with torch.cuda.graph(self._g1, stream=self._stream, capture_error_mode="thread_local"):
-            self.loss = self._fwd_bwd()
-            if not dp:
-                self._opt()
-        if dp:
-            self._g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g2, stream=self._stream, pool=self._g1.pool(), capture_error_mode="thread_local"):
-                self._opt()
-        opt.t = keep[3]
-        net._weights_changed()
+        try:
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                for _ in range(max(1, warmup)):
+                    self._fwd_bwd()
+                    self._opt()
+            torch.cuda.current_stream().wait_stream(self._stream)
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                net._arena.copy_(keep[0]); opt.m.copy_(keep[1]); opt.v.copy_(keep[2])
+            # thread_local: API calls of other threads (an RCCL watchdog, a data loader) must not invalidate the capture
+            with torch.cuda.graph(self._g1, stream=self._stream, capture_error_mode="thread_local"):
+                self.loss = self._fwd_bwd()
+                if not dp:
+                    self._opt()
+            if dp:
+                self._g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._g2, stream=self._stream, pool=self._g1.pool(),
+                                      capture_error_mode="thread_local"):
+                    self._opt()
+            self._snap = self._hyper()
+        finally:
+            # whatever happened above (a failed capture included), the warm-up and capture steps were not training steps:
+            # weights, moments and the optimiser clock go back to what the caller handed in
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                net._arena.copy_(keep[0]); opt.m.copy_(keep[1]); opt.v.copy_(keep[2])
+            opt.t = keep[3]
+            net._weights_changed()
+
+    def _hyper(self):
+        """Everything a captured kernel node took BY VALUE: replaying after one of these changed would silently train with
+        the old value (only the batch and the learning rate travel through device memory)."""
+        opt, p = self.net.optimizer, self.net.params
+        return tuple(getattr(opt, k, None) for k in ("beta1", "beta2", "beta3", "eps", "hyper")) + \
+            (p.gradient_clipping, p.weight_decay, _lib.get_gemm_precision())
 
     def _fwd_bwd(self):
         self.net.zero_grads()
@@ -81,6 +97,10 @@ class TrainStepGraph(object):
         """One training step on (x, tgt) (default: the batch already in the static buffers).  Returns the loss
         (a device scalar that the next step overwrites)."""
         net, opt = self.net, self.net.optimizer
+        if self._hyper() != self._snap:
+            raise _lib.WaveNetHipError(
+                "momentum / eps / gradient_clipping / weight_decay / GEMM precision changed after the step was captured "
+                "(%r -> %r): capture a new TrainStepGraph" % (self._snap, self._hyper()))
         if x is not None:
             self.x.copy_(x, non_blocking=True)
         if tgt is not None:

@@ -612,7 +612,10 @@ class WaveNet(object):
         if self._dp_group is not None:
             gmult = self._dp_group.all_reduce_grads(self._grad_arena)
         if isinstance(self.optimizer, EveState):
-            self.optimizer.update(gmult, loss=float(loss.detach()))      # Eve feeds the loss back (wavenet.py:73-79)
+            lv = float(loss.detach())                                    # Eve feeds the loss back (wavenet.py:73-79)
+            if self._dp_group is not None:
+                lv = self._dp_group.mean_loss(lv)                        # ... the global batch's, identical on every rank
+            self.optimizer.update(gmult, loss=lv)
         else:
             self.optimizer.update(gmult)
         self._weights_changed()
