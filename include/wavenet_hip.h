@@ -266,6 +266,42 @@ int wn_rule_step(int rule, float* param, const float* grad, float* s1, float* s2
                  const float* lr_dev, float hyper, float eps, float weight_decay, const float* sqnorm, float clip,
                  float grad_mult, void* stream);
 
+/* ======================================================================================================
+ * bf16-storage path (BASELINE.json configs[4]: 128 residual / dilation channels, 512 skip channels): activations are
+ * bfloat16 in HBM (uint16_t = raw bf16 bits, same (B, T, C) layout), every contraction accumulates in fp32 on
+ * v_mfma_f32_32x32x16_bf16, the weights stay fp32 (master copy, gradients, optimiser) and are repacked into bf16
+ * matrix-core operand images once per step.  Same reference operations as the fp32 entry points above
+ * (ResidualConvLayer.__call__ wavenet.py:358-368, forward_residual_block 572-582, forward_softmax_block 584-593 and
+ * their backward).  Covers: Cr = Cd = 128, filter width 2, Cs a multiple of 256, an even number of layers (<= 48), no
+ * conv / projection biases (the reference default); wn16_supported() says whether a stack qualifies.
+ * The forward keeps only each layer's output and z; tanh / sigmoid are recomputed by the backward.
+ * ====================================================================================================== */
+int wn16_supported(const WnStackDesc* d);
+/* bf16 elements of the packed operand images of a stack (per-layer images + the skip matrix and its transpose) */
+size_t wn16_pack_elems(const WnStackDesc* d);
+int wn16_pack_stack(const WnStackDesc* d, uint16_t* pack, void* stream);
+/* A10 on tokens, bf16 output (filter width 2) */
+int wn16_embed_fwd(const int32_t* idx, const float* W, const float* bias, uint16_t* out, int B, int T, int Q, int C,
+                   int fw, void* stream);
+int wn16_cvt_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);     /* n % 8 == 0 */
+int wn16_cvt_to_f32(const uint16_t* src, float* dst, int64_t n, void* stream);
+/* A11: xs (L,B,T,128) every layer's output, z (L,B,T,128), skip (B,T-t_off,Cs) or NULL */
+int wn16_stack_fwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x, uint16_t* xs, uint16_t* z,
+                   uint16_t* skip, int B, int T, int t_off, int compat_zero_prefix, void* stream);
+size_t wn16_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T, int t_off);
+/* A15: dout (B,T,128) or NULL, dskip (B,T-t_off,Cs) or NULL, dx (B,T,128) or NULL; fp32 gradients accumulated */
+int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x, const uint16_t* xs, const uint16_t* z,
+                   const uint16_t* dout, const uint16_t* dskip, uint16_t* dx, float* const* dWf, float* const* dWg,
+                   float* const* dWp, float* const* dWs, void* ws, size_t ws_bytes, int B, int T, int t_off,
+                   int compat_zero_prefix, void* stream);
+/* A12: Wb (Cout,Cin) and WbT (Cin,Cout) are the bf16 images of W; out is bf16 or fp32 (out_f32) */
+int wn16_pack_pointwise(const float* W, uint16_t* Wb, uint16_t* WbT, int Cout, int Cin, void* stream);
+int wn16_pointwise_fwd(const uint16_t* x, const uint16_t* Wb, const float* bias, void* out, int out_f32, int64_t N,
+                       int Cin, int Cout, int act, void* stream);
+int wn16_pointwise_bwd(const uint16_t* x, const uint16_t* WbT, const uint16_t* dout, const float* dout_f32,
+                       uint16_t* dout_scratch, uint16_t* dx, float* dW, float* dbias, int64_t N, int Cin, int Cout,
+                       int act, void* stream);
+
 /* ---- measurement aid (bench.py): per-entry-point HIP-event timing on the caller's stream ------- */
 int wn_prof_enable(int on);                    /* 1: clear + start recording, 0: stop               */
 /* "name calls total_ms min_ms max_ms" per line into buf; returns the bytes needed (synchronises). */

@@ -1,0 +1,184 @@
+"""GPU parity of the bf16-storage path (BASELINE config 5: 128 residual / dilation channels, bf16 activations in HBM, fp32
+accumulation) against oracle/bf16_ref.py, the CPU restatement that rounds to bfloat16 exactly where the kernels store or
+feed a matrix core (forward AND backward).  Tolerances: stored bf16 tensors within 2 bf16 ulp of the oracle's (an fp32
+vs float64 sum that lands on the other side of a rounding tie), logits 2e-2, loss 1e-3, every gradient tensor within
+1e-2 of the oracle's in the 2-norm (VERDICT r1 next #1b); reference ops: wavenet.py:358-368, 556-617."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bf16_ref as Q
+from oracle import wavenet_ref as R
+from wavenet_amd import Params, TrainStepGraph, WaveNet
+
+from gpu_util import dev, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def build16(over, seed=1234, head_bias=0.3):
+    p = R.make_params(**over)
+    w = R.init_weights(p, seed)
+    if head_bias:
+        for i in range(len(p["softmax_conv_channels"]) - 1):
+            w["softmax_%d/b" % i] = (np.random.RandomState(seed + i).standard_normal(w["softmax_%d/b" % i].shape) *
+                                     head_bias).astype(np.float32)
+    net = WaveNet(Params(p), seed=0, storage="bf16")
+    net.load_state_dict(w)
+    net.to_gpu()
+    return p, w, net
+
+
+def close_bf16(got, want, what, ulps=2.0, floor=1e-3):
+    got = to_np(got.float()) if isinstance(got, torch.Tensor) else got
+    tol = ulps * 2.0 ** -8 * np.abs(want) + floor * max(1.0, float(np.abs(want).max())) * 2.0 ** -8
+    bad = np.abs(got - want) > tol
+    assert not bad.any(), (what, int(bad.sum()), got.size, float(np.abs(got - want).max()), np.argwhere(bad)[:4].tolist())
+
+
+def grads_close(net, g, rel, tag="", noise=None):
+    """every gradient tensor within ``rel`` (2-norm, relative) of the oracle's -- or, when ``noise`` (a second oracle
+    run on weights perturbed by 1e-6) is given, within 1.25 x the oracle's own distance to that run + ``rel``."""
+    worst = 0.0
+    for ln, kind, off, n, shape in net._spans:
+        k = "%s/%s" % (ln.name, kind)
+        want = np.asarray(g[k], np.float64).reshape(-1)
+        got = to_np(net._grad_arena[off:off + n]).astype(np.float64)
+        nw = np.linalg.norm(want)
+        err = np.linalg.norm(got - want) / (nw + 1e-30) if nw > 0 else np.abs(got).max()
+        worst = max(worst, err)
+        bar = rel
+        if noise is not None and nw > 0:
+            bar = rel + 1.25 * np.linalg.norm(np.asarray(noise[k], np.float64).reshape(-1) - want) / nw
+        assert err <= bar, (tag, ln.name, kind, err, bar, nw)
+    return worst
+
+
+def _ws_views(net, L, B, T, Tw):
+    ws = net._last16_ws
+    al = lambda n: (n + 255) // 256 * 256
+    o = 0
+    dzs = ws[o:o + L * B * Tw * 128 * 2].view(torch.bfloat16).view(L, B, Tw, 128); o += al(L * B * Tw * 128 * 2)
+    dadg = ws[o:o + L * B * T * 256 * 2].view(torch.bfloat16).view(L, B, T, 256); o += al(L * B * T * 256 * 2)
+    dx0 = ws[o:o + B * T * 128 * 2].view(torch.bfloat16).view(B, T, 128); o += al(B * T * 128 * 2)
+    dx1 = ws[o:o + B * T * 128 * 2].view(torch.bfloat16).view(B, T, 128)
+    return dzs, dadg, (dx0, dx1)
+
+
+SMALL = dict(quantization_steps=256, causal_conv_channels=[128], residual_conv_channels=[128] * 3, residual_num_blocks=2,
+             softmax_conv_channels=[256, 256])
+
+
+@pytest.mark.parametrize("B,T,tw", [(2, 150, 90), (1, 333, 64), (3, 64, 33)])
+def test_bf16_stack_every_intermediate_against_the_rounding_oracle(B, T, tw):
+    """6 layers (d = 1, 2, 4, 1, 2, 4), ragged T: layer outputs, z, skip, logits, loss, dz_skip, [da | dg], dx of the two
+    lowest layers and every gradient."""
+    p, w, net = build16(SMALL, seed=9)
+    rs = np.random.RandomState(T)
+    idx = rs.randint(0, 256, (B, T)).astype(np.int32)
+    tgt = rs.randint(0, 256, (B, tw)).astype(np.int32)
+    c = net.forward_causal_block(dev(idx))
+    _, s = net.forward_residual_block(c, t_off=T - tw)
+    x, xs, z, skip = net._last16
+    keep = {}
+    # the head and the backward are compared on the device's own skip sum (see oracle/bf16_ref.py::train_step)
+    loss_ref, logits_ref, g = Q.train_step(p, w, idx, tgt, keep=keep, skip_override=to_np(skip.float()))
+    close_bf16(c[:, :, 0, :].permute(0, 2, 1), keep["x0"], "embedding")
+    L = len(keep["zs"])
+    # every layer on the input the device itself produced (a 1-ulp difference upstream re-rounds everything downstream, so
+    # only a teacher-forced comparison can be held to rounding-tie tolerance), then the free-running chain loosely
+    lay = list(Q._layers(p))
+    for l in range(L):
+        pre, d = lay[l]
+        xin = to_np((x if l == 0 else xs[l - 1]).float()).astype(np.float64)
+        zw, ow = Q.layer_fwd(xin, w[pre + "wf/W"], w[pre + "wg/W"], w[pre + "projection_block/W"], d, Q._Z(T, d, True))
+        close_bf16(z[l], zw, "z of layer %d" % l, floor=0.05)
+        close_bf16(xs[l], ow, "output of layer %d" % l, floor=0.1)
+        for got, want in ((z[l], keep["zs"][l]), (xs[l], keep["xs"][l])):
+            assert np.abs(to_np(got.float()) - want).max() <= 2.0 ** -6 * np.abs(want).max(), l
+    zall = np.stack([to_np(z[l].float())[:, T - tw:].astype(np.float64) for l in range(L)])
+    sw = sum(zall[l] @ Q.rb(w[lay[l][0] + "projection_softmax/W"][:, :, 0, 0]).T for l in range(L))
+    close_bf16(skip, Q.rb(sw), "skip sum", floor=0.1)
+    logits = net.forward_softmax_block(s, apply_softmax=False)
+    np.testing.assert_allclose(to_np(logits)[:, :, 0, :].transpose(0, 2, 1), logits_ref, atol=2e-2)
+    loss = net.cross_entropy(logits, tgt)
+    assert abs(float(loss.detach()) - loss_ref) < 1e-3
+    net.zero_grads()
+    loss.backward()
+    torch.cuda.synchronize()
+    dzs, dadg, dxb = _ws_views(net, L, B, T, tw)
+    # backward buffers: 2-norm comparisons (a ReLU mask that flips where the skip sum is ~0, or an upstream rounding tie,
+    # changes single elements completely; the tensors as a whole agree to bf16 accuracy)
+    def nclose(got, want, what, rel=2e-2):
+        err = np.linalg.norm(to_np(got.float()).astype(np.float64) - want) / (np.linalg.norm(want) + 1e-30)
+        assert err <= rel, (what, err)
+    for l in range(L):
+        nclose(dzs[l], keep["dzs"][l], "dz_skip of layer %d" % l)
+        nclose(dadg[l], keep["dadg"][l], "[da | dg] of layer %d" % l)
+    for l in (1, 2):                      # the ping-pong buffers still hold the dx of layers 2 and 1
+        nclose(dxb[l & 1], keep["dx"][l], "dx of layer %d" % l)
+    worst = grads_close(net, g, 1e-2)
+    assert float(net.residual_blocks[-1][-1].projection_block.W.grad.abs().sum()) == 0
+    assert worst > 1e-6                   # and it is not the fp32 path
+
+
+def test_bf16_storage_rejects_what_it_does_not_cover():
+    from wavenet_amd import WaveNetHipError
+    p = R.make_params(quantization_steps=256, causal_conv_channels=[64], residual_conv_channels=[64] * 2,
+                      residual_num_blocks=1, softmax_conv_channels=[256, 256])
+    net = WaveNet(Params(p), seed=0, storage="bf16")
+    net.to_gpu()
+    c = net.forward_causal_block(dev(np.zeros((1, 40), np.int32)))
+    with pytest.raises(WaveNetHipError):
+        net.forward_residual_block(c)
+
+
+CFG5 = dict(quantization_steps=256, causal_conv_channels=[128], residual_conv_channels=[128] * 10, residual_num_blocks=4,
+            softmax_conv_channels=[512, 256])
+
+
+def test_cfg5_full_topology_train_step_vs_the_rounding_oracle_eager_and_graph():
+    """BASELINE configs[4] as specified: 4 x 10 layers (d = 1..512), 128 / 512 channels, bf16 storage, T = input_width +
+    120, against the oracle that rounds forward and backward, launched op by op and through the replayed TrainStepGraph.
+    Forty layers of bf16 re-rounding are chaotic in the last bit: the oracle's own gradients move by ~3 % (2-norm) when its
+    weights are perturbed by 1e-6 relative.  That measured sensitivity is the bar: every gradient tensor within 1.25 x the
+    oracle's distance to its perturbed self + 2e-3 (the 6-layer test above holds a flat 1e-2; the layer kernels
+    themselves are held to rounding-tie tolerance there, input for input)."""
+    p, w, net = build16(CFG5, seed=5)
+    iw = R.input_width(p)
+    B, extra = 1, 120
+    T = iw + extra
+    rs = np.random.RandomState(3)
+    idx = rs.randint(0, 256, (B, T)).astype(np.int32)
+    tgt = rs.randint(0, 256, (B, extra)).astype(np.int32)
+    x, t = dev(idx), dev(tgt)
+    c = net.forward_causal_block(x)
+    _, s = net.forward_residual_block(c, t_off=T - extra)
+    skip = net._last16[3]
+    own = {}
+    loss_free, _, g_free = Q.train_step(p, w, idx, tgt, keep=own)
+    assert np.abs(to_np(skip.float()) - own["skip"]).max() <= 2.0 ** -5 * np.abs(own["skip"]).max()   # free-running forward
+    loss_ref, logits_ref, g = Q.train_step(p, w, idx, tgt, skip_override=to_np(skip.float()))
+    logits = net.forward_softmax_block(s, apply_softmax=False)
+    loss = net.cross_entropy(logits, t)
+    net.zero_grads()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - loss_ref) < 2e-3
+    np.testing.assert_allclose(to_np(logits)[:, :, 0, :].transpose(0, 2, 1), logits_ref, atol=5e-2)
+    w2 = {k: (v * (1 + 1e-6 * np.sign(np.random.RandomState(1).standard_normal(v.shape)))).astype(np.float32)
+          for k, v in w.items()}
+    _, _, g_noise = Q.train_step(p, w2, idx, tgt, skip_override=to_np(skip.float()))
+    worst = grads_close(net, g, 2e-3, "eager", noise=g_noise)
+    assert worst < 5e-2
+    grads_close(net, g_free, 0.25, "eager, free-running oracle")      # ReLU-mask flips on 120 columns included: sanity only
+    assert abs(loss_free - loss_ref) < 2e-2
+    net.update_laerning_rate(1e-4)
+    w0 = to_np(net._arena).copy()
+    gr = TrainStepGraph(net, x, t)
+    np.testing.assert_array_equal(to_np(net._arena), w0)
+    lg = gr.step()
+    torch.cuda.synchronize()
+    assert abs(float(lg) - loss_ref) < 2e-3
+    grads_close(net, g, 2e-3, "graph", noise=g_noise)
+    assert np.abs(to_np(net._arena) - w0).max() > 0

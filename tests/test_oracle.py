@@ -181,3 +181,31 @@ def test_train_step_alignment_and_grads_fd():
             net = R.RefWaveNet(p, wm, dtype=torch.float64)
             lm = float(net.train_loss(R.onehot_t(x, 16, torch.float64), t)[0])
             assert abs((lp - lm) / 2e-5 - g[name][i]) < 1e-7
+
+
+def test_bf16_storage_restatement_hand_backward_equals_autograd():
+    """oracle/bf16_ref.py (the checker of the bf16-storage kernels, BASELINE config 5): the numpy forward + hand-written
+    backward and the torch-autograd formulation with straight-through rounding agree; and the bf16 arithmetic stays
+    within bf16 distance of the fp32 restatement."""
+    from oracle import bf16_ref as Q
+    p = R.make_params(quantization_steps=32, causal_conv_channels=[16], residual_conv_channels=[16] * 3,
+                      residual_num_blocks=2, softmax_conv_channels=[24, 32])
+    w = R.init_weights(p, 3)
+    w["softmax_0/b"] = (np.random.RandomState(2).standard_normal(32) * 0.3).astype(np.float32)
+    rs = np.random.RandomState(4)
+    iw = R.input_width(p)
+    idx = rs.randint(0, 32, (2, iw + 21)).astype(np.int32)
+    tgt = rs.randint(0, 32, (2, 21)).astype(np.int32)
+    keep = {}
+    l1, lg1, g1 = Q.train_step(p, w, idx, tgt, keep=keep)
+    l2, lg2, g2 = Q.train_step_autograd(p, w, idx, tgt)
+    l0, lg0, g0 = R.train_step_grads(p, w, idx, tgt)
+    assert abs(l1 - l2) < 1e-6 and abs(l1 - l0) < 2e-2
+    np.testing.assert_allclose(lg1, lg2, atol=1e-5)
+    for k in g1:
+        n = np.linalg.norm(g2[k]) + 1e-12
+        assert np.linalg.norm(g1[k] - g2[k]) <= 3e-3 * n, (k, np.linalg.norm(g1[k] - g2[k]) / n)
+        assert np.linalg.norm(g1[k] - g0[k]) <= 0.1 * (np.linalg.norm(g0[k]) + 1e-12), k
+    # stored tensors hold bf16 values
+    for t in [keep["x0"], keep["skip"], keep["dskip"]] + keep["zs"] + keep["xs"] + keep["dadg"] + keep["dx"] + keep["dzs"]:
+        np.testing.assert_array_equal(Q.rb(t), t)

@@ -82,6 +82,18 @@ _SIGS = {
     "wn_scale_by_dev": (_i, [_p, _p, _i64, _p]),
     "wn_set_gemm_precision": (_i, [_i]),
     "wn_get_gemm_precision": (_i, []),
+    "wn16_supported": (_i, [C.POINTER(WnStackDesc)]),
+    "wn16_pack_elems": (C.c_size_t, [C.POINTER(WnStackDesc)]),
+    "wn16_pack_stack": (_i, [C.POINTER(WnStackDesc), _p, _p]),
+    "wn16_embed_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "wn16_cvt_to_bf16": (_i, [_p, _p, _i64, _p]),
+    "wn16_cvt_to_f32": (_i, [_p, _p, _i64, _p]),
+    "wn16_stack_fwd": (_i, [C.POINTER(WnStackDesc), _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "wn16_stack_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(WnStackDesc), _i, _i, _i]),
+    "wn16_stack_bwd": (_i, [C.POINTER(WnStackDesc)] + [_p] * 7 + [_pp] * 4 + [_p, C.c_size_t, _i, _i, _i, _i, _p]),
+    "wn16_pack_pointwise": (_i, [_p, _p, _p, _i, _i, _p]),
+    "wn16_pointwise_fwd": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _i, _p]),
+    "wn16_pointwise_bwd": (_i, [_p] * 8 + [_i64, _i, _i, _i, _p]),
     "wn_prof_enable": (_i, [_i]),
     "wn_prof_report": (_i, [C.c_char_p, _i]),
 }

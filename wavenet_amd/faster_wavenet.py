@@ -37,13 +37,13 @@ class _RingState(object):
 class FasterWaveNet(WaveNet):
     fast_head_activation = "elu"       # faster_wavenet.py:108 (the normal head is ReLU, wavenet.py:588)
 
-    def __init__(self, params, compat_zero_prefix: bool = True, seed: Optional[int] = None):
+    def __init__(self, params, compat_zero_prefix: bool = True, seed: Optional[int] = None, storage: str = "fp32"):
         self._dec = None
         self._dec_keep = None
         self._dec_stale = True
         self.prev_causal_outputs = None
         self.prev_residual_outputs = None
-        super().__init__(params, compat_zero_prefix=compat_zero_prefix, seed=seed)
+        super().__init__(params, compat_zero_prefix=compat_zero_prefix, seed=seed, storage=storage)
 
     def __del__(self):
         try:
@@ -53,6 +53,7 @@ class FasterWaveNet(WaveNet):
             pass
 
     def _weights_changed(self):
+        super()._weights_changed()
         self._dec_stale = True
 
     # -- decoder handle -------------------------------------------------------------------------
@@ -100,6 +101,13 @@ class FasterWaveNet(WaveNet):
         _need_gpu(x)
         if x.shape[0] != 1:
             raise Exception("FasterWaveNet generates one utterance at a time (batch 1), like the reference")
+        storage, self.storage = self.storage, "fp32"               # the decoder state is seeded from fp32 activations
+        try:
+            return self._prefill(x, apply_softmax, as_numpy)
+        finally:
+            self.storage = storage
+
+    def _prefill(self, x, apply_softmax, as_numpy):
         with torch.no_grad():
             causal_output = self.forward_causal_block(x)
             _, sum_skip = self.forward_residual_block(causal_output)

@@ -294,6 +294,120 @@ class _StackFn(_Fn):
 
 
 # ----------------------------------------------------------------------------------------------
+# bf16-storage nodes (BASELINE config 5; include/wavenet_hip.h "bf16-storage path"): activations are torch.bfloat16
+# (B, T, C) tensors, weights and their gradients stay fp32 in the flat arenas
+# ----------------------------------------------------------------------------------------------
+class _Embed16Fn(_Fn):
+    @staticmethod
+    def forward(ctx, idx, W, b, fw, hook):
+        B, T = idx.shape
+        Cc, Q = W.shape[0], W.shape[1]
+        out = torch.empty((B, T, Cc), device=idx.device, dtype=torch.bfloat16)
+        check(_lib.lib().wn16_embed_fwd(ptr(idx), ptr(W), ptr(b), ptr(out), B, T, Q, Cc, fw, stream_ptr()),
+              "wn16_embed_fwd")
+        ctx.save_for_backward(idx)
+        ctx.W, ctx.b, ctx.fw = W, b, fw
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        W, b = ctx.W, ctx.b
+        B, T = idx.shape
+        dout = dout.contiguous()
+        d32 = torch.empty(dout.shape, device=dout.device, dtype=torch.float32)
+        lib = _lib.lib()
+        check(lib.wn16_cvt_to_f32(ptr(dout), ptr(d32), dout.numel(), stream_ptr()), "wn16_cvt_to_f32")
+        check(lib.wn_embed_bwd(ptr(idx), ptr(d32), ptr(W.grad), ptr(None if b is None else b.grad), B, T,
+                               W.shape[1], W.shape[0], ctx.fw, stream_ptr()), "wn_embed_bwd")
+        return None, None, None, None, None
+
+
+class _Stack16Fn(_Fn):
+    """forward_residual_block in bf16 storage: one library call each way (wn16_stack_fwd / wn16_stack_bwd).  The forward
+    keeps every layer's output and z only; the backward recomputes tanh / sigmoid."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, net, t_off, train):
+        ctx.set_materialize_grads(False)
+        B, T, Cr = x.shape
+        x = x.contiguous()
+        desc = net._stack_desc()
+        L = len(net._flat_layers)
+        dev_ = x.device
+        xs = torch.empty((L, B, T, Cr), device=dev_, dtype=torch.bfloat16)
+        z = torch.empty((L, B, T, Cr), device=dev_, dtype=torch.bfloat16)
+        skip = torch.empty((B, T - t_off, net._Cs), device=dev_, dtype=torch.bfloat16)
+        check(_lib.lib().wn16_stack_fwd(desc, ptr(net._pack16), ptr(x), ptr(xs), ptr(z), ptr(skip), B, T, t_off,
+                                        1 if net.compat_zero_prefix else 0, stream_ptr()), "wn16_stack_fwd")
+        ctx.net, ctx.t_off, ctx.shape = net, t_off, (B, T, Cr)
+        ctx.saved = (x, xs, z) if train else None
+        net._last16 = (x, xs, z, skip)                               # (tests look at the intermediates)
+        return xs[L - 1], skip
+
+    @staticmethod
+    def backward(ctx, dout, dskip):
+        net, t_off = ctx.net, ctx.t_off
+        B, T, Cr = ctx.shape
+        if ctx.saved is None:
+            raise _lib.WaveNetHipError("backward through a forward that ran without grad enabled")
+        x, xs, z = ctx.saved
+        lib = _lib.lib()
+        desc = net._stack_desc()
+        gt = net._grad_tables()
+        nbytes = lib.wn16_stack_bwd_workspace_bytes(desc, B, T, t_off)
+        ws = torch.empty((nbytes,), device=x.device, dtype=torch.uint8)
+        dout = None if dout is None else dout.contiguous()
+        dskip = None if dskip is None else dskip.contiguous()
+        dx = torch.empty((B, T, Cr), device=x.device, dtype=torch.bfloat16) if ctx.needs_input_grad[0] else None
+        check(lib.wn16_stack_bwd(desc, ptr(net._pack16), ptr(x), ptr(xs), ptr(z), ptr(dout), ptr(dskip), ptr(dx),
+                                 gt["wf"], gt["wg"], gt["wp"], gt["ws"], ptr(ws), nbytes, B, T, t_off,
+                                 1 if net.compat_zero_prefix else 0, stream_ptr()), "wn16_stack_bwd")
+        net._last16_ws = ws
+        ctx.saved = None
+        return dx, None, None, None, None
+
+
+class _Pointwise16Fn(_Fn):
+    """out = W relu(x) + b on bf16 activations; the last head layer writes fp32 logits."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, Wb, WbT, act, out_f32, hook):
+        lead = x.shape[:-1]
+        Cin, Cout = x.shape[-1], W.shape[0]
+        x2 = x.reshape(-1, Cin).contiguous()
+        out = torch.empty((x2.shape[0], Cout), device=x.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        check(_lib.lib().wn16_pointwise_fwd(ptr(x2), ptr(Wb), ptr(b), ptr(out), 1 if out_f32 else 0, x2.shape[0], Cin, Cout,
+                                            act, stream_ptr()), "wn16_pointwise_fwd")
+        ctx.save_for_backward(x2)
+        ctx.W, ctx.b, ctx.WbT, ctx.act, ctx.lead = W, b, WbT, act, lead
+        return out.view(*lead, Cout)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x2,) = ctx.saved_tensors
+        W, b = ctx.W, ctx.b
+        Cout, Cin = W.shape[0], x2.shape[1]
+        N = x2.shape[0]
+        lib = _lib.lib()
+        d2 = dout.reshape(-1, Cout).contiguous()
+        d16 = d32 = scratch = None
+        if d2.dtype == torch.float32:
+            d32 = d2
+            scratch = torch.empty((N, Cout), device=d2.device, dtype=torch.bfloat16)
+        else:
+            d16 = d2
+            if b is not None:                                        # the bias gradient is summed in fp32
+                d32 = torch.empty((N, Cout), device=d2.device, dtype=torch.float32)
+                check(lib.wn16_cvt_to_f32(ptr(d16), ptr(d32), d16.numel(), stream_ptr()), "wn16_cvt_to_f32")
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        check(lib.wn16_pointwise_bwd(ptr(x2), ptr(ctx.WbT), ptr(d16), ptr(d32), ptr(scratch), ptr(dx), ptr(W.grad),
+                                     ptr(None if b is None else b.grad), N, Cin, Cout, ctx.act, stream_ptr()),
+              "wn16_pointwise_bwd")
+        return (None if dx is None else dx.view(*ctx.lead, Cin)), None, None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------------------------
 # links: objects with the attribute names the reference's scripts touch
 # ----------------------------------------------------------------------------------------------
 class _Link(object):
@@ -414,9 +528,16 @@ class WaveNet(object):
 
     head_activation = "relu"          # wavenet.py:588
 
-    def __init__(self, params, compat_zero_prefix: bool = True, seed: Optional[int] = None):
+    def __init__(self, params, compat_zero_prefix: bool = True, seed: Optional[int] = None, storage: str = "fp32"):
+        """``storage="bf16"`` (BASELINE config 5; not in the reference): activations in bfloat16, fp32 accumulation, fp32
+        master weights; for 128 residual / dilation channels, filter width 2, a multiple of 256 skip channels."""
         params.check()
+        if storage not in ("fp32", "bf16"):
+            raise Exception("storage must be 'fp32' or 'bf16'")
         self.params = params
+        self.storage = storage
+        self._pack16 = None
+        self._w16_stale = True
         self.compat_zero_prefix = compat_zero_prefix
         self._gpu = False
         self._hook = None
@@ -535,7 +656,27 @@ class WaveNet(object):
         self._weights_changed()
 
     def _weights_changed(self):
-        pass
+        self._w16_stale = True
+
+    def _pack16_if_stale(self):
+        """bf16 operand images of the current weights (one pack per optimiser step; captured with the step in a graph)."""
+        if not self._w16_stale:
+            return
+        lib = _lib.lib()
+        desc = self._stack_desc()
+        if self._pack16 is None or self._pack16.device != self._arena.device:
+            if not lib.wn16_supported(desc):
+                lib.wn16_pack_stack(desc, None, None)                  # sets the error text
+                raise _lib.WaveNetHipError("storage='bf16': %s" % lib.wn_last_error().decode())
+            self._pack16 = torch.empty((lib.wn16_pack_elems(desc),), device=self._arena.device, dtype=torch.bfloat16)
+            self._head16 = [(torch.empty(l.W.shape[:2], device=self._arena.device, dtype=torch.bfloat16),
+                             torch.empty((l.W.shape[1], l.W.shape[0]), device=self._arena.device, dtype=torch.bfloat16))
+                            for l in self.softmax_conv_layers]
+        check(lib.wn16_pack_stack(desc, ptr(self._pack16), stream_ptr()), "wn16_pack_stack")
+        for l, (wb, wbt) in zip(self.softmax_conv_layers, self._head16):
+            check(lib.wn16_pack_pointwise(ptr(l.W), ptr(wb), ptr(wbt), l.W.shape[0], l.W.shape[1], stream_ptr()),
+                  "wn16_pack_pointwise")
+        self._w16_stale = False
 
     def _stack_desc(self):
         """WnStackDesc over the current arena (rebuilt when the arena moves, e.g. to_gpu)."""
@@ -688,6 +829,13 @@ class WaveNet(object):
         x = self.to_variable(x_batch)
         _need_gpu(x)
         layers = self.causal_conv_layers
+        if self.storage == "bf16":
+            if x.is_floating_point() or x.dim() != 2 or len(layers) != 1:
+                raise Exception("storage='bf16' takes integer (B, T) tokens and one causal layer")
+            l0 = layers[0]
+            out = _Embed16Fn.apply(x.to(torch.int32).contiguous(), l0.W, l0.b, l0.filter_width, self._hook)
+            self._last_causal_outputs = [out]
+            return _as_view(out)
         if not x.is_floating_point():
             if x.dim() != 2:
                 raise Exception("integer input must be (B, T) tokens")
@@ -712,6 +860,10 @@ class WaveNet(object):
         receptive field and must not be used; loss and gradients are unchanged."""
         x = self.to_variable(x_batch)
         _need_gpu(x)
+        if self.storage == "bf16":
+            self._pack16_if_stale()
+            out, skip = _Stack16Fn.apply(_to_btc(x), self._anchor, self, int(t_off), torch.is_grad_enabled())
+            return _as_view(out), _as_view(skip)
         out, skip = _StackFn.apply(_to_btc(x), self._anchor, self, int(t_off), torch.is_grad_enabled(),
                                    bool(window_only))
         return _as_view(out), _as_view(skip)
@@ -721,6 +873,14 @@ class WaveNet(object):
         _need_gpu(x)
         act = ACT[activation or self.head_activation]
         out = _to_btc(x)
+        if self.storage == "bf16":
+            self._pack16_if_stale()
+            n = len(self.softmax_conv_layers)
+            for i, (lay, (wb, wbt)) in enumerate(zip(self.softmax_conv_layers, self._head16)):
+                out = _Pointwise16Fn.apply(out, lay.W, lay.b, wb, wbt, act, i == n - 1, self._hook)
+            if apply_softmax:
+                out = _SoftmaxFn.apply(out)
+            return _as_view(out)
         for lay in self.softmax_conv_layers:
             out = _PointwiseFn.apply(out, lay.W, lay.b, act, self._hook)
         if apply_softmax:
