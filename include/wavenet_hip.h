@@ -289,7 +289,8 @@ int wn16_cvt_to_f32(const uint16_t* src, float* dst, int64_t n, void* stream);
 int wn16_stack_fwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x, uint16_t* xs, uint16_t* z,
                    uint16_t* skip, int B, int T, int t_off, int compat_zero_prefix, void* stream);
 size_t wn16_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T, int t_off);
-/* A15: dout (B,T,128) or NULL, dskip (B,T-t_off,Cs) or NULL, dx (B,T,128) or NULL; fp32 gradients accumulated */
+/* A15: dout must be NULL (train_audio/train.py:72 discards the stack's residual output), dskip (B,T-t_off,Cs),
+ * dx (B,T,128) or NULL; fp32 gradients accumulated */
 int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x, const uint16_t* xs, const uint16_t* z,
                    const uint16_t* dout, const uint16_t* dskip, uint16_t* dx, float* const* dWf, float* const* dWg,
                    float* const* dWp, float* const* dWs, void* ws, size_t ws_bytes, int B, int T, int t_off,

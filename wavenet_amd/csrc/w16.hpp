@@ -117,10 +117,14 @@ __device__ __forceinline__ void tile_range(int ntiles, int& first, int& stride, 
 }
 
 // ---- sizes of the per-layer weight images (bf16 elements), see k16_pack_layers -------------------------------------
-static constexpr int kConvA = 8 * 16 * 64 * 8;     // fused conv: 8 waves x 16 k-steps x 64 lanes x 8
-static constexpr int kProjA = 4 * 8 * 64 * 8;      // residual projection: 4 m-tiles x 8 k-steps
-static constexpr int kDzA = 8 * 8 * 64 * 8;        // Wp^T for dz: 8 waves x 8 k-steps (rows 16..31 of each tile are 0)
-static constexpr int kDxW = 128 * 512;             // [Wf1;Wg1 | Wf0;Wg0]^T, row-major [cr][512]
-static constexpr int kLayerImg = kConvA + kProjA + kDzA + kDxW;
+static constexpr int kConvA = 4 * 2 * 16 * 64 * 8;  // forward conv: 4 waves x (filter, gate) x 16 k-steps x 64 lanes x 8
+static constexpr int kProjA = 4 * 8 * 64 * 8;       // residual projection: 4 m-tiles x 8 k-steps
+static constexpr int kConvA8 = 8 * 16 * 64 * 8;     // gate backward conv: 8 waves x 16 k-steps, tile rows [16 filter; 16 gate]
+static constexpr int kDzA8 = 8 * 8 * 64 * 8;        // Wp^T for dz: 8 waves x 8 k-steps (rows 16..31 of each tile are 0)
+static constexpr int kDxA = 4 * 2 * 16 * 64 * 8;    // [Wf1;Wg1 | Wf0;Wg0]^T: 4 m-tiles x 2 contraction halves x 16 k-steps
+static constexpr int kOffConvA8 = kConvA + kProjA;
+static constexpr int kOffDzA8 = kOffConvA8 + kConvA8;
+static constexpr int kOffDxA = kOffDzA8 + kDzA8;
+static constexpr int kLayerImg = kOffDxA + kDxA;
 
 }  // namespace w16

@@ -48,7 +48,7 @@ BwdWs carve(const WnStackDesc* d, int B, int T, int t_off, char* ws) {
     r.dadg = reinterpret_cast<bf16*>(take(L * n * 256 * 2));
     r.dxb[0] = reinterpret_cast<bf16*>(take(n * 128 * 2));
     r.dxb[1] = reinterpret_cast<bf16*>(take(n * 128 * 2));
-    r.parts = reinterpret_cast<float*>(take(L * (size_t)gate_bwd_grid(B, T) * 128 * 128 * 4));
+    r.parts = reinterpret_cast<float*>(take(L * (size_t)dx_grid(B, T) * 128 * 128 * 4));
     r.bytes = o;
     return r;
 }
@@ -141,7 +141,7 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
                    int compat_zero_prefix, void* stream) {
     W16_CHECK_DESC(d);
     WN_CHECK_ARG(pack && x && xs && z && dWf && dWg && dWp && ws && B > 0 && T > 0, "wn16_stack_bwd: bad argument");
-    WN_CHECK_ARG(dout || dskip, "wn16_stack_bwd: no incoming gradient");
+    WN_CHECK_ARG(dskip, "wn16_stack_bwd: dskip is NULL (the loss reaches the stack through the skip sum)");
     WN_CHECK_ARG(t_off >= 0 && t_off < T, "wn16_stack_bwd: t_off outside [0,T)");
     WN_CHECK_ARG(ws_bytes >= wn16_stack_bwd_workspace_bytes(d, B, T, t_off), "wn16_stack_bwd: workspace too small");
     hipStream_t s = wn::as_stream(stream);
@@ -183,10 +183,16 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
             if (np && (rc = launch_wgrad16(a, np, s))) return rc;
         }
     }
-    const int nwg = gate_bwd_grid(B, T);
+    const int nwg = dx_grid(B, T);
     const long long part_stride = (long long)nwg * 128 * 128;
     const bf16* gout = reinterpret_cast<const bf16*>(dout);
     std::vector<float*> dWp_eff(L, nullptr);
+    if (gout) {
+        // off the training path (train_audio/train.py:72 discards the stack's residual output): the top layer's dWp would
+        // need its own contraction, every other dWp comes out of the dx kernel of the layer above
+        wn::set_error("wn16_stack_bwd: a gradient through the stack's residual output is not supported in bf16 storage");
+        return WN_ESHAPE;
+    }
     {
         wn::ProfScope prof__("wn16_layer_bwd", stream);
         for (int l = L - 1; l >= 0; --l) {
@@ -195,19 +201,17 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
             const int Z = compat_zero_prefix ? zero_prefix(T, dl, 2) : 0;
             bf16* dadg = w.dadg + (size_t)l * n * 256;
             if ((rc = gate_bwd_layer(in, img + (size_t)l * kLayerImg, gout, dsk ? w.dzs + (size_t)l * nw * 128 : nullptr,
-                                     t_off, dadg, w.parts + (size_t)l * part_stride, B, T, dl, Z, s)))
+                                     t_off, dadg, B, T, dl, Z, s)))
                 return rc;
-            if (gout) dWp_eff[l] = dWp[l];
             bf16* gin = l == 0 ? reinterpret_cast<bf16*>(dx) : w.dxb[l & 1];
             if (!gin) break;                               // l == 0 and the caller does not want dx
-            // dx[t] = dout[t] + [Wf1;Wg1]^T dab[t] + [Wf0;Wg0]^T dab[t + d]
-            CG16 a{};
-            a.X[0] = dadg; a.shift[0] = 0; a.X[1] = dadg; a.shift[1] = dl;
-            a.nsrc = 2; a.ksrc = 256; a.ldx = 256; a.x_rows_per_b = T; a.x_row0 = 0;
-            a.W = img + (size_t)l * kLayerImg + kConvA + kProjA + kDzA; a.M = 128; a.K = 512;
-            a.B = B; a.rows_per_b = T; a.out = gin; a.out_f32 = 0; a.ldo = 128; a.ob_stride = 0; a.ob_col = 128;
-            if (gout) { a.ep = 1; a.extra = gout; a.lde = 128; }
-            if ((rc = launch_cgemm(a, s))) return rc;
+            // dx_l[t] = dout[t] + [Wf1;Wg1]^T dab[t] + [Wf0;Wg0]^T dab[t + d]; it is the dout of layer l - 1, whose
+            // projection gradient dWp_{l-1} += dx_l z_{l-1}^T is taken in the same pass
+            const bf16* zprev = l > 0 ? zb + (size_t)(l - 1) * n * 128 : nullptr;
+            if ((rc = dx_layer(dadg, img + (size_t)l * kLayerImg, gout, zprev, gin,
+                               l > 0 ? w.parts + (size_t)(l - 1) * part_stride : nullptr, B, T, dl, s)))
+                return rc;
+            if (l > 0) dWp_eff[l - 1] = dWp[l - 1];
             gout = gin;
         }
     }

@@ -21,7 +21,7 @@ static constexpr int kCTileB = 128 * 256;               // 32 KB: 128 rows
 static constexpr int kCgLds = 4 * kCTileB;              // X[2], W[2]
 
 template <bool RELU_X, int EP, bool OUT_F32>             // EP: 0 none, 1 + residual, 2 x (mask > 0)
-__global__ __launch_bounds__(512, 2) void k16_cgemm(CG16 a) {
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k16_cgemm(CG16 a) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     auto xt = [&](int buf) { return lds + buf * kCTileB; };
     auto wt = [&](int buf) { return lds + (2 + buf) * kCTileB; };
@@ -86,15 +86,23 @@ __global__ __launch_bounds__(512, 2) void k16_cgemm(CG16 a) {
                 barrier();
             }
         }
+        // all 24 operand fragments of the stage are requested before the first MFMA (left to itself the compiler paired
+        // every MFMA with its own ds_read + s_waitcnt lgkmcnt(0): one exposed LDS latency per matrix instruction)
         const int row = 32 * wn + j;
+        bf16x8 bv[8], av[2][8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            bf16x8 bv = frag_row(xt(buf), row, s, h);
-            if (RELU_X) bv = relu8(bv);
+            bv[s] = frag_row(xt(buf), row, s, h);
+            av[0][s] = frag_row(wt(buf), 64 * wm + j, s, h);
+            av[1][s] = frag_row(wt(buf), 64 * wm + 32 + j, s, h);
+        }
+        __builtin_amdgcn_sched_barrier(0);               // keep the reads above, the MFMAs below
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            if (RELU_X) bv[s] = relu8(bv[s]);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row(wt(buf), 64 * wm + 32 * mt + j, s, h), bv,
-                                                                  acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt][s], bv[s], acc[mt], 0, 0, 0);
         }
     }
     // ---- epilogue ----
@@ -191,7 +199,7 @@ static constexpr int kWTileB = kWT * 256;                // 16 KB
 static constexpr int kWgLds = 8 * kWTileB;               // (A0, A1, B0, B1) x 2 buffers
 
 template <bool RELU_B>
-__global__ __launch_bounds__(512, 2) void k16_wgrad(WG16 a) {
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k16_wgrad(WG16 a) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -340,11 +348,11 @@ __global__ void k16_pack_layers(PackLayersArgs a, bf16* __restrict__ img) {
     const float* Wp = a.Wp[l];
     float v[8];
     int e = g * 8;
-    if (e < kConvA) {                                    // [w][s][lane][8]: row r of wave w, k = 16 s + 8 h + jj
-        const int lane = (e >> 3) & 63, s = (e >> 9) & 15, w = e >> 13;
+    if (e < kConvA) {                                    // [w][gate][s][lane][8]: channel 32 w + r, k = 16 s + 8 h + jj
+        const int lane = (e >> 3) & 63, s = (e >> 9) & 15, gate = (e >> 13) & 1, w = e >> 14;
         const int r = lane & 31, h = lane >> 5;
-        const float* W = (r >> 4) ? Wg : Wf;
-        const int ch = 16 * w + (r & 15);
+        const float* W = gate ? Wg : Wf;
+        const int ch = 32 * w + r;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
             const int k = 16 * s + 8 * h + jj;
@@ -356,20 +364,33 @@ __global__ void k16_pack_layers(PackLayersArgs a, bf16* __restrict__ img) {
         const int r = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) v[jj] = Wp[(32 * mt + r) * 128 + 16 * s + 8 * h + jj];
-    } else if (e < kConvA + kProjA + kDzA) {             // [w][s][lane][8]: Wp[k = cr][cd = 16 w + r], rows 16.. zero
-        e -= kConvA + kProjA;
+    } else if (e < kOffDzA8) {                           // [w][s][lane][8]: row r of wave w (16 filter, 16 gate rows)
+        e -= kOffConvA8;
+        const int lane = (e >> 3) & 63, s = (e >> 9) & 15, w = e >> 13;
+        const int r = lane & 31, h = lane >> 5;
+        const float* W = (r >> 4) ? Wg : Wf;
+        const int ch = 16 * w + (r & 15);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int k = 16 * s + 8 * h + jj;
+            v[jj] = W[(ch * 128 + (k & 127)) * 2 + (k >> 7)];
+        }
+    } else if (e < kOffDxA) {                            // [w][s][lane][8]: Wp[k = cr][cd = 16 w + r], rows 16.. zero
+        e -= kOffDzA8;
         const int lane = (e >> 3) & 63, s = (e >> 9) & 7, w = e >> 12;
         const int r = lane & 31, h = lane >> 5;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) v[jj] = r < 16 ? Wp[(16 * s + 8 * h + jj) * 128 + 16 * w + r] : 0.f;
-    } else {                                             // dx weights, row-major [cr][512]: k = 256 src + kk
-        e -= kConvA + kProjA + kDzA;
-        const int cr = e >> 9, k = e & 511;
+    } else {                                             // [mt][kh][s][lane][8]: rows cr = 32 mt + r, k = 256 kh + 16 s + ..
+        e -= kOffDxA;
+        const int lane = (e >> 3) & 63, s = (e >> 9) & 15, kh = (e >> 13) & 1, mt = e >> 14;
+        const int r = lane & 31, h = lane >> 5;
+        const int cr = 32 * mt + r;
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
-            const int kk = (k + jj) & 255, src = (k + jj) >> 8;
+            const int kk = 16 * s + 8 * h + jj;          // 0..127: da channels (Wf), 128..255: dg channels (Wg)
             const float* W = kk < 128 ? Wf : Wg;
-            v[jj] = W[((kk & 127) * 128 + cr) * 2 + (src == 0 ? 1 : 0)];
+            v[jj] = W[((kk & 127) * 128 + cr) * 2 + (kh == 0 ? 1 : 0)];     // half 0 = dab[t] (tap 1), half 1 = dab[t + d] (tap 0)
         }
     }
     bf16x8 o;

@@ -52,9 +52,11 @@ int embed_fwd16(const int32_t* idx, const float* W, const float* bias, bf16* out
 
 // w16_layer.hip
 int fwd_layer(const bf16* x, const bf16* img, bf16* out, bf16* z, int B, int T, int d, int Z, hipStream_t s);
-int gate_bwd_grid(int B, int T);
-int gate_bwd_layer(const bf16* x, const bf16* img, const bf16* dout, const bf16* dzs, int dz_t0, bf16* dadg,
-                   float* dwp_part, int B, int T, int d, int Z, hipStream_t s);
+int gate_bwd_layer(const bf16* x, const bf16* img, const bf16* dout, const bf16* dzs, int dz_t0, bf16* dadg, int B, int T,
+                   int d, int Z, hipStream_t s);
+int dx_grid(int B, int T);
+int dx_layer(const bf16* dadg, const bf16* img, const bf16* dout, const bf16* zprev, bf16* dx, float* dwp_part, int B,
+             int T, int d, hipStream_t s);
 int reduce_parts(const float* part, long long layer_stride, int nwg, int n, float* const* dW_dev, int L, hipStream_t s);
 
 }  // namespace w16
