@@ -55,45 +55,49 @@ def train_step(net, x, tgt, iw):
     return loss
 
 
-def wide_channel_step(rank, world, steps=5, warmup=2):
+def wide_channel_step(rank, world, steps=10, warmup=3):
     """BASELINE config 5 as a side measurement (never the headline value): config 2's topology and batch at 128 residual /
-    dilation channels and 512 skip channels, channel GEMMs on bf16 operands with fp32 accumulation
-    (wn_set_gemm_precision(WN_GEMM_BF16); storage is fp32).  Reports the matrix-core rate against the dense bf16 peak."""
-    import wavenet_amd
+    dilation channels and 512 skip channels in bf16 STORAGE (wavenet_amd.WaveNet(storage="bf16"): bf16 activations in HBM,
+    fp32 accumulation on the bf16 matrix cores, fp32 master weights), timed as graph replays like the headline.  Reports the
+    matrix-core rate against the dense bf16 peak and the per-entry-point times of an op-by-op pass."""
     cfg = dict(CFG2)
     cfg.update(causal_conv_channels=[128], residual_conv_channels=[128] * 10, softmax_conv_channels=[512, 256])
-    before = wavenet_amd.get_gemm_precision()
-    wavenet_amd.set_gemm_precision("bf16")
-    try:
-        net = FasterWaveNet(Params(cfg), seed=1)
-        net.to_gpu()
-        net.update_laerning_rate(1e-3)
-        iw = net.input_width
-        x, tgt = make_batch(rank, world, iw)
-        for _ in range(warmup):
+    net = FasterWaveNet(Params(cfg), seed=1, storage="bf16")
+    net.to_gpu()
+    net.update_laerning_rate(1e-3)
+    iw = net.input_width
+    x, tgt = make_batch(rank, world, iw)
+    graph = TrainStepGraph(net, x, tgt)
+    for _ in range(warmup):
+        graph.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = graph.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    with _lib.profile() as prof:
+        for _ in range(3):
             train_step(net, x, tgt, iw)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = train_step(net, x, tgt, iw)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        nl, n = 40, B_PER_GPU * T
-        # SURVEY 8d: 2 (2 fw Cr Cd + Cd Cr + Cd Cs) flop per sample-layer forward, backward = 2x forward
-        flop = 3 * 2 * (2 * 2 * 128 * 128 + 128 * 128 + 128 * 512) * nl * n
-        res = {"workload": "cfg5: 4x10 layers, 128 residual/dilation + 512 skip channels, batch %d x %d, train fwd+bwd+Adam, "
-                           "op-by-op launches" % (B_PER_GPU, T),
-               "dtype": "bf16 GEMM operands, f32 accumulate, f32 storage", "ms_per_step": dt * 1e3,
-               "samples_per_s": n / dt, "loss": float(loss.detach()),
-               "mfma": {"flop_per_step": flop, "achieved": flop / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
-                        "frac": flop / dt / 1e12 / 2500.0,
-                        "note": "memory bound as built: the layer is composed of channel-GEMM launches with fp32 "
-                                "activations in HBM between them"}}
-        del net
-        torch.cuda.empty_cache()
-        return res
-    finally:
-        wavenet_amd.set_gemm_precision(before)
+    per = {k: round(v[1] / 3, 4) for k, v in sorted(prof.result().items(), key=lambda kv: -kv[1][1])}
+    nl, n = 40, B_PER_GPU * T
+    # SURVEY 8d: 2 (2 fw Cr Cd + Cd Cr + Cd Cs) flop per sample-layer forward, backward = 2x forward
+    flop = 3 * 2 * (2 * 2 * 128 * 128 + 128 * 128 + 128 * 512) * nl * n
+    # algorithmic HBM bytes per sample-layer of this design (DESIGN.md section 5): forward 768 (x in, out + z out),
+    # gate backward 1,280, dx 1,280, conv weight gradients 768, skip path 3 x 256 + dskip share
+    res = {"workload": "cfg5: 4x10 layers, 128 residual/dilation + 512 skip channels, batch %d x %d, train fwd+bwd+clip+Adam"
+                       % (B_PER_GPU, T),
+           "dtype": "bf16 storage and MFMA operands, f32 accumulate, f32 master weights", "launch": "hipGraph replay",
+           "ms_per_step": dt * 1e3, "samples_per_s": n / dt, "loss": float(loss.detach()),
+           "entry_point_ms_per_step": per,
+           "mfma": {"flop_per_step": flop, "achieved": flop / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                    "frac": flop / dt / 1e12 / 2500.0,
+                    "note": "algorithmic flops / step time / dense bf16 peak; the rocprofv3 MFMA-busy counters of the same "
+                            "step are in profiles/ (r2_cfg5_mfma_busy.json)"}}
+    del graph, net
+    torch.cuda.empty_cache()
+    return res
 
 
 def stack_forward(net, c):

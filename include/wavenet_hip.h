@@ -13,7 +13,9 @@
  *   - every tensor pointer is a DEVICE pointer owned by the caller; nothing is retained after the
  *     call returns except by decoder handles, which copy what they need at create / load time.
  *   - no allocation, no synchronisation: work is enqueued on `stream` (a hipStream_t; NULL = the
- *     default stream) and the call returns immediately.
+ *     default stream) and the call returns immediately.  Scratch memory (operand images of the split-product GEMMs,
+ *     per-workgroup partial tiles, embedding-gradient tables) comes from the caller through WnExec.
+ *   - no mutable process state: the arithmetic of the channel GEMMs is an argument of every call that has one (WnExec).
  *   - activations are float32, time-major / channel-minor:  x[b][t][c]  == the reference's
  *     (B, C, 1, T) tensor in channels-last memory format.
  *   - convolution weights keep the reference's element order: a (Cout, Cin, 1, fw) or
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 1
+#define WN_ABI_VERSION 2
 #define WN_OK      0
 #define WN_EARG   -1
 #define WN_ESHAPE -2
@@ -47,6 +49,23 @@ extern "C" {
 
 int wn_abi_version(void);
 const char* wn_last_error(void);
+
+/* Per-call execution options of the entry points that contain a channel GEMM (the skip sum, the head convolutions, the
+ * layers of widths other than 32/32/2, their backward) or need scratch memory.  The reference computes these contractions
+ * in fp32 (cuDNN / cuBLAS under Chainer); here
+ *   WN_GEMM_FP32    fp32-input MFMA                                        (exact fp32 products)
+ *   WN_GEMM_BF16X3  every operand split into three bf16 parts, six products (fp32-accurate; what NULL selects)
+ *   WN_GEMM_BF16    operands rounded to bf16 once, fp32 accumulation
+ * Storage stays fp32 in all three; the fused 32-channel layer kernels always multiply in fp32.
+ * ws / ws_bytes: device scratch, at least wn_exec_workspace_bytes() for the model and batch; its contents are dead when the
+ * call's kernels have run, so ONE buffer per stream serves every call on that stream (never one buffer for two streams).
+ * ex == NULL means { WN_GEMM_BF16X3, NULL, 0 }: fine for calls that need no scratch, WN_EARG (with the byte count) otherwise. */
+enum { WN_GEMM_FP32 = 0, WN_GEMM_BF16X3 = 1, WN_GEMM_BF16 = 2 };
+typedef struct WnExec {
+    int precision;
+    void* ws;
+    size_t ws_bytes;
+} WnExec;
 /* 1 if the fp32-MFMA fast path covers this residual-layer shape, 0 if the generic path runs */
 int wn_layer_fast_path(int Cr, int Cd, int fw);
 
@@ -57,7 +76,7 @@ int wn_embed_fwd(const int32_t* idx, const float* W, const float* bias, float* o
                  int B, int T, int Q, int C, int fw, void* stream);
 /* dW[o][q][k] += sum over (b,t) with idx[b,t-(fw-1-k)] == q of dout[b,t,o]; dbias += sum dout. */
 int wn_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* dbias,
-                 int B, int T, int Q, int C, int fw, void* stream);
+                 int B, int T, int Q, int C, int fw, const WnExec* ex, void* stream);
 
 /* ---- A5: dense dilated causal convolution, any shape (DilatedConvolution1D.__call__,
  * wavenet.py:294-342):  out[b,t,o] = sum_k sum_c W[o,c,k] x[b, t-(fw-1-k)d, c] + bias[o] for
@@ -78,7 +97,7 @@ int wn_layer_fwd(const float* x,
                  const float* Wf, const float* bf, const float* Wg, const float* bg,
                  const float* Wp, const float* bp,
                  float* out, float* z, float* f_save, float* g_save,
-                 int B, int T, int Cr, int Cd, int fw, int d, int Z, void* stream);
+                 int B, int T, int Cr, int Cd, int fw, int d, int Z, const WnExec* ex, void* stream);
 
 /* Backward of one layer (Chainer autograd through wavenet.py:358-368).
  *   dz = Wp^T dout + dz_skip      da = dz g (1-f^2)      dg = dz f g (1-g)     (0 for t < Z)
@@ -95,17 +114,17 @@ int wn_layer_bwd(const float* x, const float* f, const float* g,
                  const float* dout, const float* dz_skip,
                  float* dx, float* dWf, float* dbf, float* dWg, float* dbg, float* dWp, float* dbp,
                  float* dab_ws,
-                 int B, int T, int Cr, int Cd, int fw, int d, int Z, void* stream);
+                 int B, int T, int Cr, int Cd, int fw, int d, int Z, const WnExec* ex, void* stream);
 
 /* ---- 1x1 convolution with the activation the reference applies BEFORE it -------------------
  * out[n,:] = W act(x[n,:]) + b.   Head layers (wavenet.py:587-590: relu then conv; elu in
  * faster_wavenet.py:107-110), projection_block / projection_softmax with WN_ACT_NONE.           */
 int wn_pointwise_fwd(const float* x, const float* W, const float* bias, float* out,
-                     int N, int Cin, int Cout, int act, void* stream);
+                     int N, int Cin, int Cout, int act, const WnExec* ex, void* stream);
 /* dx[n,:] = act'(x[n,:]) * (W^T dout[n,:]) (overwritten; NULL to skip);  dW += dout act(x)^T;
  * dbias += sum dout. */
 int wn_pointwise_bwd(const float* x, const float* W, const float* dout, float* dx, float* dW,
-                     float* dbias, int N, int Cin, int Cout, int act, void* stream);
+                     float* dbias, int N, int Cin, int Cout, int act, const WnExec* ex, void* stream);
 
 /* ---- A11: the skip sum, deferred:  skip[b,t,:] = sum_l (Ws_l z_l[b, t_off+t, :] + bs_l) ------
  * (wavenet.py:574-582: sum_skip_connections += projection_softmax, all blocks, all layers).
@@ -113,14 +132,14 @@ int wn_pointwise_bwd(const float* x, const float* W, const float* dout, float* d
  * only the last train_width columns, train_audio/train.py:73).  accumulate != 0 adds to skip.  */
 int wn_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const float* const* bs,
                     const int* cd, float* skip, int B, int T, int t_off, int Tw, int Cs,
-                    int accumulate, void* stream);
+                    int accumulate, const WnExec* ex, void* stream);
 /* dz[l][b,t,:] = Ws_l^T dskip[b,t-t_off,:] for t >= t_off, 0 before (dz[l] is (B,T,cd[l])). */
 int wn_skip_sum_bwd_dz(int L, const float* const* Ws, const int* cd, const float* dskip,
-                       float* const* dz, int B, int T, int t_off, int Tw, int Cs, void* stream);
+                       float* const* dz, int B, int T, int t_off, int Tw, int Cs, const WnExec* ex, void* stream);
 /* dWs[l] += dskip^T z_l (Cs x cd[l]);  dbs[l] += sum dskip  (either table entry may be NULL). */
 int wn_skip_sum_bwd_dw(int L, const float* const* z, const int* cd, const float* dskip,
                        float* const* dWs, float* const* dbs, int B, int T, int t_off, int Tw, int Cs,
-                       void* stream);
+                       const WnExec* ex, void* stream);
 
 /* ---- A11 + A15 as one call each: the reference's per-layer Python loop (wavenet.py:572-582 and
  * Chainer's backward over it) executed inside the library on one stream.                        */
@@ -140,8 +159,12 @@ typedef struct WnStackDesc {
  * reach -- are not computed; xs / z / f / g are left untouched there and wn_stack_bwd must then be called
  * with dout == NULL.  Loss and gradients are unchanged.                                              */
 int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, float* f, float* g,
-                 float* skip, int B, int T, int t_off, int compat_zero_prefix, int window_only, void* stream);
+                 float* skip, int B, int T, int t_off, int compat_zero_prefix, int window_only, const WnExec* ex, void* stream);
 size_t wn_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T);
+/* Upper bound of the WnExec scratch any call on this model needs at batch (B, T): head_channels = softmax_conv_channels
+ * (n entries), causal_channels / causal_fw describe the first causal layer (its gradient tables).  d may be NULL. */
+size_t wn_exec_workspace_bytes(const WnStackDesc* d, int Q, int causal_channels, int causal_fw, const int* head_channels,
+                               int n_head_channels, int B, int T);
 /* dout: gradient of the last layer's output (NULL = unused, train_audio/train.py:72); dskip
  * (B,T-t_off,Cs): gradient of the skip sum (NULL = unused); dx (B,T,Cr) may be NULL.  Gradient
  * tables are host arrays of device pointers, accumulated into (the flat gradient arena).          */
@@ -149,7 +172,7 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
                  const float* g, const float* dout, const float* dskip, float* dx,
                  float* const* dWf, float* const* dbf, float* const* dWg, float* const* dbg,
                  float* const* dWp, float* const* dbp, float* const* dWs, float* const* dbs,
-                 float* ws, size_t ws_bytes, int B, int T, int t_off, int compat_zero_prefix, void* stream);
+                 float* ws, size_t ws_bytes, int B, int T, int t_off, int compat_zero_prefix, const WnExec* ex, void* stream);
 
 /* ---- softmax over the channel axis (wavenet.py:592) and A14 (wavenet.py:597-617) ------------ */
 int wn_softmax_fwd(const float* logits, float* prob, int N, int Q, void* stream);
@@ -241,17 +264,6 @@ int wn_eve_step(float* param, const float* grad, float* m, float* v, int64_t n,
 int wn_adam_step_dev(float* param, const float* grad, float* m, float* v, int64_t n,
                      const float* lr_t_dev, float beta1, float beta2, float eps, float weight_decay,
                      const float* sqnorm, float clip, float grad_mult, void* stream);
-/* Arithmetic of the channel GEMMs (skip sum, head, the wide-layer path of wn_layer_* / wn_stack_* for widths other
- * than 32/32/2, and their backward).  The reference computes them in fp32 (cuDNN/cuBLAS); here
- *   WN_GEMM_FP32    fp32-input MFMA                                        (exact fp32 products)
- *   WN_GEMM_BF16X3  every operand split into three bf16 parts, six products (fp32-accurate; the default)
- *   WN_GEMM_BF16    operands rounded to bf16 once, fp32 accumulation       (BASELINE config 5's arithmetic)
- * Process-wide; the start value can also be set with WAVENET_HIP_GEMM=fp32|bf16x3|bf16.  Storage stays fp32.  The fused
- * 32-channel layer kernels always multiply in fp32.                                                              */
-enum { WN_GEMM_FP32 = 0, WN_GEMM_BF16X3 = 1, WN_GEMM_BF16 = 2 };
-int wn_set_gemm_precision(int mode);
-int wn_get_gemm_precision(void);
-
 /* The other update rules get_optimizer() names (wavenet.py:81-97; chainer.optimizers.SGD / MomentumSGD / AdaGrad /
  * AdaDelta / NesterovAG / RMSprop as Chainer publishes them), behind the same hooks as wn_adam_step:
  *   SGD          p -= lr g                                  MomentumSGD  v = hyper v - lr g; p += v

@@ -37,3 +37,20 @@ def btc(a):
 
 def to_np(t):
     return t.detach().cpu().numpy()
+
+
+_SCRATCH = {}
+
+
+def EX(precision=None, nbytes=160 << 20):
+    """WnExec for tests that call the C ABI directly: the module-default GEMM precision (or the given one) and a scratch
+    buffer that lives as long as the test process."""
+    import ctypes as C
+    from wavenet_amd import _lib
+    if nbytes not in _SCRATCH:
+        _SCRATCH[nbytes] = torch.empty((nbytes,), device="cuda", dtype=torch.uint8)
+    ex = _lib.WnExec()
+    ex.precision = _lib.GEMM_PRECISIONS.index(precision or _lib.get_gemm_precision())
+    ex.ws, ex.ws_bytes = _SCRATCH[nbytes].data_ptr(), nbytes
+    _SCRATCH["last"] = ex
+    return C.byref(ex)

@@ -16,7 +16,7 @@ from wavenet_amd import _lib, data
 from wavenet_amd import FasterWaveNet, Params, WaveNet
 from wavenet_amd._lib import check, ptr
 
-from gpu_util import CFG1, CFG2, build, dev, btc, to_np
+from gpu_util import CFG1, CFG2, EX, build, dev, btc, to_np
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -52,7 +52,7 @@ def _run_layer(x, Wf, Wg, Wp, b, Z, Cr, Cd, fw, d, save):
     tens = [dev(Wf), None if b[0] is None else dev(b[0]), dev(Wg), None if b[1] is None else dev(b[1]), dev(Wp),
             None if b[2] is None else dev(b[2])]
     check(_lib.lib().wn_layer_fwd(ptr(xb), *[ptr(t) for t in tens], ptr(out), ptr(z), ptr(f), ptr(g), B, T, Cr, Cd, fw,
-                                  d, Z, None), "wn_layer_fwd")
+                                  d, Z, EX(), None), "wn_layer_fwd")
     torch.cuda.synchronize()
     return out, z, f, g
 
@@ -168,7 +168,7 @@ def test_embed_bwd_scatter(B, T, Q, C, fw, bias):
     db = torch.zeros((C,), device="cuda") if bias else None
     idx_d, dout_d = dev(idx), dev(dout)
     for _ in range(2):                                             # accumulates: two calls = twice the gradient
-        check(_lib.lib().wn_embed_bwd(ptr(idx_d), ptr(dout_d), ptr(dW), ptr(db), B, T, Q, C, fw, None), "wn_embed_bwd")
+        check(_lib.lib().wn_embed_bwd(ptr(idx_d), ptr(dout_d), ptr(dW), ptr(db), B, T, Q, C, fw, EX(), None), "wn_embed_bwd")
     torch.cuda.synchronize()
     np.testing.assert_allclose(to_np(dW), 2 * want, atol=2e-4 * max(1.0, np.abs(want).max()))
     if bias:
@@ -663,13 +663,13 @@ def test_pointwise_mfma_fwd_bwd(N, Cin, Cout, act, bias):
     lib = _lib.lib()
     dx_, dW_, db_ = dev(x), dev(W), (None if b is None else dev(b))
     out = torch.empty((N, Cout), device="cuda")
-    check(lib.wn_pointwise_fwd(ptr(dx_), ptr(dW_), ptr(db_), ptr(out), N, Cin, Cout, _lib.ACT[act], None))
+    check(lib.wn_pointwise_fwd(ptr(dx_), ptr(dW_), ptr(db_), ptr(out), N, Cin, Cout, _lib.ACT[act], EX(), None))
     np.testing.assert_allclose(to_np(out), ref.detach().numpy(), atol=ATOL)
     gd = dev(g)
     dx = torch.empty((N, Cin), device="cuda")
     dW = torch.zeros((Cout, Cin), device="cuda")
     dbias = torch.zeros((Cout,), device="cuda") if bias else None
-    check(lib.wn_pointwise_bwd(ptr(dx_), ptr(dW_), ptr(gd), ptr(dx), ptr(dW), ptr(dbias), N, Cin, Cout, _lib.ACT[act], None))
+    check(lib.wn_pointwise_bwd(ptr(dx_), ptr(dW_), ptr(gd), ptr(dx), ptr(dW), ptr(dbias), N, Cin, Cout, _lib.ACT[act], EX(), None))
     np.testing.assert_allclose(to_np(dx), xt.grad.numpy(), atol=ATOL)
     np.testing.assert_allclose(to_np(dW), Wt.grad.numpy(), atol=1e-4 * max(1.0, float(Wt.grad.abs().max())))
     if bias:
@@ -739,7 +739,7 @@ def test_layer_bwd(Cr, Cd, fw, d, B, T, bias, with_dout):
     check(lib.wn_layer_bwd(ptr(xb), ptr(fb), ptr(gb), ptr(wt[0]), ptr(wt[1]), ptr(wt[2]), ptr(do), ptr(dz), ptr(dx),
                            ptr(gW[0]), ptr(gb_[0]), ptr(gW[1]), ptr(gb_[1]),
                            ptr(gW[2] if with_dout else None), ptr(gb_[2] if with_dout else None), ptr(dab),
-                           B, T, Cr, Cd, fw, d, Z, None), "wn_layer_bwd")
+                           B, T, Cr, Cd, fw, d, Z, EX(), None), "wn_layer_bwd")
     torch.cuda.synchronize()
     np.testing.assert_allclose(to_np(dx), btc(dx_ref), atol=2e-4)
     for k in range(3 if with_dout else 2):
@@ -871,12 +871,19 @@ def test_c_abi_rejects_bad_arguments_without_touching_memory():
     out = torch.empty_like(x)
     z = torch.empty_like(x)
     # out aliasing x, negative Z, f without g, non-positive sizes: all refused with a message
-    assert lib.wn_layer_fwd(ptr(x), ptr(W), None, ptr(W), None, ptr(Wp), None, ptr(x), ptr(z), None, None, 1, 8, 32, 32, 2, 1, 0, None) == -1
+    assert lib.wn_layer_fwd(ptr(x), ptr(W), None, ptr(W), None, ptr(Wp), None, ptr(x), ptr(z), None, None, 1, 8, 32, 32, 2, 1, 0, None, None) == -1
     assert b"alias" in lib.wn_last_error()
-    assert lib.wn_layer_fwd(ptr(x), ptr(W), None, ptr(W), None, ptr(Wp), None, ptr(out), ptr(z), None, None, 1, 8, 32, 32, 2, 1, -3, None) == -1
-    assert lib.wn_layer_fwd(ptr(x), ptr(W), None, ptr(W), None, ptr(Wp), None, ptr(out), ptr(z), ptr(z), None, 1, 8, 32, 32, 2, 1, 0, None) == -1
-    assert lib.wn_layer_fwd(ptr(x), ptr(W), None, ptr(W), None, ptr(Wp), None, ptr(out), ptr(z), None, None, 0, 8, 32, 32, 2, 1, 0, None) == -1
-    assert lib.wn_skip_sum_fwd(1, None, None, None, None, None, 1, 8, 0, 8, 32, 0, None) == -1
+    assert lib.wn_layer_fwd(ptr(x), ptr(W), None, ptr(W), None, ptr(Wp), None, ptr(out), ptr(z), None, None, 1, 8, 32, 32, 2, 1, -3, None, None) == -1
+    assert lib.wn_layer_fwd(ptr(x), ptr(W), None, ptr(W), None, ptr(Wp), None, ptr(out), ptr(z), ptr(z), None, 1, 8, 32, 32, 2, 1, 0, None, None) == -1
+    assert lib.wn_layer_fwd(ptr(x), ptr(W), None, ptr(W), None, ptr(Wp), None, ptr(out), ptr(z), None, None, 0, 8, 32, 32, 2, 1, 0, None, None) == -1
+    assert lib.wn_skip_sum_fwd(1, None, None, None, None, None, 1, 8, 0, 8, 32, 0, None, None) == -1
+    # a call that needs scratch and gets none says how much it needs instead of allocating behind the caller's back
+    xw = torch.zeros((64, 64), device="cuda")
+    Ww = torch.zeros((64, 64), device="cuda")
+    ow = torch.empty((64, 64), device="cuda")
+    if os.environ.get("WAVENET_HIP_FORCE_GENERIC") != "1":
+        assert lib.wn_pointwise_fwd(ptr(xw), ptr(Ww), None, ptr(ow), 64, 64, 64, 0, None, None) == -1
+        assert b"WnExec scratch" in lib.wn_last_error()
     with pytest.raises(_lib.WaveNetHipError):
         check(lib.wn_softmax_xent(None, None, None, None, 4, 4, None), "wn_softmax_xent")
 
@@ -1168,3 +1175,40 @@ def test_weight_gradients_of_the_fast_path_are_bit_reproducible():
     for k in exact:
         np.testing.assert_array_equal(runs[0][k], runs[1][k], err_msg=k)
     assert np.abs(runs[0]["causal_0"] - runs[1]["causal_0"]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_models_of_different_gemm_precision_interleave_in_one_process_under_graph_capture():
+    """ABI v2: the arithmetic of the channel GEMMs travels with every call (WnExec), scratch comes from the caller, nothing
+    is allocated or switched process-wide -- an exact-fp32 model and a bf16-operand model train side by side, each through
+    its own captured graph, and each follows its own eager twin."""
+    from wavenet_amd import TrainStepGraph
+    from wavenet_amd.graph import default_loss
+    if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1":
+        pytest.skip("generic kernels only")
+    over = dict(quantization_steps=256, causal_conv_channels=[64], residual_conv_channels=[64] * 2, residual_num_blocks=2,
+                softmax_conv_channels=[128, 256])
+    nets = {}
+    for prec in ("fp32", "bf16"):
+        for kind in ("graph", "eager"):
+            p, w, n = build(over, seed=31)
+            n.gemm_precision = prec
+            n.update_laerning_rate(0.01)
+            n.optimizer.eps = 1e-3
+            nets[prec, kind] = n
+    rs = np.random.RandomState(2)
+    iw = nets["fp32", "eager"].input_width
+    batches = [(dev(rs.randint(0, 256, (2, iw + 90)).astype(np.int32)), dev(rs.randint(0, 256, (2, 90)).astype(np.int32)))
+               for _ in range(3)]
+    graphs = {prec: TrainStepGraph(nets[prec, "graph"], *batches[0]) for prec in ("fp32", "bf16")}
+    for x, t in batches:                                  # interleaved: fp32 graph, bf16 eager, bf16 graph, fp32 eager
+        graphs["fp32"].step(x, t)
+        nets["bf16", "eager"].backprop(default_loss(nets["bf16", "eager"], x, t))
+        graphs["bf16"].step(x, t)
+        nets["fp32", "eager"].backprop(default_loss(nets["fp32", "eager"], x, t))
+    torch.cuda.synchronize()
+    a32, g32 = to_np(nets["fp32", "eager"]._arena), to_np(nets["fp32", "graph"]._arena)
+    a16, g16 = to_np(nets["bf16", "eager"]._arena), to_np(nets["bf16", "graph"]._arena)
+    np.testing.assert_allclose(g32, a32, atol=3e-5)
+    np.testing.assert_allclose(g16, a16, atol=3e-5)
+    assert np.abs(a32 - a16).max() > 1e-4                 # and the two precisions really are different arithmetic

@@ -18,18 +18,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "wavenet_hip.h")).read()
-    declared = set(re.findall(r"\b(wn_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(wn(?:16)?_[a-z0-9_]+)\s*\(", hdr))
     assert declared, "no declarations parsed"
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(lib, name), "libwavenet_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert _lib.lib().wn_abi_version() == 1
+    assert _lib.lib().wn_abi_version() == 2
+    assert not hasattr(lib, "wn_set_gemm_precision")          # ABI v2: no process-wide arithmetic mode
 
 
 def test_argument_errors_do_not_need_a_gpu():
     lib = _lib.lib()
-    rc = lib.wn_layer_fwd(None, None, None, None, None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 0, None)
+    rc = lib.wn_layer_fwd(None, None, None, None, None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 0, None, None)
     assert rc == -1 and b"NULL" in lib.wn_last_error()
     with pytest.raises(_lib.WaveNetHipError):
         _lib.check(rc, "wn_layer_fwd")

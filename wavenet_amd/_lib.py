@@ -10,7 +10,7 @@ from typing import Dict, Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwavenet_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 WN_ACT_NONE, WN_ACT_RELU, WN_ACT_ELU = 0, 1, 2
 ACT = {"none": WN_ACT_NONE, None: WN_ACT_NONE, "relu": WN_ACT_RELU, "elu": WN_ACT_ELU}
@@ -21,6 +21,7 @@ _f = C.c_float
 _i64 = C.c_int64
 _pp = C.POINTER(C.c_void_p)
 _ip = C.POINTER(C.c_int)
+_ex = None      # C.POINTER(WnExec), set below the struct definition
 
 
 class WnDecoderDesc(C.Structure):
@@ -35,6 +36,14 @@ class WnDecoderDesc(C.Structure):
     ]
 
 
+class WnExec(C.Structure):
+    """Per-call options of the entry points that hold a channel GEMM or need scratch (include/wavenet_hip.h)."""
+    _fields_ = [("precision", _i), ("ws", _p), ("ws_bytes", C.c_size_t)]
+
+
+_ex = C.POINTER(WnExec)
+
+
 class WnStackDesc(C.Structure):
     _fields_ = [
         ("n_layers", _i), ("Cr", _i), ("Cs", _i), ("fw", _i), ("cd", _ip), ("dilation", _ip),
@@ -47,20 +56,21 @@ _SIGS = {
     "wn_last_error": (C.c_char_p, []),
     "wn_layer_fast_path": (_i, [_i, _i, _i]),
     "wn_embed_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "wn_embed_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "wn_embed_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _ex, _p]),
     "wn_conv_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "wn_conv_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "wn_layer_fwd": (_i, [_p] * 11 + [_i] * 7 + [_p]),
-    "wn_layer_bwd": (_i, [_p] * 16 + [_i] * 7 + [_p]),
+    "wn_layer_fwd": (_i, [_p] * 11 + [_i] * 7 + [_ex, _p]),
+    "wn_layer_bwd": (_i, [_p] * 16 + [_i] * 7 + [_ex, _p]),
     "wn_layer_bwd_workspace_floats": (C.c_size_t, [_i, _i, _i, _i, _i]),
-    "wn_pointwise_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "wn_pointwise_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "wn_skip_sum_fwd": (_i, [_i, _pp, _pp, _pp, _ip, _p, _i, _i, _i, _i, _i, _i, _p]),
-    "wn_skip_sum_bwd_dz": (_i, [_i, _pp, _ip, _p, _pp, _i, _i, _i, _i, _i, _p]),
-    "wn_skip_sum_bwd_dw": (_i, [_i, _pp, _ip, _p, _pp, _pp, _i, _i, _i, _i, _i, _p]),
-    "wn_stack_fwd": (_i, [C.POINTER(WnStackDesc), _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "wn_pointwise_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _ex, _p]),
+    "wn_pointwise_bwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _ex, _p]),
+    "wn_skip_sum_fwd": (_i, [_i, _pp, _pp, _pp, _ip, _p, _i, _i, _i, _i, _i, _i, _ex, _p]),
+    "wn_skip_sum_bwd_dz": (_i, [_i, _pp, _ip, _p, _pp, _i, _i, _i, _i, _i, _ex, _p]),
+    "wn_skip_sum_bwd_dw": (_i, [_i, _pp, _ip, _p, _pp, _pp, _i, _i, _i, _i, _i, _ex, _p]),
+    "wn_stack_fwd": (_i, [C.POINTER(WnStackDesc), _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _ex, _p]),
     "wn_stack_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(WnStackDesc), _i, _i]),
-    "wn_stack_bwd": (_i, [C.POINTER(WnStackDesc)] + [_p] * 8 + [_pp] * 8 + [_p, C.c_size_t, _i, _i, _i, _i, _p]),
+    "wn_stack_bwd": (_i, [C.POINTER(WnStackDesc)] + [_p] * 8 + [_pp] * 8 + [_p, C.c_size_t, _i, _i, _i, _i, _ex, _p]),
+    "wn_exec_workspace_bytes": (C.c_size_t, [C.POINTER(WnStackDesc), _i, _i, _i, _ip, _i, _i, _i]),
     "wn_softmax_fwd": (_i, [_p, _p, _i, _i, _p]),
     "wn_softmax_xent": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "wn_nchw_to_btc": (_i, [_p, _p, _i, _i, _i, _p]),
@@ -80,8 +90,6 @@ _SIGS = {
     "wn_eve_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p, _f, _f, _p]),
     "wn_rule_step": (_i, [_i, _p, _p, _p, _p, _i64, _f, _p, _f, _f, _f, _p, _f, _f, _p]),
     "wn_scale_by_dev": (_i, [_p, _p, _i64, _p]),
-    "wn_set_gemm_precision": (_i, [_i]),
-    "wn_get_gemm_precision": (_i, []),
     "wn16_supported": (_i, [C.POINTER(WnStackDesc)]),
     "wn16_pack_elems": (C.c_size_t, [C.POINTER(WnStackDesc)]),
     "wn16_pack_stack": (_i, [C.POINTER(WnStackDesc), _p, _p]),
@@ -179,16 +187,21 @@ def stream_ptr() -> Optional[int]:
 
 
 GEMM_PRECISIONS = ("fp32", "bf16x3", "bf16")
+_default_precision = {"fp32": "fp32", "bf16": "bf16"}.get(os.environ.get("WAVENET_HIP_GEMM", ""), "bf16x3")
 
 
 def set_gemm_precision(name: str) -> None:
-    """Arithmetic of the channel GEMMs (``wn_set_gemm_precision``): "fp32" (fp32 MFMA), "bf16x3" (three-way bf16 split,
-    fp32-accurate; the default) or "bf16" (operands rounded to bf16, fp32 accumulation: BASELINE config 5's arithmetic).
-    Process-wide; call it before capturing a TrainStepGraph (a captured graph keeps the kernels it was captured with)."""
+    """Default arithmetic of the channel GEMMs for models that do not set ``net.gemm_precision`` themselves: "fp32" (fp32
+    MFMA), "bf16x3" (three-way bf16 split, fp32-accurate; the start value, or WAVENET_HIP_GEMM) or "bf16" (operands
+    rounded to bf16, fp32 accumulation).  Pure host state: every library call carries its precision as an argument
+    (WnExec), so models of different precision coexist in one process."""
+    global _default_precision
     if name not in GEMM_PRECISIONS:
         raise ValueError("precision must be one of %r" % (GEMM_PRECISIONS,))
-    check(lib().wn_set_gemm_precision(GEMM_PRECISIONS.index(name)), "wn_set_gemm_precision")
+    if name != "fp32" and os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1":
+        raise WaveNetHipError("WAVENET_HIP_FORCE_GENERIC=1 pins the fp32 kernels")
+    _default_precision = name
 
 
 def get_gemm_precision() -> str:
-    return GEMM_PRECISIONS[lib().wn_get_gemm_precision()]
+    return "fp32" if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1" else _default_precision

@@ -12,6 +12,23 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+static thread_local const WnExec* g_exec = nullptr;
+ExecScope::ExecScope(const WnExec* ex) : prev(g_exec) { g_exec = ex; }
+ExecScope::~ExecScope() { g_exec = prev; }
+static bool force_generic();
+int gemm_mode() {
+    if (force_generic()) return WN_GEMM_FP32;
+    const int m = g_exec ? g_exec->precision : WN_GEMM_BF16X3;
+    return (m < WN_GEMM_FP32 || m > WN_GEMM_BF16) ? WN_GEMM_BF16X3 : m;
+}
+void* exec_scratch(size_t bytes, const char* what) {
+    if (!g_exec || !g_exec->ws || g_exec->ws_bytes < bytes) {
+        set_error("this call needs %zu bytes of WnExec scratch for %s (got %zu): size it with wn_exec_workspace_bytes()",
+                  bytes, what, g_exec && g_exec->ws ? g_exec->ws_bytes : (size_t)0);
+        return nullptr;
+    }
+    return g_exec->ws;
+}
 // test hook: WAVENET_HIP_FORCE_GENERIC=1 routes every call to the generic kernels
 static bool force_generic() {
     static int v = -1;
@@ -45,7 +62,9 @@ int wn_embed_fwd(const int32_t* idx, const float* W, const float* bias, float* o
 }
 
 int wn_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* dbias, int B, int T, int Q, int C,
-                 int fw, void* stream) {
+                 int fw, const WnExec* ex, void* stream) {
+    wn::ExecScope exec__(ex);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
     wn::ProfScope prof__("wn_embed_bwd", stream);
     NN(idx); NN(dout); NN(dW); POS(B); POS(T); POS(Q); POS(C); POS(fw);
     return generic_embed_bwd(idx, dout, dW, dbias, B, T, Q, C, fw, as_stream(stream));
@@ -69,7 +88,9 @@ int wn_conv_bwd(const float* x, const float* W, const float* dout, float* dx, fl
 
 int wn_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg,
                  const float* Wp, const float* bp, float* out, float* z, float* f_save, float* g_save, int B,
-                 int T, int Cr, int Cd, int fw, int d, int Z, void* stream) {
+                 int T, int Cr, int Cd, int fw, int d, int Z, const WnExec* ex, void* stream) {
+    wn::ExecScope exec__(ex);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
     wn::ProfScope prof__("wn_layer_fwd", stream);
     NN(x); NN(Wf); NN(Wg); NN(Wp); NN(out); NN(z);
     POS(B); POS(T); POS(Cr); POS(Cd); POS(fw); POS(d);
@@ -103,7 +124,9 @@ extern "C" {
 int wn_layer_bwd(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
                  const float* Wp, const float* dout, const float* dz_skip, float* dx, float* dWf, float* dbf,
                  float* dWg, float* dbg, float* dWp, float* dbp, float* dab_ws, int B, int T, int Cr, int Cd,
-                 int fw, int d, int Z, void* stream) {
+                 int fw, int d, int Z, const WnExec* ex, void* stream) {
+    wn::ExecScope exec__(ex);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
     wn::ProfScope prof__("wn_layer_bwd", stream);
     NN(x); NN(f); NN(g); NN(Wf); NN(Wg); NN(Wp); NN(dab_ws);
     POS(B); POS(T); POS(Cr); POS(Cd); POS(fw); POS(d);
@@ -123,7 +146,9 @@ int wn_layer_bwd(const float* x, const float* f, const float* g, const float* Wf
 }
 
 int wn_pointwise_fwd(const float* x, const float* W, const float* bias, float* out, int N, int Cin, int Cout,
-                     int act, void* stream) {
+                     int act, const WnExec* ex, void* stream) {
+    wn::ExecScope exec__(ex);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
     wn::ProfScope prof__("wn_pointwise_fwd", stream);
     NN(x); NN(W); NN(out); POS(N); POS(Cin); POS(Cout);
     WN_CHECK_ARG(act >= WN_ACT_NONE && act <= WN_ACT_ELU, "wn_pointwise_fwd: bad act %d", act);
@@ -133,7 +158,9 @@ int wn_pointwise_fwd(const float* x, const float* W, const float* bias, float* o
 }
 
 int wn_pointwise_bwd(const float* x, const float* W, const float* dout, float* dx, float* dW, float* dbias,
-                     int N, int Cin, int Cout, int act, void* stream) {
+                     int N, int Cin, int Cout, int act, const WnExec* ex, void* stream) {
+    wn::ExecScope exec__(ex);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
     wn::ProfScope prof__("wn_pointwise_bwd", stream);
     NN(x); NN(W); NN(dout); POS(N); POS(Cin); POS(Cout);
     WN_CHECK_ARG(act >= WN_ACT_NONE && act <= WN_ACT_ELU, "wn_pointwise_bwd: bad act %d", act);
@@ -157,7 +184,9 @@ static int check_skip(const char* fn, int L, int B, int T, int t_off, int Tw, in
 }
 
 int wn_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const float* const* bs, const int* cd,
-                    float* skip, int B, int T, int t_off, int Tw, int Cs, int accumulate, void* stream) {
+                    float* skip, int B, int T, int t_off, int Tw, int Cs, int accumulate, const WnExec* ex, void* stream) {
+    wn::ExecScope exec__(ex);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
     wn::ProfScope prof__("wn_skip_sum_fwd", stream);
     NN(z); NN(Ws); NN(cd); NN(skip);
     int rc = check_skip("wn_skip_sum_fwd", L, B, T, t_off, Tw, Cs);
@@ -169,7 +198,9 @@ int wn_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const 
 }
 
 int wn_skip_sum_bwd_dz(int L, const float* const* Ws, const int* cd, const float* dskip, float* const* dz, int B,
-                       int T, int t_off, int Tw, int Cs, void* stream) {
+                       int T, int t_off, int Tw, int Cs, const WnExec* ex, void* stream) {
+    wn::ExecScope exec__(ex);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
     wn::ProfScope prof__("wn_skip_sum_bwd_dz", stream);
     NN(Ws); NN(cd); NN(dskip); NN(dz);
     int rc = check_skip("wn_skip_sum_bwd_dz", L, B, T, t_off, Tw, Cs);
@@ -182,7 +213,9 @@ int wn_skip_sum_bwd_dz(int L, const float* const* Ws, const int* cd, const float
 }
 
 int wn_skip_sum_bwd_dw(int L, const float* const* z, const int* cd, const float* dskip, float* const* dWs,
-                       float* const* dbs, int B, int T, int t_off, int Tw, int Cs, void* stream) {
+                       float* const* dbs, int B, int T, int t_off, int Tw, int Cs, const WnExec* ex, void* stream) {
+    wn::ExecScope exec__(ex);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
     wn::ProfScope prof__("wn_skip_sum_bwd_dw", stream);
     NN(z); NN(cd); NN(dskip);
     int rc = check_skip("wn_skip_sum_bwd_dw", L, B, T, t_off, Tw, Cs);
@@ -299,16 +332,36 @@ int wn_scale_by_dev(float* x, const float* scale_dev, int64_t n, void* stream) {
     return generic_scale_by_dev(x, scale_dev, n, as_stream(stream));
 }
 
-int wn_set_gemm_precision(int mode) {
-    WN_CHECK_ARG(mode >= WN_GEMM_FP32 && mode <= WN_GEMM_BF16, "wn_set_gemm_precision: mode must be 0, 1 or 2");
-    if (force_generic() && mode != WN_GEMM_FP32) {
-        wn::set_error("wn_set_gemm_precision: WAVENET_HIP_FORCE_GENERIC=1 pins the fp32 kernels");
-        return WN_EARG;
+// Upper bound of the scratch any entry point asks for on this model (see the three users: launch_colgemm_b3's split
+// weight image, launch_wgrad_b3w's partial tiles, generic_embed_bwd's per-block tables).
+size_t wn_exec_workspace_bytes(const WnStackDesc* d, int Q, int causal_channels, int causal_fw, const int* head_channels,
+                               int n_head_channels, int B, int T) {
+    size_t mk = 0;                                          // largest (rows x contraction) product of a channel GEMM
+    size_t nprob = 8;
+    auto upd = [&](size_t m, size_t k) { if (m * k > mk) mk = m * k; };
+    if (d && d->n_layers > 0 && d->cd) {
+        size_t sum_cd = 0, max_cd = 0;
+        for (int l = 0; l < d->n_layers; ++l) { sum_cd += d->cd[l]; if ((size_t)d->cd[l] > max_cd) max_cd = d->cd[l]; }
+        upd(d->Cs, sum_cd);                                 // skip sum, dz of all layers
+        upd(2 * max_cd, (size_t)d->fw * d->Cr);             // wide layers: gate GEMM (filter and gate rows interleaved)
+        upd(d->Cr, 2 * max_cd * d->fw);                     // their dx
+        upd(max_cd, d->Cr);
+        nprob = sum_cd / 32 + d->Cs / 32 + 8;
     }
-    wn::set_gemm_mode(mode);
-    return WN_OK;
+    for (int i = 0; i + 1 < n_head_channels; ++i) {
+        upd(head_channels[i + 1], head_channels[i]);
+        nprob += head_channels[i] / 32 + head_channels[i + 1] / 32;
+    }
+    const size_t image = 12 * mk + (64u << 10);             // 6 KB per 32 x 32 tile, twice in gate mode, + the 128/128 Wp image
+    const size_t nB = B > 0 ? (size_t)B : 1;
+    const size_t parts = (256 + nB * ((nprob + 7) / 8) + 64) * (8 * 8 * 16 * 64) * sizeof(float);
+    const size_t tables = causal_channels > 0
+                              ? (size_t)256 * ((size_t)Q * causal_fw * causal_channels + causal_channels) * sizeof(float)
+                              : 0;
+    size_t need = image > parts ? image : parts;
+    if (tables > need) need = tables;
+    (void)T;
+    return (need + 4095) & ~(size_t)4095;
 }
-
-int wn_get_gemm_precision(void) { return wn::gemm_mode(); }
 
 }  // extern "C"

@@ -3,12 +3,11 @@
 // The shapes BASELINE.json names take the MFMA kernels in mfma_*.hip instead; these are the
 // fallback for everything else and the on-GPU cross-check of the fast kernels.
 #include <cstdlib>
-#include <map>
-#include <mutex>
 
 #include "wn_common.hpp"
 
 namespace wn {
+void* exec_scratch(size_t bytes, const char* what);       // api.hip: the current call's WnExec scratch
 
 static constexpr int kThreads = 256;
 
@@ -781,23 +780,6 @@ int generic_embed_fwd(const int32_t* idx, const float* W, const float* bias, flo
     return WN_OK;
 }
 
-// per-stream scratch for the per-block embedding-gradient tables (grown on first use, then reused)
-struct EmbScratch { void* buf = nullptr; size_t bytes = 0; };
-static std::mutex g_emb_mu;
-static std::map<hipStream_t, EmbScratch> g_emb_scratch;
-static void* embed_scratch_for(hipStream_t s, size_t bytes) {
-    std::lock_guard<std::mutex> lk(g_emb_mu);
-    EmbScratch& sc = g_emb_scratch[s];
-    if (sc.bytes < bytes) {
-        if (sc.buf) (void)hipFree(sc.buf);
-        sc.buf = nullptr;
-        sc.bytes = 0;
-        if (hipMalloc(&sc.buf, bytes) != hipSuccess) { sc.buf = nullptr; return nullptr; }
-        sc.bytes = bytes;
-    }
-    return sc.buf;
-}
-
 int generic_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* dbias, int B, int T,
                       int Q, int C, int fw, hipStream_t s) {
     int Cs = C;                                            // channel slice whose table fits in LDS
@@ -812,8 +794,9 @@ int generic_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* d
         int cpb = (int)((ncol + nb - 1) / nb);
         int nblk = (int)((ncol + cpb - 1) / cpb);
         const int nent = Q * fw * Cs + Cs;
-        float* ws = reinterpret_cast<float*>(embed_scratch_for(s, (size_t)nsl * nblk * nent * sizeof(float)));
-        if (!ws) { wn::set_error("embed_bwd: cannot allocate the per-block table scratch"); return WN_EHIP; }
+        float* ws = reinterpret_cast<float*>(exec_scratch((size_t)nsl * nblk * nent * sizeof(float),
+                                                          "the per-block embedding-gradient tables"));
+        if (!ws) return WN_EARG;
 #define EMB_LAUNCH(FW)                                                                                        \
     do {                                                                                                      \
         static bool attr_set = false;                                                                         \

@@ -61,9 +61,7 @@ struct WGArgs {
 };
 
 // 1 unless WAVENET_HIP_GEMM=fp32: contractions use three-way bf16 splits (6 bf16 MFMAs per product term)
-bool gemm_b3_enabled();
-int gemm_mode();            // 0 fp32 MFMA, 1 bf16x3 (default), 2 bf16 (one term)
-void set_gemm_mode(int m);
+bool gemm_b3_enabled();      // the current call's precision is bf16x3 or bf16
 // mode 0: multi-source, one output; mode 2: nprob problems of 32 rows sharing X.  Returns WN_ESHAPE when
 // the shape is not covered (the caller then uses the exact-fp32 kernel).
 int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s);

@@ -12,9 +12,6 @@
 // (tile = 32 rows x 32 k x {h,m,l} = 6 KB), so the per-chunk LDS fill is a plain copy done by LDS-DMA
 // (global_load_lds, no staging registers) into a double buffer: the copy of chunk c+1 lands while chunk c
 // computes.  X columns are split in registers right after their (prefetched) float4 loads.
-#include <map>
-#include <mutex>
-
 #include "mfma_gemm.hpp"
 
 namespace wn {
@@ -26,22 +23,6 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 static constexpr int kTileElems = 2 * 3 * 64 * 8;          // bf16 elements of one tile image: [ks][comp][lane][8]
 static constexpr int kTileBytes = kTileElems * 2;          // 6144
 
-// 0 = fp32 MFMA (mfma_gemm.hip), 1 = bf16x3 (six terms: fp32-accurate, the default), 2 = bf16 (one term: operands
-// rounded to bf16, fp32 accumulation -- BASELINE config 5's arithmetic).  WAVENET_HIP_GEMM=fp32|bf16x3|bf16 sets the
-// start value; wn_set_gemm_precision() changes it at run time.
-static int g_gemm_mode = -1;
-int gemm_mode() {
-    if (g_gemm_mode < 0) {
-        const char* e = getenv("WAVENET_HIP_GEMM");
-        const char* g = getenv("WAVENET_HIP_FORCE_GENERIC");
-        int v = 1;
-        if ((e && strcmp(e, "fp32") == 0) || (g && g[0] == '1')) v = 0;
-        else if (e && strcmp(e, "bf16") == 0) v = 2;
-        g_gemm_mode = v;
-    }
-    return g_gemm_mode;
-}
-void set_gemm_mode(int m) { g_gemm_mode = m; }
 bool gemm_b3_enabled() { return gemm_mode() >= 1; }
 static bool one_term() { return gemm_mode() == 2; }
 
@@ -471,24 +452,6 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
     }
 }
 
-// ---- per-stream scratch for the weight images (grown on first use, then reused: no allocation in steady state)
-struct Scratch { void* buf = nullptr; size_t bytes = 0; };
-static std::mutex g_mu;
-static std::map<hipStream_t, Scratch> g_scratch;
-static void* scratch_for(hipStream_t s, size_t bytes) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    Scratch& sc = g_scratch[s];
-    if (sc.bytes < bytes) {
-        if (sc.buf) (void)hipFree(sc.buf);
-        sc.buf = nullptr;
-        sc.bytes = 0;
-        size_t want = bytes < (4u << 20) ? (4u << 20) : bytes * 2;
-        if (hipMalloc(&sc.buf, want) != hipSuccess) { sc.buf = nullptr; return nullptr; }
-        sc.bytes = want;
-    }
-    return sc.buf;
-}
-
 int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     if (mode != 0 && mode != 2 && mode != 3 && mode != 4 && mode != 5) return WN_ESHAPE;
     int mtiles, nchunks, cps;
@@ -510,8 +473,8 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     const bool one = one_term();
     const size_t bytes = (size_t)nchunks * mtiles * (one ? kTileBytes / 3 : kTileBytes);
     const size_t bytes2 = mode == 5 ? (size_t)16 * (kTileBytes / 3) : 0;        // Wp's image behind the gate image
-    __bf16* img = reinterpret_cast<__bf16*>(scratch_for(s, bytes + bytes2));
-    if (!img) { wn::set_error("colgemm_b3: cannot allocate %zu bytes of weight scratch", bytes + bytes2); return WN_EHIP; }
+    __bf16* img = reinterpret_cast<__bf16*>(exec_scratch(bytes + bytes2, "the split weight image"));
+    if (!img) return WN_EARG;
     hipLaunchKernelGGL(k_split_w, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img, one ? 1 : 0);
     if (mode == 5) {
         if (!a.proj_W || !a.residual || !a.gate_z || a.act != WN_ACT_NONE || mtiles != 8) {
@@ -911,8 +874,8 @@ int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
     // atomics per workgroup into the same addresses -- cost more than the contraction; with long slabs (config 2's dWs: 85
     // chunks) the two cost the same (the partial tiles are ~60 MB of extra traffic) and this form is deterministic.
     const size_t part_bytes = (size_t)grid.x * grid.y * 8 * (8 * 16 * 64) * sizeof(float);
-    a.part = reinterpret_cast<float*>(scratch_for(s, part_bytes));
-    if (!a.part) { wn::set_error("wgrad_b3w: cannot allocate %zu bytes of partial-tile scratch", part_bytes); return WN_EHIP; }
+    a.part = reinterpret_cast<float*>(exec_scratch(part_bytes, "the weight-gradient partial tiles"));
+    if (!a.part) return WN_EARG;
     const bool one = one_term();
 #define W_LAUNCH(B2_, ACT_)                                                                                     \
     do {                                                                                                        \

@@ -47,7 +47,8 @@ size_t wn_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T) {
 }
 
 int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, float* f, float* g, float* skip,
-                 int B, int T, int t_off, int compat_zero_prefix, int window_only, void* stream) {
+                 int B, int T, int t_off, int compat_zero_prefix, int window_only, const WnExec* ex, void* stream) {
+    wn::ExecScope exec__(ex);
     int rc = check_desc(d);
     if (rc) return rc;
     WN_CHECK_ARG(x && xs && z && B > 0 && T > 0, "wn_stack_fwd: bad argument");
@@ -91,7 +92,7 @@ int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, floa
             } else {
                 rc = wn_layer_fwd(in, d->Wf[l], d->bf ? d->bf[l] : nullptr, d->Wg[l], d->bg ? d->bg[l] : nullptr, d->Wp[l],
                                   d->bp ? d->bp[l] : nullptr, out, z + zoff, f ? f + zoff : nullptr, g ? g + zoff : nullptr,
-                                  B, T, d->Cr, d->cd[l], d->fw, d->dilation[l], Z, stream);
+                                  B, T, d->Cr, d->cd[l], d->fw, d->dilation[l], Z, ex, stream);
             }
             if (rc) return rc;
             zp[l] = z + zoff;
@@ -100,7 +101,7 @@ int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, floa
         }
     }
     if (skip)
-        return wn_skip_sum_fwd(L, zp.data(), d->Ws, d->bs, d->cd, skip, B, T, t_off, T - t_off, d->Cs, 0, stream);
+        return wn_skip_sum_fwd(L, zp.data(), d->Ws, d->bs, d->cd, skip, B, T, t_off, T - t_off, d->Cs, 0, ex, stream);
     return WN_OK;
 }
 
@@ -108,7 +109,8 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
                  const float* g, const float* dout, const float* dskip, float* dx,
                  float* const* dWf, float* const* dbf, float* const* dWg, float* const* dbg, float* const* dWp,
                  float* const* dbp, float* const* dWs, float* const* dbs, float* ws, size_t ws_bytes, int B, int T,
-                 int t_off, int compat_zero_prefix, void* stream) {
+                 int t_off, int compat_zero_prefix, const WnExec* ex, void* stream) {
+    wn::ExecScope exec__(ex);
     int rc = check_desc(d);
     if (rc) return rc;
     WN_CHECK_ARG(x && xs && z && f && g && ws && dWf && dWg && dWp, "wn_stack_bwd: NULL argument");
@@ -140,11 +142,11 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
             wn::ProfScope prof__("wn_skip_sum_bwd_dz", stream);
             rc = mfma_skip_bwd_dz(L, d->Ws, d->cd, dskip, dzp.data(), B, T, t_off, Tw, d->Cs, true, as_stream(stream));
         } else {
-            rc = wn_skip_sum_bwd_dz(L, d->Ws, d->cd, dskip, dzp.data(), B, T, t_off, Tw, d->Cs, stream);
+            rc = wn_skip_sum_bwd_dz(L, d->Ws, d->cd, dskip, dzp.data(), B, T, t_off, Tw, d->Cs, ex, stream);
         }
         if (rc) return rc;
         if (dWs) {
-            rc = wn_skip_sum_bwd_dw(L, zp.data(), d->cd, dskip, dWs, dbs, B, T, t_off, Tw, d->Cs, stream);
+            rc = wn_skip_sum_bwd_dw(L, zp.data(), d->cd, dskip, dWs, dbs, B, T, t_off, Tw, d->Cs, ex, stream);
             if (rc) return rc;
         }
     }
@@ -201,7 +203,7 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
         } else
         rc = wn_layer_bwd(in, f + off[l], g + off[l], d->Wf[l], d->Wg[l], d->Wp[l], gout, dskip ? dzp[l] : nullptr, gin,
                           dWf[l], dbf ? dbf[l] : nullptr, dWg[l], dbg ? dbg[l] : nullptr, gout ? dWp[l] : nullptr,
-                          (gout && dbp) ? dbp[l] : nullptr, dab, B, T, d->Cr, d->cd[l], d->fw, d->dilation[l], Z, stream);
+                          (gout && dbp) ? dbp[l] : nullptr, dab, B, T, d->Cr, d->cd[l], d->fw, d->dilation[l], Z, ex, stream);
         if (rc) return rc;
         gout = gin;
         if (!gin) break;          // l == 0 and the caller does not want dx

@@ -157,12 +157,20 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
 }
 
+static int launch_cgemm256(CG16& a, hipStream_t s);
+
 int launch_cgemm(CG16& a, hipStream_t s) {
     if (a.M % 128 || a.ksrc % 128 || a.nsrc < 1 || a.nsrc > kMaxSrc16 || a.K != a.nsrc * a.ksrc) {
         wn::set_error("w16 cgemm: unsupported shape M=%d K=%d nsrc=%d ksrc=%d", a.M, a.K, a.nsrc, a.ksrc);
         return WN_ESHAPE;
     }
     if (a.ep != 0 && a.ob_stride != 0) { wn::set_error("w16 cgemm: extra operand with split outputs"); return WN_EARG; }
+    {
+        bool plain = a.ep == 0 && !a.relu_x && !a.out_f32 && a.M % 256 == 0 && a.ksrc % 64 == 0 && a.ob_col % 128 == 0 &&
+                     (a.ob_col == 0 || a.ob_col == 128) && (long long)a.B * a.rows_per_b >= 4096;
+        for (int i = 0; i < a.nsrc && plain; ++i) plain = a.shift[i] == 0;
+        if (plain && a.x_row0 >= 0 && a.x_row0 + a.rows_per_b <= a.x_rows_per_b) return launch_cgemm256(a, s);
+    }
     a.blocks_per_b = (a.rows_per_b + 127) / 128;
     a.n_blocks = a.B * a.blocks_per_b;
     const int grid = a.n_blocks * (a.M / 128);
@@ -187,6 +195,151 @@ int launch_cgemm(CG16& a, hipStream_t s) {
         default: wn::set_error("w16 cgemm: unsupported epilogue combination %d", key); return WN_EARG;
     }
 #undef CGL
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+// =============================================================================================
+// k16_cgemm256: the same contraction for the two large ones (the deferred skip sum, K = 128 L; dz_skip of all layers,
+// M = 128 L): 256 columns x 256 output channels per workgroup, 64-deep stages (128-byte tile rows).
+// With 128 x 128 blocks these GEMMs ran one 64 KB stage per ~1.8 us of LDS-DMA latency (measured: 0.98 / 0.87 ms, the
+// same whether the LDS reads were serialised with the MFMAs or batched): the latency is paid per stage, so a stage now
+// carries four times the work (8.4 MFLOP per 64 KB) and the X tile is re-read from L2 half as often.
+// Tile format here: rows of 128 bytes, chunk c (0..7) of row r at position c ^ ((r >> 1) & 7) -- two rows share a
+// 256-byte bank line, so the 16 rows of a ds_read_b128 lane group hit 16 distinct 16-byte slots.
+// =============================================================================================
+static constexpr int kBTileB = 256 * 128;               // 32 KB: 256 rows x 64 bf16
+static constexpr int kCg256Lds = 4 * kBTileB;           // X[2], W[2]
+
+__device__ __forceinline__ int boff(int r, int c) { return (r << 7) + ((c ^ ((r >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k16_cgemm256(CG16 a) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    auto xt = [&](int buf) { return lds + buf * kBTileB; };
+    auto wt = [&](int buf) { return lds + (2 + buf) * kBTileB; };
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int wn = w & 1, wm = w >> 1;                   // wave tile: columns 128 wn .., channels 64 wm ..
+    const int nmb = a.M >> 8;
+    int nblk, mblk;
+    {
+        const int id = blockIdx.x;
+        if ((a.n_blocks & 7) == 0) {
+            const int xcd = id & 7, slot = id >> 3;
+            mblk = slot % nmb;
+            nblk = (slot / nmb) * 8 + xcd;
+        } else {
+            mblk = id % nmb;
+            nblk = id / nmb;
+        }
+    }
+    const int bpb = a.blocks_per_b;
+    const int b = nblk / bpb;
+    const int r0 = (nblk - b * bpb) * 256;
+    const int m0 = mblk * 256;
+    const int spk = a.ksrc >> 6;                         // stages per source
+    const int nst = a.nsrc * spk;
+    const int lr = lane >> 3, lp = lane & 7;
+
+    auto issue = [&](int st, int buf) {
+        const int src = st / spk;
+        const int k0 = (st - src * spk) * 64;
+        const bf16* xb = a.X[src] + ((long long)b * a.x_rows_per_b) * a.ldx + k0;
+        const int sh = a.x_row0 + r0;
+        const int hi = a.x_rows_per_b - 1;
+        const bf16* wb = a.W + (long long)m0 * a.K + st * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int p = w + 8 * i;
+            const int r = 8 * p + lr;
+            const int c = lp ^ ((r >> 1) & 7);
+            int t = sh + r;
+            t = t > hi ? hi : t;
+            W16_DMA16(xb + (long long)t * a.ldx + c * 8, xt(buf) + p * 1024);
+            W16_DMA16(wb + (long long)r * a.K + c * 8, wt(buf) + p * 1024);
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
+    issue(0, 0);
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        wait_vm<0>();
+        barrier();
+        if (st + 1 < nst) issue(st + 1, buf ^ 1);
+        const char* xb = xt(buf);
+        const char* wb = wt(buf);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 bv[4], av[2];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const bf16x8*>(xb + boff(128 * wn + 32 * nt + j, 2 * s + h));
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) av[mt] = *reinterpret_cast<const bf16x8*>(wb + boff(64 * wm + 32 * mt + j, 2 * s + h));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[nt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: two 128-channel halves, each a [256 rows][256 B] tile in the format of w16.hpp, then whole rows ----
+    barrier();
+    const int nrows = a.rows_per_b - r0 < 256 ? a.rows_per_b - r0 : 256;
+    const long long orow0 = (long long)b * a.rows_per_b + r0;
+    {
+        char* half = lds + (wm >> 1) * (256 * 256);      // this wave's 64 channels lie in half wm >> 1
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int row = 128 * wn + 32 * nt + j;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int mc = 64 * (wm & 1) + 32 * mt + 8 * q + 4 * h;      // channel inside the half
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = acc[nt][mt][4 * q + e] + (a.bias ? a.bias[m0 + 128 * (wm >> 1) + mc + e] : 0.f);
+                    *reinterpret_cast<bf16x4*>(half + toff(row, mc >> 3) + 8 * ((mc >> 2) & 1)) = pack4(v[0], v[1], v[2], v[3]);
+                }
+        }
+    }
+    barrier();
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int ob = 2 * mblk + hh;                    // 128-channel output block
+        bf16* o = reinterpret_cast<bf16*>(a.out) + (long long)ob * a.ob_stride + orow0 * a.ldo + ob * a.ob_col;
+        const char* half = lds + hh * (256 * 256);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = w + 8 * i;                     // 4-row piece of the half tile
+            const int r = 4 * p + (lane >> 4);
+            const int c = (lane & 15) ^ key(r);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(half + p * 1024 + lane * 16);
+            if (r < nrows) *reinterpret_cast<u32x4*>(o + (long long)r * a.ldo + c * 8) = v;
+        }
+    }
+}
+
+static int launch_cgemm256(CG16& a, hipStream_t s) {
+    a.blocks_per_b = (a.rows_per_b + 255) / 256;
+    a.n_blocks = a.B * a.blocks_per_b;
+    const int grid = a.n_blocks * (a.M / 256);
+    static bool attr = false;
+    if (!attr) {
+        WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k16_cgemm256), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kCg256Lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k16_cgemm256, dim3(grid), dim3(512), kCg256Lds, s, a);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

@@ -37,8 +37,15 @@ int generic_sample(const float*, const double*, int32_t*, int, int, hipStream_t)
 int generic_mulaw_encode_pcm16(const int16_t* pcm, const int32_t* lut, int32_t* tok, long long n, hipStream_t s);
 int generic_mulaw_decode(const int32_t* tok, const float* table, float* out, long long n, int Q, hipStream_t s);
 int generic_sqnorm(const float* g, const float* p, long long n, float gmult, float wd, float* out, hipStream_t s);
-int gemm_mode();            // mfma_gemm_b3.hip: 0 fp32 MFMA, 1 bf16x3 (default), 2 bf16 (one term)
-void set_gemm_mode(int m);
+// ---- the current call's WnExec, handed down the host-side call tree through a thread-local (set by the entry point for
+// the duration of the call: nothing survives it, calls on different threads do not see each other) ----------------
+struct ExecScope {
+    const WnExec* prev;
+    explicit ExecScope(const WnExec* ex);
+    ~ExecScope();
+};
+int gemm_mode();                       // WN_GEMM_* of the current call (WN_GEMM_FP32 under WAVENET_HIP_FORCE_GENERIC=1)
+void* exec_scratch(size_t bytes, const char* what);   // the caller's scratch; NULL + error text when it is too small
 int generic_scale_by_dev(float* x, const float* sdev, long long n, hipStream_t s);
 int generic_rule(int rule, float* p, const float* g, float* s1, float* s2, long long n, float lr, float hy, float eps,
                  float wd, const float* sqnorm, float clip, float gmult, const float* lr_dev, hipStream_t s);

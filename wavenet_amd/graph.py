@@ -82,7 +82,7 @@ class TrainStepGraph(object):
         the old value (only the batch and the learning rate travel through device memory)."""
         opt, p = self.net.optimizer, self.net.params
         return tuple(getattr(opt, k, None) for k in ("beta1", "beta2", "beta3", "eps", "hyper")) + \
-            (p.gradient_clipping, p.weight_decay, _lib.get_gemm_precision())
+            (p.gradient_clipping, p.weight_decay, self.net.gemm_precision or _lib.get_gemm_precision())
 
     def _fwd_bwd(self):
         self.net.zero_grads()

@@ -121,14 +121,14 @@ class _Fn(torch.autograd.Function):
 
 class _EmbedFn(_Fn):
     @staticmethod
-    def forward(ctx, idx, W, b, fw, hook):
+    def forward(ctx, idx, W, b, fw, net):
         B, T = idx.shape
         Cc, Q = W.shape[0], W.shape[1]
         out = torch.empty((B, T, Cc), device=idx.device, dtype=torch.float32)
         check(_lib.lib().wn_embed_fwd(ptr(idx), ptr(W), ptr(b), ptr(out), B, T, Q, Cc, fw, stream_ptr()),
               "wn_embed_fwd")
         ctx.save_for_backward(idx)
-        ctx.W, ctx.b, ctx.fw = W, b, fw
+        ctx.W, ctx.b, ctx.fw, ctx.net = W, b, fw, net
         return out
 
     @staticmethod
@@ -138,7 +138,7 @@ class _EmbedFn(_Fn):
         B, T = idx.shape
         dout = dout.contiguous()
         check(_lib.lib().wn_embed_bwd(ptr(idx), ptr(dout), ptr(W.grad), ptr(None if b is None else b.grad), B, T,
-                                      W.shape[1], W.shape[0], ctx.fw, stream_ptr()), "wn_embed_bwd")
+                                      W.shape[1], W.shape[0], ctx.fw, ctx.net._exec(B), stream_ptr()), "wn_embed_bwd")
         return None, None, None, None, None
 
 
@@ -175,15 +175,15 @@ class _PointwiseFn(_Fn):
     """out = W act(x) + b  (head convs, projection convs)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, act, hook):
+    def forward(ctx, x, W, b, act, net):
         lead = x.shape[:-1]
         Cin, Cout = x.shape[-1], W.shape[0]
         x2 = x.reshape(-1, Cin).contiguous()
         out = torch.empty((x2.shape[0], Cout), device=x.device, dtype=torch.float32)
         check(_lib.lib().wn_pointwise_fwd(ptr(x2), ptr(W), ptr(b), ptr(out), x2.shape[0], Cin, Cout, act,
-                                          stream_ptr()), "wn_pointwise_fwd")
+                                          net._exec(), stream_ptr()), "wn_pointwise_fwd")
         ctx.save_for_backward(x2)
-        ctx.W, ctx.b, ctx.act, ctx.lead = W, b, act, lead
+        ctx.W, ctx.b, ctx.act, ctx.lead, ctx.net = W, b, act, lead, net
         return out.view(*lead, Cout)
 
     @staticmethod
@@ -195,7 +195,7 @@ class _PointwiseFn(_Fn):
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
         check(_lib.lib().wn_pointwise_bwd(ptr(x2), ptr(W), ptr(dout2), ptr(dx), ptr(W.grad),
                                           ptr(None if b is None else b.grad), x2.shape[0], Cin, Cout, ctx.act,
-                                          stream_ptr()), "wn_pointwise_bwd")
+                                          ctx.net._exec(), stream_ptr()), "wn_pointwise_bwd")
         return (None if dx is None else dx.view(*ctx.lead, Cin)), None, None, None, None
 
 
@@ -260,8 +260,8 @@ class _StackFn(_Fn):
         g = torch.empty_like(z) if train else None
         skip = torch.empty((B, T - t_off, net._Cs), device=dev_, dtype=torch.float32)
         check(_lib.lib().wn_stack_fwd(desc, ptr(x), ptr(xs), ptr(z), ptr(f), ptr(g), ptr(skip), B, T, t_off,
-                                      1 if net.compat_zero_prefix else 0, 1 if window_only else 0, stream_ptr()),
-              "wn_stack_fwd")
+                                      1 if net.compat_zero_prefix else 0, 1 if window_only else 0, net._exec(B),
+                                      stream_ptr()), "wn_stack_fwd")
         ctx.net, ctx.t_off, ctx.shape, ctx.window_only = net, t_off, (B, T, Cr), bool(window_only)
         ctx.saved = (x, xs, z, f, g) if train else None
         net._last_layer_inputs = [x] + [xs[l] for l in range(L - 1)]      # FasterWaveNet seeds its rings from these
@@ -287,8 +287,8 @@ class _StackFn(_Fn):
         dx = torch.empty((B, T, Cr), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         check(lib.wn_stack_bwd(desc, ptr(x), ptr(xs), ptr(z), ptr(f), ptr(g), ptr(dout), ptr(dskip), ptr(dx),
                                gt["wf"], gt["bf"], gt["wg"], gt["bg"], gt["wp"], gt["bp"], gt["ws"], gt["bs"],
-                               ptr(ws), nbytes, B, T, t_off, 1 if net.compat_zero_prefix else 0, stream_ptr()),
-              "wn_stack_bwd")
+                               ptr(ws), nbytes, B, T, t_off, 1 if net.compat_zero_prefix else 0, net._exec(B),
+                               stream_ptr()), "wn_stack_bwd")
         ctx.saved = None
         return dx, None, None, None, None, None
 
@@ -299,14 +299,14 @@ class _StackFn(_Fn):
 # ----------------------------------------------------------------------------------------------
 class _Embed16Fn(_Fn):
     @staticmethod
-    def forward(ctx, idx, W, b, fw, hook):
+    def forward(ctx, idx, W, b, fw, net):
         B, T = idx.shape
         Cc, Q = W.shape[0], W.shape[1]
         out = torch.empty((B, T, Cc), device=idx.device, dtype=torch.bfloat16)
         check(_lib.lib().wn16_embed_fwd(ptr(idx), ptr(W), ptr(b), ptr(out), B, T, Q, Cc, fw, stream_ptr()),
               "wn16_embed_fwd")
         ctx.save_for_backward(idx)
-        ctx.W, ctx.b, ctx.fw = W, b, fw
+        ctx.W, ctx.b, ctx.fw, ctx.net = W, b, fw, net
         return out
 
     @staticmethod
@@ -319,7 +319,7 @@ class _Embed16Fn(_Fn):
         lib = _lib.lib()
         check(lib.wn16_cvt_to_f32(ptr(dout), ptr(d32), dout.numel(), stream_ptr()), "wn16_cvt_to_f32")
         check(lib.wn_embed_bwd(ptr(idx), ptr(d32), ptr(W.grad), ptr(None if b is None else b.grad), B, T,
-                               W.shape[1], W.shape[0], ctx.fw, stream_ptr()), "wn_embed_bwd")
+                               W.shape[1], W.shape[0], ctx.fw, ctx.net._exec(B), stream_ptr()), "wn_embed_bwd")
         return None, None, None, None, None
 
 
@@ -459,7 +459,7 @@ class Convolution1x1(_Link):
     def __call__(self, x, act="none"):
         x = self.net.to_variable(x)
         _need_gpu(x)
-        return _as_view(_PointwiseFn.apply(_to_btc(x), self.W, self.b, ACT[act], self.net._hook))
+        return _as_view(_PointwiseFn.apply(_to_btc(x), self.W, self.b, ACT[act], self.net))
 
 
 class ResidualConvLayer(object):
@@ -488,7 +488,7 @@ class ResidualConvLayer(object):
         check(_lib.lib().wn_layer_fwd(ptr(xb), ptr(self.wf.W), ptr(self.wf.b), ptr(self.wg.W), ptr(self.wg.b),
                                       ptr(self.projection_block.W), ptr(self.projection_block.b), ptr(out), ptr(z),
                                       None, None, B, T, Cr, self.cd, self.fw, self.dilation,
-                                      self.net._Z(T, self.dilation), stream_ptr()), "wn_layer_fwd")
+                                      self.net._Z(T, self.dilation), self.net._exec(B), stream_ptr()), "wn_layer_fwd")
         return out, z
 
     def __call__(self, x):
@@ -497,7 +497,7 @@ class ResidualConvLayer(object):
         _need_gpu(x)
         with torch.no_grad():
             out, z = self._run(_to_btc(x).contiguous(), False)
-            skip = _PointwiseFn.apply(z, self.projection_softmax.W, self.projection_softmax.b, ACT["none"], None)
+            skip = _PointwiseFn.apply(z, self.projection_softmax.W, self.projection_softmax.b, ACT["none"], self.net)
         return _as_view(out), _as_view(skip)
 
     def _forward(self, x):
@@ -513,10 +513,10 @@ class ResidualConvLayer(object):
             z = torch.empty((B, T, self.cd), device=taps.device, dtype=torch.float32)
             check(_lib.lib().wn_layer_fwd(ptr(taps), ptr(self.wf.W), ptr(self.wf.b), ptr(self.wg.W), ptr(self.wg.b),
                                           ptr(self.projection_block.W), ptr(self.projection_block.b), ptr(out),
-                                          ptr(z), None, None, B, T, Cr, self.cd, fw, 1, 0, stream_ptr()),
-                  "wn_layer_fwd")
+                                          ptr(z), None, None, B, T, Cr, self.cd, fw, 1, 0, self.net._exec(B),
+                                          stream_ptr()), "wn_layer_fwd")
             skip = _PointwiseFn.apply(z[:, -1:, :], self.projection_softmax.W, self.projection_softmax.b,
-                                      ACT["none"], None)
+                                      ACT["none"], self.net)
         return _as_view(out[:, -1:, :]), _as_view(skip)
 
 
@@ -536,6 +536,8 @@ class WaveNet(object):
             raise Exception("storage must be 'fp32' or 'bf16'")
         self.params = params
         self.storage = storage
+        self.gemm_precision = None          # None: the module default (wavenet_amd.set_gemm_precision) at call time
+        self._scratch, self._scratch_keep = {}, []
         self._pack16 = None
         self._w16_stale = True
         self.compat_zero_prefix = compat_zero_prefix
@@ -657,6 +659,27 @@ class WaveNet(object):
 
     def _weights_changed(self):
         self._w16_stale = True
+
+    def _exec(self, B: int = 8):
+        """WnExec for a library call on the current stream: this model's GEMM precision (``self.gemm_precision``, or the
+        module default) and a scratch buffer owned by (model, stream).  Buffers are never freed or moved once handed out
+        -- a captured graph keeps the pointer -- a larger batch gets a new, larger one."""
+        lib = _lib.lib()
+        key = (stream_ptr() or 0, self._arena.device.index)
+        ent = self._scratch.get(key)
+        if ent is None or ent[1] < B:
+            p = self.params
+            hc = int_array(p.softmax_conv_channels)
+            nbytes = lib.wn_exec_workspace_bytes(self._stack_desc(), p.quantization_steps, p.causal_conv_channels[0],
+                                                 p.causal_conv_filter_width, hc, len(p.softmax_conv_channels), max(B, 8), 0)
+            buf = torch.empty((nbytes,), device=self._arena.device, dtype=torch.uint8)
+            self._scratch_keep.append(buf)
+            ent = (buf, max(B, 8))
+            self._scratch[key] = ent
+        ex = _lib.WnExec()
+        ex.precision = _lib.GEMM_PRECISIONS.index(self.gemm_precision or _lib.get_gemm_precision())
+        ex.ws, ex.ws_bytes = ent[0].data_ptr(), ent[0].numel()
+        return C.byref(ex)
 
     def _pack16_if_stale(self):
         """bf16 operand images of the current weights (one pack per optimiser step; captured with the step in a graph)."""
@@ -833,14 +856,14 @@ class WaveNet(object):
             if x.is_floating_point() or x.dim() != 2 or len(layers) != 1:
                 raise Exception("storage='bf16' takes integer (B, T) tokens and one causal layer")
             l0 = layers[0]
-            out = _Embed16Fn.apply(x.to(torch.int32).contiguous(), l0.W, l0.b, l0.filter_width, self._hook)
+            out = _Embed16Fn.apply(x.to(torch.int32).contiguous(), l0.W, l0.b, l0.filter_width, self)
             self._last_causal_outputs = [out]
             return _as_view(out)
         if not x.is_floating_point():
             if x.dim() != 2:
                 raise Exception("integer input must be (B, T) tokens")
             l0 = layers[0]
-            out = _EmbedFn.apply(x.to(torch.int32).contiguous(), l0.W, l0.b, l0.filter_width, self._hook)
+            out = _EmbedFn.apply(x.to(torch.int32).contiguous(), l0.W, l0.b, l0.filter_width, self)
             start = 1
         else:
             out = _to_btc(x.to(torch.float32))
@@ -882,7 +905,7 @@ class WaveNet(object):
                 out = _SoftmaxFn.apply(out)
             return _as_view(out)
         for lay in self.softmax_conv_layers:
-            out = _PointwiseFn.apply(out, lay.W, lay.b, act, self._hook)
+            out = _PointwiseFn.apply(out, lay.W, lay.b, act, self)
         if apply_softmax:
             out = _SoftmaxFn.apply(out)
         return _as_view(out)
@@ -907,7 +930,7 @@ class WaveNet(object):
         check(_lib.lib().wn_skip_sum_fwd(
             len(L), ptr_array(zs), ptr_array([lay.projection_softmax.W for lay in L]),
             ptr_array([lay.projection_softmax.b for lay in L]), int_array([lay.cd for lay in L]), ptr(skip), B, T,
-            t_off, Tw, self._Cs, 0, stream_ptr()), "wn_skip_sum_fwd")
+            t_off, Tw, self._Cs, 0, self._exec(B), stream_ptr()), "wn_skip_sum_fwd")
 
     # -- checkpoints (wavenet.py:619-639): reference key names, .npz container (h5py is absent) --
     def save(self, model_dir="./"):
