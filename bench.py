@@ -126,7 +126,7 @@ def cpu_baseline(budget_s=25.0):
     fast decode (faster_wavenet.py:50-113 restated: caches rolled every step)."""
     from oracle import wavenet_ref as R
     from oracle import data_ref as D
-    cores = min(os.cpu_count() or 1, 16)          # small convs stop scaling past ~16 threads
+    cores = os.cpu_count() or 1                   # every host core (SURVEY 8d); the count is part of the line
     torch.set_num_threads(cores)
     p = R.make_params(**{k: v for k, v in CFG2.items() if k != "sampling_rate"})
     w = R.init_weights(p, 1234)
@@ -137,9 +137,9 @@ def cpu_baseline(budget_s=25.0):
     t0 = time.perf_counter()
     R.train_step_grads(p, w, tok[:, :Tp], tok[:, iw + 1:Tp + 1])            # warm-up + pilot
     pilot = (time.perf_counter() - t0) / Tp
-    Tc = int(min(T, max(iw + 1024, budget_s * 0.3 / max(pilot, 1e-9))))
+    Tc = int(min(T, max(iw + 1024, budget_s * 0.2 / max(pilot, 1e-9))))
     x, tgt = tok[:, :Tc], tok[:, iw + 1:Tc + 1]
-    reps, ts = 2, []
+    reps, ts = 3, []
     for _ in range(reps):
         t0 = time.perf_counter()
         R.train_step_grads(p, w, x, tgt)
@@ -155,7 +155,7 @@ def cpu_baseline(budget_s=25.0):
         fast._forward_one_step(D.onehot_pixel_image(buf.reshape(1, -1), 256))
         n += 1
     dec_sps = n / (time.perf_counter() - t0)
-    return {"value": train_sps, "unit": "samples/s", "cores": cores, "kind": "port",
+    return {"value": train_sps, "unit": "samples/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": "oracle literal restatement (Chainer-equivalent op sequence, not Chainer), torch-CPU fp32, "
                       "%d threads: train fwd+bwd cfg2 topology B=1 x T=%d, median of %d steps; "
                       "fast decode %d steps at W=4094" % (cores, Tc, reps, n),
@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--no-decode", action="store_true")
     ap.add_argument("--no-wide", action="store_true", help="skip the config-5 (128/512 channels, bf16 operands) side measurement")
     ap.add_argument("--no-graph", action="store_true", help="time op-by-op launches instead of hipGraph replays")
+    ap.add_argument("--wide-only", action="store_true", help="only the config-5 side measurement (profiling passes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -193,6 +194,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # "nccl" is RCCL on ROCm
         barrier = dist.barrier
 
+    if args.wide_only:
+        print(json.dumps({"wide_channel": wide_channel_step(rank, world, steps=args.steps, warmup=args.warmup)}))
+        return
     p = Params(CFG2)
     net = FasterWaveNet(p, seed=1234)
     net.to_gpu()
@@ -237,6 +241,7 @@ def main():
         barrier()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    local_dt = dt
     if world > 1:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -293,8 +298,20 @@ def main():
             "frac_of_hbm_8TBps": nl * alg_bytes_layer / (stack_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "TFLOPs": nl * alg_flops_layer / (stack_ms * 1e-3) / 1e12,
             "note": "algorithmic bytes = SURVEY 8(d)'s 2,304 B per sample-layer, which include the per-layer skip "
-                    "read-modify-write; the deferred skip sum does not move those bytes, so the fraction can exceed 1",
+                    "read-modify-write; the deferred skip sum does not move those bytes, so frac_of_hbm_8TBps can exceed 1: "
+                    "layer_traffic_frac is the layer kernel's measured HBM bytes / its time / 8 TB/s",
         }
+        tfile = next((f for f in (os.path.join(ROOT, "profiles", "r2_hbm_traffic.json"),
+                                  os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) if os.path.exists(f)), None)
+        pmc = json.load(open(tfile))["kernels"] if tfile else {}
+
+        def pmc_bytes(names):
+            got = [pmc[k]["hbm_bytes_per_launch"] for k in names if k in pmc]
+            return float(sum(got)) if got else None
+        fb = pmc_bytes(["wn::k_layer_fwd_mfma32_t1<0, false>", "wn::k_layer_fwd_mfma32_t1<false, false>"])
+        if fb:
+            out["stack_forward"]["layer_traffic_bytes"] = fb
+            out["stack_forward"]["layer_traffic_frac"] = fb / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         # ---- roofline of the dominant unit of the TIMED REGION (the training step) -------------------
         # Units = the library's per-op entry points; times are HIP-event means over the timed steps.
         # Algorithmic bytes / flops are SURVEY.md section 8(d)'s per-sample-layer figures x the
@@ -307,8 +324,9 @@ def main():
         units = {
             # name: (bound, algorithmic amount per launch, launches per step, kernels for PMC traffic)
             "wn_layer_bwd": ("hbm", es * (3 * Cr + Cs + 2 * Cd) * n_col, nl,
-                             ["wn::k_layer_bwd_chainsp<true, true, true>"]),
-            "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl, ["wn::k_layer_fwd_mfma32_t1<true, false>"]),
+                             ["wn::k_layer_bwd_chainsp<true, true, true, true>", "wn::k_layer_bwd_chainsp<true, true, true>"]),
+            "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl,
+                             ["wn::k_layer_fwd_mfma32_t1<2, false>", "wn::k_layer_fwd_mfma32_t1<true, false>"]),
             "wn_skip_sum_fwd": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<0, 0, false, 4>"]),
             "wn_skip_sum_bwd_dw": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_wgrad_b3w<false, 0, false>"]),
             "wn_skip_sum_bwd_dz": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<2, 0, false, 4>"]),
@@ -317,18 +335,24 @@ def main():
         bound, amount, launches, knames = units[dom]
         launch_ms = per_step[dom] / launches
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")
-        if os.path.exists(tf):
-            kk = json.load(open(tf))["kernels"]
-            got = [kk[k]["hbm_bytes_per_launch"] for k in knames if k in kk]
-            traffic = float(sum(got)) if got else None
+        for kn in knames:                                   # first name the PMC summary knows (names change with templates)
+            if kn in pmc:
+                traffic = float(pmc[kn]["hbm_bytes_per_launch"])
+                break
+        # flops one launch of the dominant unit really executes (fp32 MFMA in the layer kernels)
+        layer_flops = {"wn_layer_bwd": 2 * 2 * (2 * 2 * Cr * Cd + Cd * Cr) * n_col, "wn_layer_fwd": 2 * (2 * 2 * Cr * Cd + Cd * Cr) * n_col}
         if bound == "hbm":
             ach = amount / (launch_ms * 1e-3) / 1e9
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": launch_ms,
                                "algorithmic_bytes_per_launch": amount,
-                               "note": "algorithmic bytes per SURVEY 8(d) (include the per-layer skip traffic the deferred "
-                                       "skip sum avoids); traffic = measured HBM bytes per launch"}
+                               "traffic_frac": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                               "mfma_frac": layer_flops.get(dom, 0) / (launch_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                               "note": "frac: SURVEY 8(d)'s algorithmic bytes (1,664 B per sample-layer for the backward, "
+                                       "1,024 B of them the per-layer dskip read that the deferred skip sum never "
+                                       "performs) / launch time / 8 TB/s; traffic_frac: HBM bytes MEASURED by the PMC "
+                                       "passes in profiles/ / launch time / 8 TB/s; mfma_frac: fp32 MFMA flops of the "
+                                       "launch / time / 157.3 TFLOP/s"}
         else:
             ach = amount / (launch_ms * 1e-3) / 1e12
             peak = F32_MFMA_PEAK_TF if os.environ.get("WAVENET_HIP_GEMM") == "fp32" else BF16X3_PEAK_TF
@@ -340,8 +364,16 @@ def main():
                              for k in units if units[k][0] == "mfma" and k in per_step}
         # ---- AR decode, config 4: 16k samples on one GPU, persistent per-layer state -----------
         if not args.no_decode:
+            # decode with the seeded initial weights (not the ones the timed steps just trained), so that the first 256
+            # tokens can be held against the committed oracle trace tests/golden/cfg4_decode_trace.npz
             n = args.decode_samples
             u = np.random.RandomState(7).random_sample(n)
+            gold = None
+            gf = os.path.join(ROOT, "tests", "golden", "cfg4_decode_trace.npz")
+            if os.path.exists(gf) and n >= 256:
+                gold = np.load(gf)
+                u[:256] = gold["uniforms"]
+            net.load_state_dict(FasterWaveNet(p, seed=1234).state_dict())
             net.generate(64, u)                                           # warm-up (creates the handle)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -351,6 +383,10 @@ def main():
             out["ar_generate"] = {"samples_per_s": n / ddt, "seconds": ddt, "samples": n,
                                   "workload": "cfg4: faster_wavenet queue-cached decode, window 4094, 1 GPU",
                                   "token_checksum": int(toks.sum().item())}
+            if gold is not None:
+                first = toks[:256].cpu().numpy()
+                out["ar_generate"]["golden_first_256_tokens_match"] = bool(np.array_equal(first, gold["tokens"].astype(np.int32)))
+                out["ar_generate"]["golden_first_256_checksum"] = [int(first.sum()), int(gold["tokens"].astype(np.int64).sum())]
         if not args.no_wide:
             out["wide_channel"] = wide_channel_step(rank, world)
         if not args.no_cpu_baseline:
@@ -358,6 +394,14 @@ def main():
             if "ar_generate" in out:
                 out["ar_generate"]["vs_cpu_baseline"] = out["ar_generate"]["samples_per_s"] / \
                     out["cpu_baseline"]["decode_value"]
+    if world > 1:
+        # what every rank actually ran, so that a scaling record can be trusted at first sight
+        forms = [None] * world
+        dist.all_gather_object(forms, {"rank": rank, "device": torch.cuda.current_device(), "launch": out["launch"],
+                                       "ms_per_step_local": local_dt * 1e3})
+        out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": forms,
+                       "collective": "one all-reduce(SUM) of the flat fp32 gradient arena per step (%d floats)"
+                                     % net._grad_arena.numel()}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

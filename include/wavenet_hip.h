@@ -158,6 +158,9 @@ typedef struct WnStackDesc {
  * output): columns that cannot influence skip[t_off:] -- further below t_off than the layers above a layer
  * reach -- are not computed; xs / z / f / g are left untouched there and wn_stack_bwd must then be called
  * with dout == NULL.  Loss and gradients are unchanged.                                              */
+/* 1 if wn_stack_bwd needs tanh saved (f); 0 if every layer runs on the fused 32-channel kernels without conv / projection
+ * biases: then f may be NULL in both calls (only z and sigmoid are kept; tanh = z / sigmoid is recovered by the backward). */
+int wn_stack_saves_tanh(const WnStackDesc* d);
 int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, float* f, float* g,
                  float* skip, int B, int T, int t_off, int compat_zero_prefix, int window_only, const WnExec* ex, void* stream);
 size_t wn_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T);
@@ -176,11 +179,13 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
 
 /* ---- softmax over the channel axis (wavenet.py:592) and A14 (wavenet.py:597-617) ------------ */
 int wn_softmax_fwd(const float* logits, float* prob, int N, int Q, void* stream);
-/* row_loss[n] = -log softmax(logits[n])[target[n]]; *loss = mean(row_loss) (device scalar);
- * dlogits (may be NULL) = (softmax - onehot) / N.  Rows are b*Tw + t, as after the reference's
- * transpose(0,3,2,1) + reshape.  target < 0 or >= Q -> WN_EARG is NOT checked on device.        */
-int wn_softmax_xent(const float* logits, const int32_t* target, float* loss, float* dlogits,
-                    int N, int Q, void* stream);
+/* *loss (device scalar) = sum over rows of -log softmax(logits[n])[target[n]] / n_norm; dlogits (may be NULL) =
+ * (softmax - onehot) / n_norm.  Rows are b*Tw + t, as after the reference's transpose(0,3,2,1) + reshape.  A row whose
+ * target is -1 is ignored (no loss, zero gradient) as chainer.functions.softmax_cross_entropy does; so is any other target
+ * outside [0, Q) -- nothing is read out of bounds.  n_norm = the number of rows that count (Chainer: labels != -1);
+ * n_norm <= 0 means N.                                                                                            */
+int wn_softmax_xent(const float* logits, const int32_t* target, float* loss, float* dlogits, int N, int Q,
+                    int64_t n_norm, void* stream);
 
 /* x[i] *= *scale_dev (a device scalar), and nothing at all when *scale_dev == 1: the backward of the loss node
  * (chainer's softmax_cross_entropy backward multiplies by the upstream gradient, which is 1 for `loss.backward()`).  */

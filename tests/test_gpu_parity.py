@@ -885,7 +885,7 @@ def test_c_abi_rejects_bad_arguments_without_touching_memory():
         assert lib.wn_pointwise_fwd(ptr(xw), ptr(Ww), None, ptr(ow), 64, 64, 64, 0, None, None) == -1
         assert b"WnExec scratch" in lib.wn_last_error()
     with pytest.raises(_lib.WaveNetHipError):
-        check(lib.wn_softmax_xent(None, None, None, None, 4, 4, None), "wn_softmax_xent")
+        check(lib.wn_softmax_xent(None, None, None, None, 4, 4, 0, None), "wn_softmax_xent")
 
 
 @pytest.mark.parametrize("B,T", [(1, 1), (1, 2), (3, 5), (2, 33), (1, 513)])
@@ -1212,3 +1212,31 @@ def test_models_of_different_gemm_precision_interleave_in_one_process_under_grap
     np.testing.assert_allclose(g32, a32, atol=3e-5)
     np.testing.assert_allclose(g16, a16, atol=3e-5)
     assert np.abs(a32 - a16).max() > 1e-4                 # and the two precisions really are different arithmetic
+
+
+@pytest.mark.gpu
+def test_cross_entropy_ignores_label_minus_one_like_chainer_and_rejects_other_bad_labels():
+    """chainer.functions.softmax_cross_entropy(ignore_label=-1, normalize=True), the call at wavenet.py:616: ignored rows
+    carry no loss and no gradient and do not count in the mean; any other label outside [0, Q) is a caller error."""
+    p, w, net = build(CFG1)
+    B, Tw, Q = 2, 37, 256
+    rs = np.random.RandomState(3)
+    logits = rs.standard_normal((B, Q, 1, Tw)).astype(np.float32)
+    tgt = rs.randint(0, Q, (B, Tw)).astype(np.int32)
+    tgt[0, 3] = tgt[1, 0] = tgt[1, 36] = -1
+    lt = dev(logits).requires_grad_(True)
+    loss = net.cross_entropy(lt, tgt)
+    loss.backward()
+    x = torch.tensor(logits[:, :, 0, :].transpose(0, 2, 1).reshape(B * Tw, Q), requires_grad=True)
+    ref = torch.nn.functional.cross_entropy(x, torch.tensor(tgt.reshape(-1).astype(np.int64)), ignore_index=-1)
+    ref.backward()
+    assert abs(float(loss.detach()) - float(ref)) < 1e-5
+    got = to_np(lt.grad)[:, :, 0, :].transpose(0, 2, 1).reshape(B * Tw, Q)
+    np.testing.assert_allclose(got, x.grad.numpy(), atol=1e-7)
+    assert np.abs(got[3]).max() == 0 and np.abs(got[Tw]).max() == 0
+    bad = tgt.copy(); bad[0, 0] = Q
+    with pytest.raises(Exception, match="labels"):
+        net.cross_entropy(dev(logits), bad)
+    # a device-resident target is trusted for its range but still cannot make the kernel read out of bounds
+    l2 = net.cross_entropy(dev(logits), dev(bad))
+    assert np.isfinite(float(l2))

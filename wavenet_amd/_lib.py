@@ -68,11 +68,12 @@ _SIGS = {
     "wn_skip_sum_bwd_dz": (_i, [_i, _pp, _ip, _p, _pp, _i, _i, _i, _i, _i, _ex, _p]),
     "wn_skip_sum_bwd_dw": (_i, [_i, _pp, _ip, _p, _pp, _pp, _i, _i, _i, _i, _i, _ex, _p]),
     "wn_stack_fwd": (_i, [C.POINTER(WnStackDesc), _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _ex, _p]),
+    "wn_stack_saves_tanh": (_i, [C.POINTER(WnStackDesc)]),
     "wn_stack_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(WnStackDesc), _i, _i]),
     "wn_stack_bwd": (_i, [C.POINTER(WnStackDesc)] + [_p] * 8 + [_pp] * 8 + [_p, C.c_size_t, _i, _i, _i, _i, _ex, _p]),
     "wn_exec_workspace_bytes": (C.c_size_t, [C.POINTER(WnStackDesc), _i, _i, _i, _ip, _i, _i, _i]),
     "wn_softmax_fwd": (_i, [_p, _p, _i, _i, _p]),
-    "wn_softmax_xent": (_i, [_p, _p, _p, _p, _i, _i, _p]),
+    "wn_softmax_xent": (_i, [_p, _p, _p, _p, _i, _i, _i64, _p]),
     "wn_nchw_to_btc": (_i, [_p, _p, _i, _i, _i, _p]),
     "wn_btc_to_nchw": (_i, [_p, _p, _i, _i, _i, _p]),
     "wn_decoder_create": (_i, [_pp, C.POINTER(WnDecoderDesc), _p]),

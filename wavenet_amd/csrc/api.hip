@@ -237,10 +237,10 @@ int wn_softmax_fwd(const float* logits, float* prob, int N, int Q, void* stream)
 }
 
 int wn_softmax_xent(const float* logits, const int32_t* target, float* loss, float* dlogits, int N, int Q,
-                    void* stream) {
+                    int64_t n_norm, void* stream) {
     wn::ProfScope prof__("wn_softmax_xent", stream);
     NN(logits); NN(target); NN(loss); POS(N); POS(Q);
-    return generic_softmax_xent(logits, target, loss, dlogits, N, Q, as_stream(stream));
+    return generic_softmax_xent(logits, target, loss, dlogits, N, Q, n_norm, as_stream(stream));
 }
 
 int wn_nchw_to_btc(const float* src, float* dst, int B, int C, int T, void* stream) {

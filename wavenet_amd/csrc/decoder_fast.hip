@@ -163,8 +163,24 @@ __device__ __forceinline__ float bcast(float v, int k) {       // lane k's value
 
 // The chain wave: one residual layer of one step.  xc = x_l[n] (channel lane % 32, valid in every lane); returns
 // x_{l+1}[n].  Writes z to zall[l] and x_{l+1}[n] to xcur[l+1] (for the ring update), then publishes the layer.
+// Hand-off protocol between the waves of the ONE workgroup of this kernel (all on one CU, all through LDS):
+//   producer: data ds_writes ... counter ds_write, in that order in ITS instruction stream;
+//   consumer: counter ds_read (spin) ... data ds_reads, in that order in its stream.
+// What makes this sufficient is a property of the hardware, not of the HSA memory model: a CU has ONE LDS pipeline
+// that executes the DS instructions of all its waves in the order they were issued, and a wave's DS instructions issue
+// in program order -- so the data writes are in the array before the counter write is, and a read issued after the
+// counter read that saw the new value is served after both.  The fences below are therefore wavefront-scope: they only
+// stop the COMPILER from moving DS accesses across the counter access (a workgroup-scope release would add an
+// s_waitcnt lgkmcnt(0) on the 40-layer critical path for an ordering the pipeline already gives).  gfx950-specific by
+// construction, like everything else in this file; the 256-step golden trace of config 4
+// (tests/test_gpu_baseline_configs.py) and the 16,000-step bench run would show a reordering as a token mismatch.
+// The spin is bounded: a lost hand-off traps (kernel abort, reported by the next HIP call) instead of hanging the GPU.
 __device__ __forceinline__ void wait_count(const int* c, int v) {               // *c >= v, then an acquire at compile level
-    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) __builtin_amdgcn_s_sleep(1);
+    int spins = 0;
+    while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < v) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 24)) __builtin_trap();
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // wave 1: the x[n-d] half of gate row `lane` of layer l -> aold[l][lane]

@@ -529,7 +529,7 @@ __global__ void k_softmax(const float* __restrict__ logits, float* __restrict__ 
 }
 
 __global__ void k_softmax_xent(const float* __restrict__ logits, const int32_t* __restrict__ target,
-                               float* __restrict__ loss, float* __restrict__ dlogits, long long N, int Q) {
+                               float* __restrict__ loss, float* __restrict__ dlogits, long long N, int Q, long long n_norm) {
     // one wave per row; rows of up to 256 logits live in registers (one float4 per lane).  Waves stride
     // over rows so that the loss leaves with ONE atomic per block: thousands of adds to one address
     // would serialise at ~13 ns each.
@@ -541,7 +541,14 @@ __global__ void k_softmax_xent(const float* __restrict__ logits, const int32_t* 
         float rl = 0.f;
         const float* r = logits + row * Q;
         const int tg = target[row];
-        const float invN = 1.f / (float)N;
+        const float invN = 1.f / (float)n_norm;
+        if (tg < 0 || tg >= Q) {
+            // Chainer's softmax_cross_entropy ignores label -1 (no loss, no gradient, not counted in the mean: n_norm); any
+            // other label outside [0, Q) is treated the same way here instead of reading out of bounds
+            if (dlogits)
+                for (int q = lane; q < Q; q += 64) dlogits[row * Q + q] = 0.f;
+            continue;
+        }
         if (Q <= 256 && (Q & 3) == 0) {
             const bool on = 4 * lane < Q;
             float4 v = on ? *reinterpret_cast<const float4*>(r + 4 * lane) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
@@ -580,7 +587,7 @@ __global__ void k_softmax_xent(const float* __restrict__ logits, const int32_t* 
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int w = 0; w < (int)(blockDim.x / 64); ++w) s += part[w];
-        atomicAdd(loss, s / (float)N);
+        atomicAdd(loss, s / (float)n_norm);
     }
 }
 
@@ -1010,11 +1017,12 @@ int generic_softmax(const float* logits, float* prob, long long N, int Q, hipStr
 }
 
 int generic_softmax_xent(const float* logits, const int32_t* target, float* loss, float* dlogits, long long N,
-                         int Q, hipStream_t s) {
+                         int Q, long long n_norm, hipStream_t s) {
     WN_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
     int blocks = cdiv(N, 4);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_softmax_xent, dim3(blocks), dim3(256), 0, s, logits, target, loss, dlogits, N, Q);
+    hipLaunchKernelGGL(k_softmax_xent, dim3(blocks), dim3(256), 0, s, logits, target, loss, dlogits, N, Q,
+                       n_norm > 0 ? n_norm : N);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

@@ -30,7 +30,7 @@ __device__ __forceinline__ int ch_of(int s, int h) { return (s & 3) + 8 * (s >> 
 static constexpr int kWRow = 66;     // LDS row stride of W[i][.][.] (64 floats + 2: rows land on different banks)
 static constexpr int kPRow = 33;     // LDS row stride of Wp[i][.]
 
-template <bool SAVE_FG, bool HAS_BIAS>
+template <int SAVE, bool HAS_BIAS>
 __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
     const float* __restrict__ x, const float* __restrict__ Wf, const float* __restrict__ bf,
     const float* __restrict__ Wg, const float* __restrict__ bg, const float* __restrict__ Wp,
@@ -168,12 +168,12 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
                     make_float4(ao[4 * q], ao[4 * q + 1], ao[4 * q + 2], ao[4 * q + 3]);
                 *reinterpret_cast<float4*>(zout + row + 8 * q) =
                     make_float4(zz[4 * q], zz[4 * q + 1], zz[4 * q + 2], zz[4 * q + 3]);
-                if (SAVE_FG) {
+                if (SAVE == 1)
                     *reinterpret_cast<float4*>(fout + row + 8 * q) =
                         make_float4(ff[4 * q], ff[4 * q + 1], ff[4 * q + 2], ff[4 * q + 3]);
+                if (SAVE >= 1)
                     *reinterpret_cast<float4*>(gout + row + 8 * q) =
                         make_float4(gg[4 * q], gg[4 * q + 1], gg[4 * q + 2], gg[4 * q + 3]);
-                }
             }
         }
         if (more) {
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void k_layer_fwd_mfma32(
 // others instead of under one sibling's.  No tile loop, no prefetch, no tile-count quantisation: a workgroup is four
 // consecutive tiles.
 // ---------------------------------------------------------------------------------------------
-template <bool SAVE_FG, bool HAS_BIAS>
+template <int SAVE, bool HAS_BIAS>
 __global__ __launch_bounds__(256, 4) void k_layer_fwd_mfma32_t1(
     const float* __restrict__ x, const float* __restrict__ Wf, const float* __restrict__ bf,
     const float* __restrict__ Wg, const float* __restrict__ bg, const float* __restrict__ Wp,
@@ -282,10 +282,8 @@ __global__ __launch_bounds__(256, 4) void k_layer_fwd_mfma32_t1(
             zz[r] = f4[m] * g4[m];
         }
         if (valid) {                                 // f, g and z leave as soon as they exist: registers stay under 128
-            if (SAVE_FG) {
-                *reinterpret_cast<float4*>(fout + row + 8 * q) = make_float4(f4[0], f4[1], f4[2], f4[3]);
-                *reinterpret_cast<float4*>(gout + row + 8 * q) = make_float4(g4[0], g4[1], g4[2], g4[3]);
-            }
+            if (SAVE == 1) *reinterpret_cast<float4*>(fout + row + 8 * q) = make_float4(f4[0], f4[1], f4[2], f4[3]);
+            if (SAVE >= 1) *reinterpret_cast<float4*>(gout + row + 8 * q) = make_float4(g4[0], g4[1], g4[2], g4[3]);
             *reinterpret_cast<float4*>(zout + row + 8 * q) = make_float4(zz[4 * q], zz[4 * q + 1], zz[4 * q + 2], zz[4 * q + 3]);
         }
     }
@@ -304,6 +302,8 @@ __global__ __launch_bounds__(256, 4) void k_layer_fwd_mfma32_t1(
 
 bool mfma_layer_supported(int Cr, int Cd, int fw) { return Cr == 32 && Cd == 32 && fw == 2; }
 
+// fs / gs: where tanh / sigmoid are saved for the backward: both (any backward), gs only (the chained stack backward,
+// which recovers tanh = z / sigmoid), or neither (inference)
 int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg,
                    const float* Wp, const float* bp, float* out, float* z, float* fs, float* gs, int B, int T,
                    int d, int Z, int t_live, hipStream_t s) {
@@ -323,10 +323,12 @@ int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float
 #define FWD1_LAUNCH(SAVE, BIAS)                                                                              \
     hipLaunchKernelGGL((k_layer_fwd_mfma32_t1<SAVE, BIAS>), dim3(blocks), dim3(256), 0, s, x, Wf, bf, Wg, bg, Wp, bp, \
                        out, z, fs, gs, B, T, d, Z, tile_lo, tiles_per_b, ntiles)
-        if (fs && hb) FWD1_LAUNCH(true, true);
-        else if (fs) FWD1_LAUNCH(true, false);
-        else if (hb) FWD1_LAUNCH(false, true);
-        else FWD1_LAUNCH(false, false);
+        if (fs && hb) FWD1_LAUNCH(1, true);
+        else if (fs) FWD1_LAUNCH(1, false);
+        else if (gs && hb) FWD1_LAUNCH(2, true);
+        else if (gs) FWD1_LAUNCH(2, false);
+        else if (hb) FWD1_LAUNCH(0, true);
+        else FWD1_LAUNCH(0, false);
 #undef FWD1_LAUNCH
         WN_LAUNCH_CHECK();
         return WN_OK;
@@ -335,10 +337,12 @@ int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float
 #define FWD_LAUNCH(SAVE, BIAS)                                                                               \
     hipLaunchKernelGGL((k_layer_fwd_mfma32<SAVE, BIAS>), dim3(blocks), dim3(256), 0, s, x, Wf, bf, Wg, bg, Wp, bp, \
                        out, z, fs, gs, B, T, d, Z, tile_lo, tiles_per_b, ntiles)
-    if (fs && hb) FWD_LAUNCH(true, true);
-    else if (fs) FWD_LAUNCH(true, false);
-    else if (hb) FWD_LAUNCH(false, true);
-    else FWD_LAUNCH(false, false);
+    if (fs && hb) FWD_LAUNCH(1, true);
+    else if (fs) FWD_LAUNCH(1, false);
+    else if (gs && hb) FWD_LAUNCH(2, true);
+    else if (gs) FWD_LAUNCH(2, false);
+    else if (hb) FWD_LAUNCH(0, true);
+    else FWD_LAUNCH(0, false);
 #undef FWD_LAUNCH
     WN_LAUNCH_CHECK();
     return WN_OK;

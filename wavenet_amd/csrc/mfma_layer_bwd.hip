@@ -211,7 +211,9 @@ static constexpr int kCMaxBlocks = 256;
 // Tile order: workgroups are dealt to the 8 XCDs round-robin, so XCD k = blockIdx % 8 gets the k-th contiguous eighth
 // of the tiles (x[t-d] and U[t+dU] of a tile are rows a neighbouring CU of the same XCD fetches in the same round).
 // ---------------------------------------------------------------------------------------------
-template <bool HAS_DO, bool HAS_U, bool HAS_DZ>
+// FROM_Z: the forward saved z and sigmoid only; `f` points at z and tanh is recovered as z / sigmoid (z = tanh * sigmoid was
+// rounded once in fp32, so the quotient is tanh to ~1.2e-7 relative; where sigmoid underflowed, da and dg are 0 anyway).
+template <bool HAS_DO, bool HAS_U, bool HAS_DZ, bool FROM_Z>
 __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
     const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
@@ -368,9 +370,14 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float dz = live ? acc[r] : 0.f;
+            if (FROM_Z) {
+                zz[r] = ff[r];                                            // the slot held z
+                ff[r] = gg[r] > 1e-30f ? zz[r] * __builtin_amdgcn_rcpf(gg[r]) : 0.f;
+            } else {
+                zz[r] = ff[r] * gg[r];
+            }
             da[r] = dz * gg[r] * (1.f - ff[r] * ff[r]);
             dg[r] = dz * ff[r] * gg[r] * (1.f - gg[r]);
-            zz[r] = ff[r] * gg[r];
         }
         f32x16 v1, u0;
 #pragma unroll
@@ -727,7 +734,7 @@ size_t mfma_layer_bwd_extra_ws_floats() { return (size_t)kMaxBlocks * kPartFloat
 int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
                          const float* Wp, const float* Vin, const float* Uin, int dU, int vu_t0, const float* dzs,
                          int dz_t0, float* Vout, float* Uout, float* part, int B, int T, int d, int Z, int t_live,
-                         int* nwg, hipStream_t s) {
+                         int* nwg, hipStream_t s, bool from_z) {
     const int tiles_all = (T + 31) / 32;
     const int tile_lo = t_live > 0 ? t_live / 32 : 0;
     const int tiles_per_b = tiles_all - tile_lo;
@@ -739,17 +746,22 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
     int blocks = (ntiles + kCWaves - 1) / kCWaves;
     if (blocks > kCMaxBlocks) blocks = kCMaxBlocks;
     if (nwg) *nwg = blocks;
-#define CH_LAUNCH(DO, UU, DZ)                                                                                      \
+#define CH_LAUNCH2(DO, UU, DZ, FZ)                                                                                 \
     do {                                                                                                           \
         static bool attr_set = false;                                                                              \
         if (!attr_set) {                                                                                           \
-            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chainsp<DO, UU, DZ>),             \
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chainsp<DO, UU, DZ, FZ>),         \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kCLdsBytes));                   \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL((k_layer_bwd_chainsp<DO, UU, DZ>), dim3(blocks), dim3(64 * kCWaves), kCLdsBytes, s, x, f, g, \
-                           Wp, Wf, Wg, Vin, Uin, dU, vu_t0, dzs, dz_t0, Vout, Uout, part, B, T, d, Z, tile_lo,     \
+        hipLaunchKernelGGL((k_layer_bwd_chainsp<DO, UU, DZ, FZ>), dim3(blocks), dim3(64 * kCWaves), kCLdsBytes, s, x, f, \
+                           g, Wp, Wf, Wg, Vin, Uin, dU, vu_t0, dzs, dz_t0, Vout, Uout, part, B, T, d, Z, tile_lo,  \
                            tiles_per_b, ntiles);                                                                   \
+    } while (0)
+#define CH_LAUNCH(DO, UU, DZ)                                 \
+    do {                                                      \
+        if (from_z) CH_LAUNCH2(DO, UU, DZ, true);             \
+        else CH_LAUNCH2(DO, UU, DZ, false);                   \
     } while (0)
     const int key = (Vin ? 4 : 0) | (Uin ? 2 : 0) | (dzs ? 1 : 0);
     switch (key) {
@@ -762,6 +774,7 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
         default: CH_LAUNCH(false, false, true); break;
     }
 #undef CH_LAUNCH
+#undef CH_LAUNCH2
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

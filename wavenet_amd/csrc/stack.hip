@@ -15,6 +15,14 @@ static int zero_prefix(int T, int d, int fw) {           // wavenet.py:303-340
     int z = (fw - 1) * d - pad;
     return z > 0 ? z : 0;
 }
+// every layer on the fused 32-channel kernels and no conv / projection bias: the stack backward takes the chained path, which
+// reads z and sigmoid only (tanh = z / sigmoid)
+static bool chain_capable(const WnStackDesc* d) {
+    for (int l = 0; l < d->n_layers; ++l)
+        if (!wn_layer_fast_path(d->Cr, d->cd[l], d->fw) || (d->bf && d->bf[l]) || (d->bg && d->bg[l]) || (d->bp && d->bp[l]))
+            return false;
+    return true;
+}
 static int check_desc(const WnStackDesc* d) {
     WN_CHECK_ARG(d, "stack: desc is NULL");
     WN_CHECK_ARG(d->n_layers > 0 && d->Cr > 0 && d->Cs > 0 && d->fw > 0, "stack: non-positive size");
@@ -26,6 +34,8 @@ static int check_desc(const WnStackDesc* d) {
 using namespace wn;
 
 extern "C" {
+
+int wn_stack_saves_tanh(const WnStackDesc* d) { return (check_desc(d) == WN_OK && chain_capable(d)) ? 0 : 1; }
 
 size_t wn_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T) {
     if (!d || B <= 0 || T <= 0) return 0;
@@ -52,7 +62,9 @@ int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, floa
     int rc = check_desc(d);
     if (rc) return rc;
     WN_CHECK_ARG(x && xs && z && B > 0 && T > 0, "wn_stack_fwd: bad argument");
-    WN_CHECK_ARG((f == nullptr) == (g == nullptr), "wn_stack_fwd: f and g go together");
+    WN_CHECK_ARG(!f || g, "wn_stack_fwd: f without g");
+    const bool g_only = g && !f;
+    WN_CHECK_ARG(!g_only || chain_capable(d), "wn_stack_fwd: this stack's backward needs tanh saved (wn_stack_saves_tanh)");
     WN_CHECK_ARG(t_off >= 0 && t_off < T, "wn_stack_fwd: t_off outside [0,T)");
     const size_t n = (size_t)B * T;
     const int L = d->n_layers;
@@ -84,7 +96,7 @@ int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, floa
         for (int l = 0; l < L; ++l) {
             float* out = xs + (size_t)l * n * d->Cr;
             int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
-            if (live[l] > 0) {
+            if (live[l] > 0 || g_only) {
                 wn::ProfScope prof__("wn_layer_fwd", stream);
                 rc = mfma_layer_fwd(in, d->Wf[l], d->bf ? d->bf[l] : nullptr, d->Wg[l], d->bg ? d->bg[l] : nullptr,
                                     d->Wp[l], d->bp ? d->bp[l] : nullptr, out, z + zoff, f ? f + zoff : nullptr,
@@ -113,7 +125,8 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
     wn::ExecScope exec__(ex);
     int rc = check_desc(d);
     if (rc) return rc;
-    WN_CHECK_ARG(x && xs && z && f && g && ws && dWf && dWg && dWp, "wn_stack_bwd: NULL argument");
+    WN_CHECK_ARG(x && xs && z && g && ws && dWf && dWg && dWp, "wn_stack_bwd: NULL argument");
+    WN_CHECK_ARG(f || chain_capable(d), "wn_stack_bwd: this stack's backward needs tanh saved (wn_stack_saves_tanh)");
     WN_CHECK_ARG(dout || dskip, "wn_stack_bwd: no incoming gradient");
     WN_CHECK_ARG(ws_bytes >= wn_stack_bwd_workspace_bytes(d, B, T), "wn_stack_bwd: workspace too small");
     const size_t n = (size_t)B * T;
@@ -173,10 +186,10 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
             const float* in = l == 0 ? x : xs + (size_t)(l - 1) * n * d->Cr;
             int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
             const int live = (t_live / 32) * 32;
-            rc = mfma_layer_bwd_chain(in, f + off[l], g + off[l], d->Wf[l], d->Wg[l], d->Wp[l], Vin, Uin, dU, vu_t0,
-                                      dskip ? dzp[l] : nullptr, (dskip && d->Cs % 32 == 0) ? t_off : 0, Vb[l & 1],
-                                      Ub[l & 1], parts + (size_t)l * mfma_chain_part_floats(), B, T, d->dilation[l], Z,
-                                      live, &nwg[l], as_stream(stream));
+            rc = mfma_layer_bwd_chain(in, f ? f + off[l] : z + off[l], g + off[l], d->Wf[l], d->Wg[l], d->Wp[l], Vin, Uin,
+                                      dU, vu_t0, dskip ? dzp[l] : nullptr, (dskip && d->Cs % 32 == 0) ? t_off : 0,
+                                      Vb[l & 1], Ub[l & 1], parts + (size_t)l * mfma_chain_part_floats(), B, T,
+                                      d->dilation[l], Z, live, &nwg[l], as_stream(stream), f == nullptr);
             if (rc) return rc;
             dWp_eff[l] = (Vin || Uin) ? dWp[l] : nullptr;
             Vin = Vb[l & 1]; Uin = Ub[l & 1]; dU = d->dilation[l];

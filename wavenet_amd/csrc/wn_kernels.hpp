@@ -31,7 +31,7 @@ int generic_skip_bwd_dw(int L, const float* const* z, const int* cd, const float
                         float* const* dbs, int B, int T, int t_off, int Tw, int Cs, hipStream_t s);
 int generic_colsum(const float* A, int nB, int nT, int tmin, int lda, int M, float* out, hipStream_t s);
 int generic_softmax(const float*, float*, long long, int, hipStream_t);
-int generic_softmax_xent(const float*, const int32_t*, float*, float*, long long, int, hipStream_t);
+int generic_softmax_xent(const float*, const int32_t*, float*, float*, long long, int, long long n_norm, hipStream_t);
 int generic_transpose(const float* src, float* dst, int batch, int R, int Cc, hipStream_t s);
 int generic_sample(const float*, const double*, int32_t*, int, int, hipStream_t);
 int generic_mulaw_encode_pcm16(const int16_t* pcm, const int32_t* lut, int32_t* tok, long long n, hipStream_t s);
@@ -69,7 +69,7 @@ size_t mfma_layer_bwd_extra_ws_floats();
 int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const float* Wf, const float* Wg,
                          const float* Wp, const float* Vin, const float* Uin, int dU, int vu_t0, const float* dzs,
                          int dz_t0, float* Vout, float* Uout, float* part, int B, int T, int d, int Z, int t_live,
-                         int* nwg, hipStream_t s);
+                         int* nwg, hipStream_t s, bool from_z = false);   // from_z: `f` holds z, tanh = z / sigmoid
 size_t mfma_chain_part_floats();
 int mfma_chain_reduce_all(const float* part, int L, const int* nwg, float* const* dWf, float* const* dWg,
                           float* const* dWp, hipStream_t s);

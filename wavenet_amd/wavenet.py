@@ -218,11 +218,11 @@ class _SoftmaxFn(_Fn):
 
 class _XentFn(_Fn):
     @staticmethod
-    def forward(ctx, logits, target):
+    def forward(ctx, logits, target, n_norm=0):
         N, Q = logits.shape
         loss = torch.empty((), device=logits.device, dtype=torch.float32)
         dlog = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
-        check(_lib.lib().wn_softmax_xent(ptr(logits), ptr(target), ptr(loss), ptr(dlog), N, Q, stream_ptr()),
+        check(_lib.lib().wn_softmax_xent(ptr(logits), ptr(target), ptr(loss), ptr(dlog), N, Q, int(n_norm), stream_ptr()),
               "wn_softmax_xent")
         ctx.dlog = dlog
         return loss
@@ -236,7 +236,7 @@ class _XentFn(_Fn):
             raise RuntimeError("the cross-entropy node can be backpropagated once (its gradient buffer is scaled in place)")
         d = dloss.to(torch.float32).reshape(1).contiguous()
         check(_lib.lib().wn_scale_by_dev(ptr(dlog), ptr(d), dlog.numel(), stream_ptr()), "wn_scale_by_dev")
-        return dlog, None
+        return dlog, None, None
 
 
 class _StackFn(_Fn):
@@ -256,7 +256,8 @@ class _StackFn(_Fn):
         dev_ = x.device
         xs = torch.empty((L, B, T, Cr), device=dev_, dtype=torch.float32)
         z = torch.empty((B * T * ncd,), device=dev_, dtype=torch.float32)
-        f = torch.empty_like(z) if train else None
+        # tanh is saved only when the backward cannot take the chained path (which recovers it as z / sigmoid)
+        f = torch.empty_like(z) if train and _lib.lib().wn_stack_saves_tanh(desc) else None
         g = torch.empty_like(z) if train else None
         skip = torch.empty((B, T - t_off, net._Cs), device=dev_, dtype=torch.float32)
         check(_lib.lib().wn_stack_fwd(desc, ptr(x), ptr(xs), ptr(z), ptr(f), ptr(g), ptr(skip), B, T, t_off,
@@ -916,13 +917,22 @@ class WaveNet(object):
             raise Exception("target_signal_data cannot be Variable")
         raw = self.to_variable(raw_network_output)
         _need_gpu(raw)
+        n_norm = 0
+        if not isinstance(target_signal_data, torch.Tensor):
+            # a host array (what the reference requires): labels are checked here -- Chainer type-checks them too -- and
+            # -1 is chainer's ignore_label: such rows carry no loss and do not count in the mean
+            lab = np.asarray(target_signal_data)
+            Q = raw.shape[1]
+            if lab.size and (lab.min() < -1 or lab.max() >= Q):
+                raise Exception("cross_entropy: labels must lie in [0, %d) or be -1 (ignored)" % Q)
+            n_norm = max(int((lab != -1).sum()), 1)
         tgt = self.to_variable(np.asarray(target_signal_data) if not isinstance(target_signal_data, torch.Tensor)
                                else target_signal_data)
         if raw.shape[3] != tgt.shape[1]:
             raise Exception("raw_network_output.width != target.width")
         rows = _to_btc(raw)                                        # row b*T'+t, as after the reference's transpose
         B, Tw, Q = rows.shape
-        return _XentFn.apply(rows.reshape(B * Tw, Q).contiguous(), tgt.to(torch.int32).reshape(-1).contiguous())
+        return _XentFn.apply(rows.reshape(B * Tw, Q).contiguous(), tgt.to(torch.int32).reshape(-1).contiguous(), n_norm)
 
     # -- the deferred skip projection -----------------------------------------------------------
     def _skip_sum(self, zs: Sequence[torch.Tensor], skip: torch.Tensor, B, T, t_off, Tw):
