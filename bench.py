@@ -263,8 +263,12 @@ def main():
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": spinup,
         "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "gemm_mode": ("exact fp32 MFMA" if os.environ.get("WAVENET_HIP_GEMM") == "fp32" else
-                      "bf16x3 split products, fp32 accumulate (fp32-accurate; layer kernels exact fp32 MFMA)"),
+        "gemm_mode": {"fp32": "exact fp32 MFMA",
+                      "bf16x3": "bf16x3 split products (six terms), fp32 accumulate (fp32-accurate; layer kernels exact fp32 MFMA)",
+                      "fp16x2": "skip-path contractions on fp16x2 split products (three terms, operands scaled by a power "
+                                "of two from their measured range), head on bf16x3, fp32 accumulate (fp32-accurate: same 1e-4 "
+                                "parity bars; layer kernels exact fp32 MFMA)",
+                      "bf16": "bf16 operands"}[_lib.get_gemm_precision()],
         "config": {"workload": "cfg2 train step: 4 blocks x 10 dilations (1..512), 32 residual / 256 skip ch, "
                                "16 kHz, %d clips x 16384 samples per GPU, loss over last 12290 columns, "
                                "fwd + bwd + clip + Adam%s" % (B_PER_GPU, " + RCCL all-reduce" if world > 1 else ""),
@@ -355,11 +359,11 @@ def main():
                                        "launch / time / 157.3 TFLOP/s"}
         else:
             ach = amount / (launch_ms * 1e-3) / 1e12
-            peak = F32_MFMA_PEAK_TF if os.environ.get("WAVENET_HIP_GEMM") == "fp32" else BF16X3_PEAK_TF
+            peak = {"fp32": F32_MFMA_PEAK_TF, "fp16x2": 2500.0 / 3.0}.get(_lib.get_gemm_precision(), BF16X3_PEAK_TF)
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak,
                                "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                                "launch_ms": launch_ms, "flops_per_launch": amount,
-                               "note": "fp32-equivalent flops; peak = dense bf16 MFMA / 6 (bf16x3 split products)"}
+                               "note": "fp32-equivalent flops; peak = dense 16-bit MFMA / terms of the split product"}
         out["mfma_units"] = {k: {"ms": per_step[k], "TFLOPs": units[k][1] / (per_step[k] * 1e-3) / 1e12}
                              for k in units if units[k][0] == "mfma" and k in per_step}
         # ---- AR decode, config 4: 16k samples on one GPU, persistent per-layer state -----------

@@ -56,11 +56,14 @@ const char* wn_last_error(void);
  *   WN_GEMM_FP32    fp32-input MFMA                                        (exact fp32 products)
  *   WN_GEMM_BF16X3  every operand split into three bf16 parts, six products (fp32-accurate; what NULL selects)
  *   WN_GEMM_BF16    operands rounded to bf16 once, fp32 accumulation
- * Storage stays fp32 in all three; the fused 32-channel layer kernels always multiply in fp32.
+ *   WN_GEMM_FP16X2  forward contractions (skip sum, head convs): operands scaled by a power of two and split into two fp16
+ *                   parts, three products (fp32-accurate to 2^-21 at half the matrix work of BF16X3); gradients, whose
+ *                   magnitude is not known in advance, keep the BF16X3 split
+ * Storage stays fp32 in all of them; the fused 32-channel layer kernels always multiply in fp32.
  * ws / ws_bytes: device scratch, at least wn_exec_workspace_bytes() for the model and batch; its contents are dead when the
  * call's kernels have run, so ONE buffer per stream serves every call on that stream (never one buffer for two streams).
  * ex == NULL means { WN_GEMM_BF16X3, NULL, 0 }: fine for calls that need no scratch, WN_EARG (with the byte count) otherwise. */
-enum { WN_GEMM_FP32 = 0, WN_GEMM_BF16X3 = 1, WN_GEMM_BF16 = 2 };
+enum { WN_GEMM_FP32 = 0, WN_GEMM_BF16X3 = 1, WN_GEMM_BF16 = 2, WN_GEMM_FP16X2 = 3 };
 typedef struct WnExec {
     int precision;
     void* ws;

@@ -1104,7 +1104,7 @@ def test_gemm_precision_switch_round_trip():
         return
     before = wavenet_amd.get_gemm_precision()
     try:
-        for name in ("fp32", "bf16", "bf16x3"):
+        for name in ("fp32", "bf16", "bf16x3", "fp16x2"):
             wavenet_amd.set_gemm_precision(name)
             assert wavenet_amd.get_gemm_precision() == name
         with pytest.raises(ValueError):
@@ -1240,3 +1240,33 @@ def test_cross_entropy_ignores_label_minus_one_like_chainer_and_rejects_other_ba
     # a device-resident target is trusted for its range but still cannot make the kernel read out of bounds
     l2 = net.cross_entropy(dev(logits), dev(bad))
     assert np.isfinite(float(l2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [2.0 ** 20, 1.0, 2.0 ** -30])
+def test_fp16x2_split_follows_the_gradient_range(scale):
+    """WN_GEMM_FP16X2 scales the operands of the skip-path contractions by a power of two taken from their MEASURED range
+    (fp16 has five exponent bits): gradients a million times larger or a billion times smaller than usual -- a scaled
+    loss -- come out scaled by exactly that factor, to the same 1e-4 bar as the bf16x3 split."""
+    if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1":
+        pytest.skip("generic kernels only")
+    over = dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 5, residual_num_blocks=2,
+                softmax_conv_channels=[256, 256])
+    p, w, net = build(over)
+    net.gemm_precision = "fp16x2"
+    B, T, tw = 2, 400, 300
+    idx = np.random.RandomState(5).randint(0, 256, (B, T)).astype(np.int32)
+    tgt = np.random.RandomState(6).randint(0, 256, (B, tw)).astype(np.int32)
+    loss_ref, _, g = R.train_step_grads(p, w, idx, tgt)
+    c = net.forward_causal_block(idx)
+    _, s = net.forward_residual_block(c, t_off=T - tw)
+    loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt)
+    net.zero_grads()
+    (loss * scale).backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - loss_ref) < 1e-4
+    for ln, kind, off, n, shape in net._spans:
+        want = g["%s/%s" % (ln.name, kind)] * scale
+        got = to_np(net._grad_arena[off:off + n].view(shape))
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-30), (ln.name, kind)

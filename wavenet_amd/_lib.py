@@ -187,14 +187,16 @@ def stream_ptr() -> Optional[int]:
     return torch.cuda.current_stream().cuda_stream or None
 
 
-GEMM_PRECISIONS = ("fp32", "bf16x3", "bf16")
-_default_precision = {"fp32": "fp32", "bf16": "bf16"}.get(os.environ.get("WAVENET_HIP_GEMM", ""), "bf16x3")
+GEMM_PRECISIONS = ("fp32", "bf16x3", "bf16", "fp16x2")
+_default_precision = {"fp32": "fp32", "bf16": "bf16", "bf16x3": "bf16x3"}.get(os.environ.get("WAVENET_HIP_GEMM", ""), "fp16x2")
 
 
 def set_gemm_precision(name: str) -> None:
     """Default arithmetic of the channel GEMMs for models that do not set ``net.gemm_precision`` themselves: "fp32" (fp32
-    MFMA), "bf16x3" (three-way bf16 split, fp32-accurate; the start value, or WAVENET_HIP_GEMM) or "bf16" (operands
-    rounded to bf16, fp32 accumulation).  Pure host state: every library call carries its precision as an argument
+    MFMA), "bf16x3" (three-way bf16 split, six products, fp32-accurate), "fp16x2" (the skip-path contractions on a two-way
+    fp16 split with power-of-two scaling from the operands' measured range, three products, fp32-accurate to 2^-21;
+    everything else as bf16x3 -- the start value, or WAVENET_HIP_GEMM) or "bf16" (operands rounded to bf16, fp32
+    accumulation).  Pure host state: every library call carries its precision as an argument
     (WnExec), so models of different precision coexist in one process."""
     global _default_precision
     if name not in GEMM_PRECISIONS:

@@ -13,15 +13,36 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 static thread_local const WnExec* g_exec = nullptr;
-ExecScope::ExecScope(const WnExec* ex) : prev(g_exec) { g_exec = ex; }
-ExecScope::~ExecScope() { g_exec = prev; }
+static thread_local int g_exec_depth = 0;
+static thread_local const void* g_absmax_key[16];
+static thread_local int g_absmax_n = 0;
+static constexpr size_t kExecTail = 256;                  // bytes at the end of the scratch kept for the absmax words
+ExecScope::ExecScope(const WnExec* ex) : prev(g_exec) { g_exec = ex; ++g_exec_depth; }
+ExecScope::~ExecScope() {
+    g_exec = prev;
+    if (--g_exec_depth == 0) g_absmax_n = 0;              // the outermost entry point returns: nothing survives the call
+}
 static bool force_generic();
 int gemm_mode() {
     if (force_generic()) return WN_GEMM_FP32;
     const int m = g_exec ? g_exec->precision : WN_GEMM_BF16X3;
-    return (m < WN_GEMM_FP32 || m > WN_GEMM_BF16) ? WN_GEMM_BF16X3 : m;
+    return (m < WN_GEMM_FP32 || m > WN_GEMM_FP16X2) ? WN_GEMM_BF16X3 : m;
+}
+const unsigned* exec_absmax(const float* x, long long n, hipStream_t s) {
+    if (!g_exec || !g_exec->ws || g_exec->ws_bytes < kExecTail) {
+        set_error("this call needs WnExec scratch (the fp16 split scales its operands by their measured range)");
+        return nullptr;
+    }
+    unsigned* slots = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(g_exec->ws) + g_exec->ws_bytes - kExecTail);
+    for (int i = 0; i < g_absmax_n; ++i)
+        if (g_absmax_key[i] == x) return slots + i;
+    if (g_absmax_n >= 16) { set_error("exec_absmax: more than 16 arrays in one call"); return nullptr; }
+    if (generic_absmax(x, n, slots + g_absmax_n, s) != WN_OK) return nullptr;
+    g_absmax_key[g_absmax_n] = x;
+    return slots + g_absmax_n++;
 }
 void* exec_scratch(size_t bytes, const char* what) {
+    bytes += kExecTail;
     if (!g_exec || !g_exec->ws || g_exec->ws_bytes < bytes) {
         set_error("this call needs %zu bytes of WnExec scratch for %s (got %zu): size it with wn_exec_workspace_bytes()",
                   bytes, what, g_exec && g_exec->ws ? g_exec->ws_bytes : (size_t)0);
@@ -64,7 +85,7 @@ int wn_embed_fwd(const int32_t* idx, const float* W, const float* bias, float* o
 int wn_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* dbias, int B, int T, int Q, int C,
                  int fw, const WnExec* ex, void* stream) {
     wn::ExecScope exec__(ex);
-    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_FP16X2), "%s: WnExec.precision must be 0 .. 3", __func__);
     wn::ProfScope prof__("wn_embed_bwd", stream);
     NN(idx); NN(dout); NN(dW); POS(B); POS(T); POS(Q); POS(C); POS(fw);
     return generic_embed_bwd(idx, dout, dW, dbias, B, T, Q, C, fw, as_stream(stream));
@@ -90,7 +111,7 @@ int wn_layer_fwd(const float* x, const float* Wf, const float* bf, const float* 
                  const float* Wp, const float* bp, float* out, float* z, float* f_save, float* g_save, int B,
                  int T, int Cr, int Cd, int fw, int d, int Z, const WnExec* ex, void* stream) {
     wn::ExecScope exec__(ex);
-    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_FP16X2), "%s: WnExec.precision must be 0 .. 3", __func__);
     wn::ProfScope prof__("wn_layer_fwd", stream);
     NN(x); NN(Wf); NN(Wg); NN(Wp); NN(out); NN(z);
     POS(B); POS(T); POS(Cr); POS(Cd); POS(fw); POS(d);
@@ -126,7 +147,7 @@ int wn_layer_bwd(const float* x, const float* f, const float* g, const float* Wf
                  float* dWg, float* dbg, float* dWp, float* dbp, float* dab_ws, int B, int T, int Cr, int Cd,
                  int fw, int d, int Z, const WnExec* ex, void* stream) {
     wn::ExecScope exec__(ex);
-    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_FP16X2), "%s: WnExec.precision must be 0 .. 3", __func__);
     wn::ProfScope prof__("wn_layer_bwd", stream);
     NN(x); NN(f); NN(g); NN(Wf); NN(Wg); NN(Wp); NN(dab_ws);
     POS(B); POS(T); POS(Cr); POS(Cd); POS(fw); POS(d);
@@ -148,7 +169,7 @@ int wn_layer_bwd(const float* x, const float* f, const float* g, const float* Wf
 int wn_pointwise_fwd(const float* x, const float* W, const float* bias, float* out, int N, int Cin, int Cout,
                      int act, const WnExec* ex, void* stream) {
     wn::ExecScope exec__(ex);
-    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_FP16X2), "%s: WnExec.precision must be 0 .. 3", __func__);
     wn::ProfScope prof__("wn_pointwise_fwd", stream);
     NN(x); NN(W); NN(out); POS(N); POS(Cin); POS(Cout);
     WN_CHECK_ARG(act >= WN_ACT_NONE && act <= WN_ACT_ELU, "wn_pointwise_fwd: bad act %d", act);
@@ -160,7 +181,7 @@ int wn_pointwise_fwd(const float* x, const float* W, const float* bias, float* o
 int wn_pointwise_bwd(const float* x, const float* W, const float* dout, float* dx, float* dW, float* dbias,
                      int N, int Cin, int Cout, int act, const WnExec* ex, void* stream) {
     wn::ExecScope exec__(ex);
-    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_FP16X2), "%s: WnExec.precision must be 0 .. 3", __func__);
     wn::ProfScope prof__("wn_pointwise_bwd", stream);
     NN(x); NN(W); NN(dout); POS(N); POS(Cin); POS(Cout);
     WN_CHECK_ARG(act >= WN_ACT_NONE && act <= WN_ACT_ELU, "wn_pointwise_bwd: bad act %d", act);
@@ -186,7 +207,7 @@ static int check_skip(const char* fn, int L, int B, int T, int t_off, int Tw, in
 int wn_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const float* const* bs, const int* cd,
                     float* skip, int B, int T, int t_off, int Tw, int Cs, int accumulate, const WnExec* ex, void* stream) {
     wn::ExecScope exec__(ex);
-    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_FP16X2), "%s: WnExec.precision must be 0 .. 3", __func__);
     wn::ProfScope prof__("wn_skip_sum_fwd", stream);
     NN(z); NN(Ws); NN(cd); NN(skip);
     int rc = check_skip("wn_skip_sum_fwd", L, B, T, t_off, Tw, Cs);
@@ -200,7 +221,7 @@ int wn_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, const 
 int wn_skip_sum_bwd_dz(int L, const float* const* Ws, const int* cd, const float* dskip, float* const* dz, int B,
                        int T, int t_off, int Tw, int Cs, const WnExec* ex, void* stream) {
     wn::ExecScope exec__(ex);
-    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_FP16X2), "%s: WnExec.precision must be 0 .. 3", __func__);
     wn::ProfScope prof__("wn_skip_sum_bwd_dz", stream);
     NN(Ws); NN(cd); NN(dskip); NN(dz);
     int rc = check_skip("wn_skip_sum_bwd_dz", L, B, T, t_off, Tw, Cs);
@@ -215,7 +236,7 @@ int wn_skip_sum_bwd_dz(int L, const float* const* Ws, const int* cd, const float
 int wn_skip_sum_bwd_dw(int L, const float* const* z, const int* cd, const float* dskip, float* const* dWs,
                        float* const* dbs, int B, int T, int t_off, int Tw, int Cs, const WnExec* ex, void* stream) {
     wn::ExecScope exec__(ex);
-    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_BF16), "%s: WnExec.precision must be 0, 1 or 2", __func__);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_FP16X2), "%s: WnExec.precision must be 0 .. 3", __func__);
     wn::ProfScope prof__("wn_skip_sum_bwd_dw", stream);
     NN(z); NN(cd); NN(dskip);
     int rc = check_skip("wn_skip_sum_bwd_dw", L, B, T, t_off, Tw, Cs);
@@ -361,7 +382,7 @@ size_t wn_exec_workspace_bytes(const WnStackDesc* d, int Q, int causal_channels,
     size_t need = image > parts ? image : parts;
     if (tables > need) need = tables;
     (void)T;
-    return (need + 4095) & ~(size_t)4095;
+    return ((need + 4095) & ~(size_t)4095) + 4096;
 }
 
 }  // extern "C"

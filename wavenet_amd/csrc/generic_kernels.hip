@@ -1027,6 +1027,36 @@ int generic_softmax_xent(const float* logits, const int32_t* target, float* loss
     return WN_OK;
 }
 
+// bits of max |x[i]| (0 for an empty or all-zero array): block maxima, one atomic per block
+__global__ void k_absmax(const float* __restrict__ x, long long n4, long long n, unsigned* __restrict__ slot) {
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (blockIdx.x == 0)
+        for (long long i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    __shared__ float part[16];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, part[w]);
+        atomicMax(slot, __float_as_uint(m));
+    }
+}
+int generic_absmax(const float* x, long long n, unsigned* slot, hipStream_t s) {
+    WN_HIP(hipMemsetAsync(slot, 0, sizeof(unsigned), s));
+    if (n <= 0) return WN_OK;
+    if (reinterpret_cast<uintptr_t>(x) & 15) { wn::set_error("absmax: the array must be 16-byte aligned"); return WN_EARG; }
+    long long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_absmax, dim3((unsigned)blocks), dim3(256), 0, s, x, n / 4, n, slot);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
 int generic_transpose(const float* src, float* dst, int batch, int R, int Cc, hipStream_t s) {
     dim3 grid(cdiv(Cc, 32), cdiv(R, 32), batch);
     hipLaunchKernelGGL(k_transpose, grid, dim3(32, 8), 0, s, src, dst, R, Cc);

@@ -228,6 +228,7 @@ int mfma_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, cons
         a.rows_out_per_b = Tw; a.rows_src_per_b = T; a.off = t_off;
         a.act = WN_ACT_NONE; a.gate_x = nullptr; a.gate_act = 0;
         a.accumulate = (accumulate || l0 > 0) ? 1 : 0;
+        a.h2_ok = 1;                                     // z = tanh * sigmoid lies in [-1, 1]
         int rc = launch_colgemm<false>(a, 1, s);
         if (rc) return rc;
     }
@@ -258,6 +259,7 @@ int mfma_skip_bwd_dz(int L, const float* const* Ws, const int* cd, const float* 
             a.N = (long long)B * T; a.rows_out_per_b = T; a.rows_src_per_b = Tw; a.off = -t_off;
         }
         a.act = WN_ACT_NONE; a.gate_x = nullptr; a.accumulate = 0;
+        if (gemm_mode() == WN_GEMM_FP16X2 && !(a.xmax_dev = exec_absmax(dskip, (long long)B * Tw * Cs, s))) return WN_EARG;
         int rc = launch_colgemm<true>(a, np, s);
         if (rc) return rc;
     }
@@ -274,6 +276,8 @@ int mfma_pointwise_fwd(const float* x, const float* W, const float* bias, float*
     a.rows_out_per_b = (int)(N < (1ll << 30) ? N : (1ll << 30)); a.rows_src_per_b = a.rows_out_per_b; a.off = 0;
     if (N >= (1ll << 30)) { wn::set_error("pointwise: N too large"); return WN_ESHAPE; }
     a.act = act; a.gate_x = nullptr; a.accumulate = 0;
+    // (the head keeps the six-term split under WN_GEMM_FP16X2: its input is bounded only by the weights, and measuring the
+    // range -- a 100 MB pass per call -- costs more than the fp16 split saves on a contraction this small: 0.095 -> 0.111 ms)
     return launch_colgemm<false>(a, 1, s);
 }
 
@@ -463,6 +467,10 @@ int mfma_skip_bwd_dw(int L, const float* const* z, const int* cd, const float* d
         if (a.nprob == 0) continue;
         a.ldb = width; a.ldo = width; a.osk = 1;
         a.nB = B; a.rows_A_per_b = Tw; a.rows_B_per_b = T; a.off = t_off; a.act = WN_ACT_NONE;
+        if (gemm_mode() == WN_GEMM_FP16X2) {             // A = dskip: measured range; B = z in [-1, 1]
+            if (!(a.amax_dev = exec_absmax(dskip, (long long)B * Tw * Cs, s))) return WN_EARG;
+            a.h2 = 1;
+        }
         int rc = launch_wgrad(a, Cs, s);
         if (rc) return rc;
     }

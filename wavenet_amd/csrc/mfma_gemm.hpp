@@ -37,6 +37,8 @@ struct CGArgs {
     int ldx;                         // row stride of every X source when != 0 (default: K[src])
     // fused-layer mode (mode 5 = gate mode + the residual projection, 128/128 channels, one-term products): out[0] (row
     // stride ldo = 128) = Wp z + proj_bias + residual, Wp's image is the kernel's second image argument
+    int h2_ok;                       // X is provably within the fp16 split's static range (z = tanh * sigmoid)
+    const unsigned* xmax_dev;        // else: device word with the bits of max |X| (exec_absmax) -> dynamic power-of-two scale
     const float* proj_W;             // Wp[128][128], row-major
     const float* proj_bias;
 };
@@ -58,6 +60,9 @@ struct WGArgs {
     float* out2[WN_MAX_SRC];
     int m_split;
     float* part;                     // wide block: per-workgroup partial tiles go here (plain stores), a second kernel sums them
+    // fp16 split (WN_GEMM_FP16X2): amax_dev = bits of max |A| (required); bmax_dev = bits of max |B| or NULL when B is
+    // provably in [-1, 1] (z)
+    const unsigned* amax_dev; const unsigned* bmax_dev; int h2;
 };
 
 // 1 unless WAVENET_HIP_GEMM=fp32: contractions use three-way bf16 splits (6 bf16 MFMAs per product term)

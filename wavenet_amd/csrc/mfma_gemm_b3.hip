@@ -25,6 +25,32 @@ static constexpr int kTileBytes = kTileElems * 2;          // 6144
 
 bool gemm_b3_enabled() { return gemm_mode() >= 1; }
 static bool one_term() { return gemm_mode() == 2; }
+static bool half2_mode() { return gemm_mode() == 3; }
+
+// fp16 two-way split (WN_GEMM_FP16X2): x S = h + m with h, m in fp16 (11 significant bits each, |x S - h - m| <= 2^-22 |x S|
+// while m is a normal number), products wh xh + (wh xm + wm xh): the dropped wm xm term is 2^-22 relative, so the result
+// is fp32-accurate like the six-term bf16 split at HALF the matrix instructions.  fp16's narrow exponent range is what
+// restricts it: operands are scaled by a power of two (exact) and must stay below 65504 after scaling, which is known for
+// the forward contractions (z = tanh * sigmoid in [-1, 1]; weights; the skip sum in front of the head) and is not for
+// gradients, whose magnitude follows the batch size and any loss scaling -- those keep the bf16 split.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+static constexpr float kH2ScaleW = 256.f;        // weights: |w| < 255
+static constexpr float kH2ScaleX = 16.f;         // activations: |x| < 4094 (larger values saturate instead of overflowing)
+// power-of-two scale that brings max |x| just below 2^14 (mx_dev = bits of max |x|); `fixed` when the range is static
+__device__ __forceinline__ float h2_scale(const unsigned* mx_dev, float fixed) {
+    if (!mx_dev) return fixed;
+    const float m = __uint_as_float(*mx_dev);
+    if (!(m > 0.f) || !(m < 3e38f)) return 1.f;
+    int e;
+    (void)frexpf(m, &e);                                  // m = f 2^e, f in [0.5, 1)
+    return ldexpf(1.f, 14 - e);
+}
+__device__ __forceinline__ void split2h(float x, _Float16& h, _Float16& m) {
+    x = fminf(fmaxf(x, -65000.f), 65000.f);
+    h = (_Float16)x;
+    m = (_Float16)(x - (float)h);
+}
 
 __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
     h = (__bf16)x;
@@ -39,6 +65,7 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
 // mode 2: m-tile t = problem t (32 rows), chunk c = k slice of W[t]
 // one != 0 (one-term products): only the h parts are stored, 2 KB per tile instead of 6
 __global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __bf16* __restrict__ img, int one) {
+    // one: 1 = h parts only (one-term bf16), 3 = fp16 two-way split of W * kH2ScaleW, 0 = bf16 three-way split
     const int tile = blockIdx.x;
     const int c = tile / mtiles, t = tile - c * mtiles;
     const int i = threadIdx.x & 31, c4 = threadIdx.x >> 5;           // row, group of 4 consecutive k
@@ -71,6 +98,19 @@ __global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __
         h[e] = hh; m[e] = mm; l[e] = ll;
     }
     const int ks = c4 >> 2, hh = (c4 >> 1) & 1, jo = 4 * (c4 & 1);
+    if (one == 3) {
+        f16x4 fh, fm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 a0, a1;
+            split2h(w[e] * kH2ScaleW, a0, a1);
+            fh[e] = a0; fm[e] = a1;
+        }
+        __bf16* d = img + (long long)tile * (kTileElems * 2 / 3) + (i + 32 * hh) * 8 + jo;
+        *reinterpret_cast<f16x4*>(d + (ks * 2 + 0) * 512) = fh;
+        *reinterpret_cast<f16x4*>(d + (ks * 2 + 1) * 512) = fm;
+        return;
+    }
     if (one) {
         __bf16* d = img + (long long)tile * (kTileElems / 3) + (i + 32 * hh) * 8 + jo;
         *reinterpret_cast<bf16x4*>(d + ks * 512) = h;
@@ -148,12 +188,17 @@ __device__ __forceinline__ float act_apply_t(float x) {
 
 // MT = 8 (one-term mode only: 128 accumulator registers, 16 KB of LDS per buffer) halves the number of times X is
 // re-read when there are 8 or more m-tiles (skip sum, dz, the gate-mode layer GEMM).
-template <int MODE, int ACT, bool ONE, int MT>
+// TM: terms of a product -- 6 (bf16 x 3), 1 (bf16), 3 (fp16 x 2: modes 0 and 2 only)
+template <int MODE, int ACT, int TM, int MT>
 __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, const __bf16* __restrict__ img, int mtiles,
                                                                      int nchunks, int chunks_per_src,
                                                                      const __bf16* __restrict__ img2) {
+    constexpr bool ONE = TM == 1;
+    constexpr bool H2 = TM == 3;
+    const float h2sx = H2 ? h2_scale(a.xmax_dev, kH2ScaleX) : 1.f;
     static_assert(MT == 4 || (MT == 8 && ONE), "8 m-tiles per workgroup only with one-term products");
-    constexpr int TB = ONE ? kTileBytes / 3 : kTileBytes;                       // bytes of one tile image (h only / h, m, l)
+    static_assert(!H2 || MODE == 0 || MODE == 2, "the fp16 split serves the plain contractions only");
+    constexpr int TB = ONE ? kTileBytes / 3 : (H2 ? kTileBytes * 2 / 3 : kTileBytes);   // bytes of one tile image
     __shared__ __attribute__((aligned(16))) char lds[2 * MT * TB];              // double-buffered tile images
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -194,7 +239,8 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
                 for (int mt = 0; mt < MT; ++mt)
                     if (t0 + mt < mtiles) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[mt][r] += a.bias[src][(t0 + mt) * 32 + b3_ch(r, h)];
+                        for (int r = 0; r < 16; ++r)
+                            acc[mt][r] += a.bias[src][(t0 + mt) * 32 + b3_ch(r, h)] * (H2 ? kH2ScaleW * h2sx : 1.f);
                     }
             }
     }
@@ -237,11 +283,23 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
         for (int ks = 0; ks < 2; ++ks) {
             const float v[8] = {xr[2 * ks].x, xr[2 * ks].y, xr[2 * ks].z, xr[2 * ks].w,
                                 xr[2 * ks + 1].x, xr[2 * ks + 1].y, xr[2 * ks + 1].z, xr[2 * ks + 1].w};
+            if (H2) {
+                f16x8 fh, fm;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                __bf16 hh, mm, ll;
-                split3(act_apply_t<ACT>(v[e]) * ms, hh, mm, ll);
-                xh[ks][e] = hh; xm[ks][e] = mm; xl[ks][e] = ll;
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 a0, a1;
+                    split2h(act_apply_t<ACT>(v[e]) * (ms * h2sx), a0, a1);
+                    fh[e] = a0; fm[e] = a1;
+                }
+                xh[ks] = __builtin_bit_cast(bf16x8, fh);
+                xm[ks] = __builtin_bit_cast(bf16x8, fm);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    __bf16 hh, mm, ll;
+                    split3(act_apply_t<ACT>(v[e]) * ms, hh, mm, ll);
+                    xh[ks][e] = hh; xm[ks][e] = mm; xl[ks][e] = ll;
+                }
             }
         }
         __syncthreads();                 // vmcnt(0): chunk c's image has landed; every wave is done with chunk c-1
@@ -257,7 +315,15 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
                 const char* p = Ab + mt * TB + ks * (TB / 2);
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(p);
                 const bf16x8 am = *reinterpret_cast<const bf16x8*>(p + (ONE ? 0 : 1024));
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(p + (ONE ? 0 : 2048));
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(p + ((ONE || H2) ? 0 : 2048));
+                if (H2) {                                  // fp16 two-way split: wm xh + wh xm + wh xh
+                    const f16x8 fah = __builtin_bit_cast(f16x8, ah), fam = __builtin_bit_cast(f16x8, am);
+                    const f16x8 fxh = __builtin_bit_cast(f16x8, xh[ks]), fxm = __builtin_bit_cast(f16x8, xm[ks]);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam, fxh, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fxm, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fxh, acc[mt], 0, 0, 0);
+                    continue;
+                }
                 // smallest terms first
                 if (!ONE) {
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, xh[ks], acc[mt], 0, 0, 0);
@@ -359,6 +425,12 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
             tile_store_rows(patch5, lane, t, a.out[0], a.ldo, mt * 32, rm5);
         }
         return;
+    }
+    if (H2) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] *= 1.f / (kH2ScaleW * h2sx);            // exact: a power of two
     }
     __syncthreads();                                               // the image buffers become the waves' 4 KB row patches
     float* patch = reinterpret_cast<float*>(lds) + wave * 1024;
@@ -471,11 +543,13 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
         nchunks = cps;
     }
     const bool one = one_term();
-    const size_t bytes = (size_t)nchunks * mtiles * (one ? kTileBytes / 3 : kTileBytes);
+    // fp16 split: plain contractions whose operands the caller declared range-safe (forward activations); else six terms
+    const bool h2 = half2_mode() && (a.h2_ok || a.xmax_dev) && (mode == 0 || mode == 2);
+    const size_t bytes = (size_t)nchunks * mtiles * (one ? kTileBytes / 3 : (h2 ? kTileBytes * 2 / 3 : kTileBytes));
     const size_t bytes2 = mode == 5 ? (size_t)16 * (kTileBytes / 3) : 0;        // Wp's image behind the gate image
     __bf16* img = reinterpret_cast<__bf16*>(exec_scratch(bytes + bytes2, "the split weight image"));
     if (!img) return WN_EARG;
-    hipLaunchKernelGGL(k_split_w, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img, one ? 1 : 0);
+    hipLaunchKernelGGL(k_split_w, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img, one ? 1 : (h2 ? 3 : 0));
     if (mode == 5) {
         if (!a.proj_W || !a.residual || !a.gate_z || a.act != WN_ACT_NONE || mtiles != 8) {
             wn::set_error("colgemm_b3: fused-layer mode needs Wp, the residual input, z and 128 gate channels");
@@ -485,7 +559,7 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
         b.nsrc = 1; b.W[0] = a.proj_W; b.wsm[0] = 128; b.wsk = 1; b.K[0] = 128; b.M = 128;
         __bf16* img2 = reinterpret_cast<__bf16*>(reinterpret_cast<char*>(img) + bytes);
         hipLaunchKernelGGL(k_split_w, dim3(16), dim3(256), 0, s, b, 0, 4, 4, img2, 1);
-        hipLaunchKernelGGL((k_colgemm_b3<5, WN_ACT_NONE, true, 8>), dim3(cdiv(a.N, 128), 1), dim3(256), 0, s, a,
+        hipLaunchKernelGGL((k_colgemm_b3<5, WN_ACT_NONE, 1, 8>), dim3(cdiv(a.N, 128), 1), dim3(256), 0, s, a,
                            (const __bf16*)img, mtiles, nchunks, cps, (const __bf16*)img2);
         WN_LAUNCH_CHECK();
         return WN_OK;
@@ -494,13 +568,25 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     dim3 grid(cdiv(a.N, 128), cdiv(mtiles, mt8 ? 8 : 4));
 #define CG_LAUNCH(MODE_, ACT_)                                                                                          \
     do {                                                                                                                \
-        if (mt8) hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, true, 8>), grid, dim3(256), 0, s, a, (const __bf16*)img, \
+        if (mt8) hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, 1, 8>), grid, dim3(256), 0, s, a, (const __bf16*)img,    \
                                     mtiles, nchunks, cps, (const __bf16*)nullptr);                                      \
-        else if (one) hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, true, 4>), grid, dim3(256), 0, s, a,                \
+        else if (one) hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, 1, 4>), grid, dim3(256), 0, s, a,                   \
                                          (const __bf16*)img, mtiles, nchunks, cps, (const __bf16*)nullptr);             \
-        else hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, false, 4>), grid, dim3(256), 0, s, a, (const __bf16*)img,    \
+        else hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, 6, 4>), grid, dim3(256), 0, s, a, (const __bf16*)img,        \
                                 mtiles, nchunks, cps, (const __bf16*)nullptr);                                          \
     } while (0)
+#define CG_LAUNCH_H2(MODE_, ACT_)                                                                                       \
+    hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, 3, 4>), grid, dim3(256), 0, s, a, (const __bf16*)img, mtiles, nchunks, \
+                       cps, (const __bf16*)nullptr)
+    if (h2) {
+        if (mode == 2) CG_LAUNCH_H2(2, WN_ACT_NONE);
+        else if (a.act == WN_ACT_RELU) CG_LAUNCH_H2(0, WN_ACT_RELU);
+        else if (a.act == WN_ACT_ELU) CG_LAUNCH_H2(0, WN_ACT_ELU);
+        else CG_LAUNCH_H2(0, WN_ACT_NONE);
+        WN_LAUNCH_CHECK();
+        return WN_OK;
+    }
+#undef CG_LAUNCH_H2
     if (mode == 3) {
         if (a.act != WN_ACT_NONE || !a.gate_z) { wn::set_error("colgemm_b3: gate mode takes no activation and needs gate_z"); return WN_EARG; }
         CG_LAUNCH(3, WN_ACT_NONE);
@@ -683,9 +769,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_b3(WGArgs a) {
 // barrier per chunk), and every wave runs 96 MFMAs per chunk on its own problem's B values.
 // Grid: x = batch * row slabs, y = ceil(nprob / 8); M == 256.
 // ---------------------------------------------------------------------------------------------
-template <bool HAS_B2, int ACT, bool ONE>
+template <bool HAS_B2, int ACT, int TM>
 __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
     constexpr int MT = 8;
+    constexpr bool ONE = TM == 1;
+    constexpr bool H2 = TM == 3;
+    const float h2sa = H2 ? h2_scale(a.amax_dev, 1.f) : 1.f;
+    const float h2sb = H2 ? h2_scale(a.bmax_dev, kH2ScaleX) : 1.f;
     extern __shared__ __attribute__((aligned(16))) char ldsw[];               // 2 x MT x 6 KB
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -774,17 +864,25 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
                     av *= ra < r_end ? 1.f : 0.f;
                     bv *= (rb < r_end && rb + off >= 0 && rb + off < a.rows_B_per_b) ? 1.f : 0.f;
                 }
-                __bf16 x0, x1, x2;
-                split3(av, x0, x1, x2);
-                ah[e] = x0; am[e] = x1; al[e] = x2;
-                split3(bv, x0, x1, x2);
-                bh[ks][e] = x0; bm[ks][e] = x1; bl[ks][e] = x2;
+                if (H2) {                                // fp16 two-way split of the scaled operands (bit patterns travel as bf16x8)
+                    _Float16 y0, y1;
+                    split2h(av * h2sa, y0, y1);
+                    ah[e] = __builtin_bit_cast(__bf16, y0); am[e] = __builtin_bit_cast(__bf16, y1);
+                    split2h(bv * h2sb, y0, y1);
+                    bh[ks][e] = __builtin_bit_cast(__bf16, y0); bm[ks][e] = __builtin_bit_cast(__bf16, y1);
+                } else {
+                    __bf16 x0, x1, x2;
+                    split3(av, x0, x1, x2);
+                    ah[e] = x0; am[e] = x1; al[e] = x2;
+                    split3(bv, x0, x1, x2);
+                    bh[ks][e] = x0; bm[ks][e] = x1; bl[ks][e] = x2;
+                }
             }
             // image: tile fm>>5, [ks][comp][lane = (fm & 31) + 32*fhh][8]
             char* d = buf + (fm >> 5) * kTileBytes + (ks * 3) * 1024 + ((fm & 31) + 32 * fhh) * 16;
             *reinterpret_cast<bf16x8*>(d) = ah;
             *reinterpret_cast<bf16x8*>(d + 1024) = am;
-            *reinterpret_cast<bf16x8*>(d + 2048) = al;
+            if (!H2) *reinterpret_cast<bf16x8*>(d + 2048) = al;
         }
         __syncthreads();                 // the image of this chunk is complete (the buffer written next was read two chunks ago)
         if (r0 + 32 < r_end) issue(r0 + 32);                 // in flight during the MFMAs below
@@ -796,6 +894,14 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
                 const char* q = Al + mt * kTileBytes + ks * 3 * 1024;
                 const bf16x8 xh = *reinterpret_cast<const bf16x8*>(q);
                 const bf16x8 xm = *reinterpret_cast<const bf16x8*>(q + 1024);
+                if (H2) {
+                    const f16x8 fah = __builtin_bit_cast(f16x8, xh), fam = __builtin_bit_cast(f16x8, xm);
+                    const f16x8 fbh = __builtin_bit_cast(f16x8, bh[ks]), fbm = __builtin_bit_cast(f16x8, bm[ks]);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam, fbh, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbm, acc[mt], 0, 0, 0);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbh, acc[mt], 0, 0, 0);
+                    continue;
+                }
                 const bf16x8 xl = *reinterpret_cast<const bf16x8*>(q + 2048);
                 if (!ONE) {
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh[ks], acc[mt], 0, 0, 0);
@@ -809,6 +915,13 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
         }
     }
     if (!active) return;
+    if (H2) {
+        const float inv = 1.f / (h2sa * h2sb);               // exact: powers of two
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] *= inv;
+    }
     // [workgroup][wave = problem][mt][r][lane]: whole 256-byte rows per store instruction, no atomics; k_wgrad_b3w_reduce
     // sums the workgroups' tiles.  (256 workgroups adding 64 K values each into the SAME 64 K addresses with float atomics
     // were 98 of this kernel's 155 us at config 5's layer shapes.)
@@ -846,9 +959,11 @@ int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
 #define W_ATTR(B2_, ACT_)                                                                               \
-    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_b3w<B2_, ACT_, false>),             \
+    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_b3w<B2_, ACT_, 6>),                 \
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * kTileBytes));        \
-    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_b3w<B2_, ACT_, true>),              \
+    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_b3w<B2_, ACT_, 3>),                 \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * kTileBytes));        \
+    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_b3w<B2_, ACT_, 1>),                 \
                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * kTileBytes))
         W_ATTR(false, WN_ACT_NONE); W_ATTR(false, WN_ACT_RELU); W_ATTR(false, WN_ACT_ELU);
         W_ATTR(true, WN_ACT_NONE); W_ATTR(true, WN_ACT_RELU); W_ATTR(true, WN_ACT_ELU);
@@ -877,10 +992,12 @@ int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
     a.part = reinterpret_cast<float*>(exec_scratch(part_bytes, "the weight-gradient partial tiles"));
     if (!a.part) return WN_EARG;
     const bool one = one_term();
+    const bool h2 = half2_mode() && a.h2 && a.amax_dev && !any_b2;
 #define W_LAUNCH(B2_, ACT_)                                                                                     \
     do {                                                                                                        \
-        if (one) hipLaunchKernelGGL((k_wgrad_b3w<B2_, ACT_, true>), grid, dim3(512), 2 * 8 * kTileBytes, s, a);  \
-        else hipLaunchKernelGGL((k_wgrad_b3w<B2_, ACT_, false>), grid, dim3(512), 2 * 8 * kTileBytes, s, a);     \
+        if (one) hipLaunchKernelGGL((k_wgrad_b3w<B2_, ACT_, 1>), grid, dim3(512), 2 * 8 * kTileBytes, s, a);     \
+        else if (h2) hipLaunchKernelGGL((k_wgrad_b3w<B2_, ACT_, 3>), grid, dim3(512), 2 * 8 * kTileBytes, s, a); \
+        else hipLaunchKernelGGL((k_wgrad_b3w<B2_, ACT_, 6>), grid, dim3(512), 2 * 8 * kTileBytes, s, a);         \
     } while (0)
 #define W_LAUNCH_A(B2_)                                           \
     do {                                                          \

@@ -46,6 +46,11 @@ struct ExecScope {
 };
 int gemm_mode();                       // WN_GEMM_* of the current call (WN_GEMM_FP32 under WAVENET_HIP_FORCE_GENERIC=1)
 void* exec_scratch(size_t bytes, const char* what);   // the caller's scratch; NULL + error text when it is too small
+// Device word holding the bits of max |x[i]| (a positive float orders like an unsigned): one pass per array and entry-point
+// call, shared by the launchers below it (the word lives in the last 256 bytes of the caller's scratch); NULL + error text
+// when there is no scratch.  Used by the fp16 split (WN_GEMM_FP16X2) to scale operands whose range is not known in advance.
+const unsigned* exec_absmax(const float* x, long long n, hipStream_t s);
+int generic_absmax(const float* x, long long n, unsigned* slot, hipStream_t s);
 int generic_scale_by_dev(float* x, const float* sdev, long long n, hipStream_t s);
 int generic_rule(int rule, float* p, const float* g, float* s1, float* s2, long long n, float lr, float hy, float eps,
                  float wd, const float* sqnorm, float clip, float gmult, const float* lr_dev, hipStream_t s);
