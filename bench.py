@@ -331,9 +331,9 @@ def main():
                              ["wn::k_layer_bwd_chainsp<true, true, true, true>", "wn::k_layer_bwd_chainsp<true, true, true>"]),
             "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl,
                              ["wn::k_layer_fwd_mfma32_t1<2, false>", "wn::k_layer_fwd_mfma32_t1<true, false>"]),
-            "wn_skip_sum_fwd": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<0, 0, false, 4>"]),
-            "wn_skip_sum_bwd_dw": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_wgrad_b3w<false, 0, false>"]),
-            "wn_skip_sum_bwd_dz": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<2, 0, false, 4>"]),
+            "wn_skip_sum_fwd": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<0, 0, 3, 4>", "wn::k_colgemm_b3<0, 0, 6, 4>", "wn::k_colgemm_b3<0, 0, false, 4>"]),
+            "wn_skip_sum_bwd_dw": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_wgrad_b3w<false, 0, 3>", "wn::k_wgrad_b3w<false, 0, 6>", "wn::k_wgrad_b3w<false, 0, false>"]),
+            "wn_skip_sum_bwd_dz": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<2, 0, 3, 4>", "wn::k_colgemm_b3<2, 0, 6, 4>", "wn::k_colgemm_b3<2, 0, false, 4>"]),
         }
         dom = max(units, key=lambda k: per_step.get(k, 0.0))
         bound, amount, launches, knames = units[dom]

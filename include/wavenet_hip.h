@@ -56,9 +56,11 @@ const char* wn_last_error(void);
  *   WN_GEMM_FP32    fp32-input MFMA                                        (exact fp32 products)
  *   WN_GEMM_BF16X3  every operand split into three bf16 parts, six products (fp32-accurate; what NULL selects)
  *   WN_GEMM_BF16    operands rounded to bf16 once, fp32 accumulation
- *   WN_GEMM_FP16X2  forward contractions (skip sum, head convs): operands scaled by a power of two and split into two fp16
- *                   parts, three products (fp32-accurate to 2^-21 at half the matrix work of BF16X3); gradients, whose
- *                   magnitude is not known in advance, keep the BF16X3 split
+ *   WN_GEMM_FP16X2  the skip contraction and its two backward GEMMs: operands scaled by a power of two and split into two
+ *                   fp16 parts, three products (fp32-accurate to 2^-21 at half the matrix work of BF16X3).  Weights and
+ *                   tanh*sigmoid outputs use fixed scales (a weight outside +-2^7 makes the launch fall back to BF16X3),
+ *                   gradients the power of two that fits their absolute maximum, measured on the device by one extra
+ *                   pass (no host synchronisation).  The head convolutions keep the BF16X3 split.
  * Storage stays fp32 in all of them; the fused 32-channel layer kernels always multiply in fp32.
  * ws / ws_bytes: device scratch, at least wn_exec_workspace_bytes() for the model and batch; its contents are dead when the
  * call's kernels have run, so ONE buffer per stream serves every call on that stream (never one buffer for two streams).
