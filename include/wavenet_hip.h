@@ -305,6 +305,11 @@ int wn16_pack_stack(const WnStackDesc* d, uint16_t* pack, void* stream);
 /* A10 on tokens, bf16 output (filter width 2) */
 int wn16_embed_fwd(const int32_t* idx, const float* W, const float* bias, uint16_t* out, int B, int T, int Q, int C,
                    int fw, void* stream);
+/* its gradient (the backward of data.py:61-68 + wavenet.py:298-301 on tokens): dW (C,Q,2) += one-hot(tokens)^T dout on
+ * the matrix cores, dbias (C) += column sums or NULL; dout (B,T,128) bf16; 128 channels, 256 token values, filter width 2 */
+size_t wn16_embed_bwd_workspace_bytes(int B, int T);
+int wn16_embed_bwd(const int32_t* idx, const uint16_t* dout, float* dW, float* dbias, int B, int T, int Q, int C, int fw,
+                   void* ws, size_t ws_bytes, void* stream);
 int wn16_cvt_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream);     /* n % 8 == 0 */
 int wn16_cvt_to_f32(const uint16_t* src, float* dst, int64_t n, void* stream);
 /* A11: xs (L,B,T,128) every layer's output, z (L,B,T,128), skip (B,T-t_off,Cs) or NULL */

@@ -182,3 +182,36 @@ def test_cfg5_full_topology_train_step_vs_the_rounding_oracle_eager_and_graph():
     assert abs(float(lg) - loss_ref) < 2e-3
     grads_close(net, g, 2e-3, "graph", noise=g_noise)
     assert np.abs(to_np(net._arena) - w0).max() > 0
+
+
+@pytest.mark.parametrize("B,T", [(1, 70), (2, 1000), (3, 4133), (8, 16384)])
+def test_embedding_gradient_on_the_matrix_cores_matches_a_float64_scatter(B, T):
+    """wn16_embed_bwd (the backward of data.py:61-68 + wavenet.py:298-301 on tokens, as a one-hot x dout contraction in
+    bf16 MFMA with fp32 accumulation): every table entry within 1e-5 (relative to the column scale) of a float64
+    scatter-add of the same bf16 gradient, the bias gradient likewise; accumulates into dW (+=); ragged T, T < one stage."""
+    from wavenet_amd import _lib
+    from wavenet_amd._lib import check, ptr, stream_ptr
+    lib = _lib.lib()
+    rs = np.random.RandomState(B * 1000 + T)
+    idx = rs.randint(0, 256, (B, T)).astype(np.int32)
+    idx[:, : T // 3] = (128 + 20 * np.sin(np.arange(T // 3) / 7.0)).astype(np.int32)     # runs of equal tokens, as in audio
+    dout = torch.as_tensor(rs.standard_normal((B, T, 128)).astype(np.float32)).to(torch.bfloat16).cuda()
+    d64 = dout.float().cpu().numpy().astype(np.float64)
+    want = np.zeros((128, 256, 2))
+    for b in range(B):
+        np.add.at(want[:, :, 1].T, idx[b], d64[b])                                       # tap 1: the current token
+        np.add.at(want[:, :, 0].T, idx[b, :-1], d64[b, 1:])                              # tap 0: the token one step back
+    dW = torch.full((128, 256, 1, 2), 0.25, device="cuda", dtype=torch.float32)
+    db = torch.full((128,), -1.0, device="cuda", dtype=torch.float32)
+    nws = lib.wn16_embed_bwd_workspace_bytes(B, T)
+    ws = torch.empty((nws,), device="cuda", dtype=torch.uint8)
+    check(lib.wn16_embed_bwd(ptr(dev(idx)), ptr(dout), ptr(dW), ptr(db), B, T, 256, 128, 2, ptr(ws), nws, stream_ptr()),
+          "wn16_embed_bwd")
+    torch.cuda.synchronize()
+    got = to_np(dW).reshape(128, 256, 2).astype(np.float64) - 0.25
+    scale = np.abs(d64).sum() / (128 * 256) + 1.0
+    assert np.abs(got - want).max() <= 1e-5 * scale, (np.abs(got - want).max(), scale)
+    gb = to_np(db).astype(np.float64) + 1.0
+    assert np.abs(gb - d64.sum((0, 1))).max() <= 1e-5 * (np.abs(d64).sum() / 128 + 1.0)
+    rc = lib.wn16_embed_bwd(ptr(dev(idx)), ptr(dout), ptr(dW), None, B, T, 256, 64, 2, ptr(ws), nws, stream_ptr())
+    assert rc != 0 and b"128 channels" in lib.wn_last_error()

@@ -95,6 +95,8 @@ _SIGS = {
     "wn16_pack_elems": (C.c_size_t, [C.POINTER(WnStackDesc)]),
     "wn16_pack_stack": (_i, [C.POINTER(WnStackDesc), _p, _p]),
     "wn16_embed_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "wn16_embed_bwd_workspace_bytes": (C.c_size_t, [_i, _i]),
+    "wn16_embed_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p, C.c_size_t, _p]),
     "wn16_cvt_to_bf16": (_i, [_p, _p, _i64, _p]),
     "wn16_cvt_to_f32": (_i, [_p, _p, _i64, _p]),
     "wn16_stack_fwd": (_i, [C.POINTER(WnStackDesc), _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),

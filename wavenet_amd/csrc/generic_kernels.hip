@@ -63,6 +63,9 @@ __global__ void k_embed_fwd4(const int32_t* __restrict__ idx, const float* __res
 // their loads (values and tokens) before the first LDS atomic -- a loop of "load, then atomics on it" runs one
 // memory latency per element (this kernel took 0.24 ms per step that way; the data is 17 MB).
 static constexpr int kEmbU = 8;
+// 16 waves per block: with one block per CU (the table fills LDS) 4 waves had 32 loads in flight per SIMD lane group and
+// the kernel ran at 6 cycles per element and CU -- latency, not LDS atomics or HBM (17 MB), set its time
+static constexpr int kEmbThreads = 1024;
 template <int FW>
 __global__ void k_embed_bwd_lds(const int32_t* __restrict__ idx, const float* __restrict__ dout,
                                 float* __restrict__ ws, int has_bias,
@@ -812,7 +815,7 @@ int generic_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* d
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));              \
             attr_set = true;                                                                                  \
         }                                                                                                     \
-        hipLaunchKernelGGL(k_embed_bwd_lds<FW>, dim3(nblk, nsl), dim3(kThreads), lds, s, idx, dout, ws, dbias ? 1 : 0, B, T, \
+        hipLaunchKernelGGL(k_embed_bwd_lds<FW>, dim3(nblk, nsl), dim3(kEmbThreads), lds, s, idx, dout, ws, dbias ? 1 : 0, B, T, \
                            Q, Cs, fw, cpb, C);                                                                \
     } while (0)
         if (fw == 1) EMB_LAUNCH(1);

@@ -196,14 +196,34 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
     constexpr bool ONE = TM == 1;
     constexpr bool H2 = TM == 3;
     const float h2sx = H2 ? h2_scale(a.xmax_dev, kH2ScaleX) : 1.f;
-    static_assert(MT == 4 || (MT == 8 && ONE), "8 m-tiles per workgroup only with one-term products");
+    static_assert(MT == 4 || (MT == 8 && (ONE || H2)), "8 m-tiles per workgroup: one-term or fp16-split products");
     static_assert(!H2 || MODE == 0 || MODE == 2, "the fp16 split serves the plain contractions only");
     constexpr int TB = ONE ? kTileBytes / 3 : (H2 ? kTileBytes * 2 / 3 : kTileBytes);   // bytes of one tile image
     __shared__ __attribute__((aligned(16))) char lds[2 * MT * TB];              // double-buffered tile images
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int t0 = blockIdx.y * MT;                        // first m-tile (mode 2: first problem) of this workgroup
-    const long long n = ((long long)blockIdx.x * 4 + wave) * 32 + j;
+    // Workgroup -> (column block bx, m-tile group by).  The `ny` groups of one column block read the same X: they get
+    // linear ids xcd + 8 * by (+ a multiple of 8 ny), i.e. the SAME XCD at consecutive dispatch slots, so that X comes from
+    // HBM once and from that XCD's L2 for the others (with by as the slow grid index the re-reads were HBM reads: the skip
+    // sum fetched 1.38 GB for 0.5 GB of z, dz 1.02 GB for 0.1 GB of dskip -- both ran at the HBM limit, 5.2-5.4 TB/s).
+    int bx, by;
+    {
+        const int ny = (mtiles + MT - 1) / MT;
+        const int nx = gridDim.x / ny;
+        const int id = blockIdx.x;
+        const int full = nx & ~7;
+        if (id < full * ny) {
+            const int g = id / (8 * ny), rem = id - g * 8 * ny;
+            bx = g * 8 + (rem & 7);
+            by = rem >> 3;
+        } else {
+            const int t = id - full * ny;
+            by = t % ny;
+            bx = full + t / ny;
+        }
+    }
+    const int t0 = by * MT;                                // first m-tile (mode 2: first problem) of this workgroup
+    const long long n = ((long long)bx * 4 + wave) * 32 + j;
     const bool nvalid = n < a.N;
     long long rb0 = 0;                 // first source row of this column's clip
     int rbase = -(1 << 30);            // row inside the clip before the per-source shift (invalid column: far out)
@@ -559,13 +579,13 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
         b.nsrc = 1; b.W[0] = a.proj_W; b.wsm[0] = 128; b.wsk = 1; b.K[0] = 128; b.M = 128;
         __bf16* img2 = reinterpret_cast<__bf16*>(reinterpret_cast<char*>(img) + bytes);
         hipLaunchKernelGGL(k_split_w, dim3(16), dim3(256), 0, s, b, 0, 4, 4, img2, 1);
-        hipLaunchKernelGGL((k_colgemm_b3<5, WN_ACT_NONE, 1, 8>), dim3(cdiv(a.N, 128), 1), dim3(256), 0, s, a,
+        hipLaunchKernelGGL((k_colgemm_b3<5, WN_ACT_NONE, 1, 8>), dim3(cdiv(a.N, 128)), dim3(256), 0, s, a,
                            (const __bf16*)img, mtiles, nchunks, cps, (const __bf16*)img2);
         WN_LAUNCH_CHECK();
         return WN_OK;
     }
-    const bool mt8 = one && mtiles >= 8;
-    dim3 grid(cdiv(a.N, 128), cdiv(mtiles, mt8 ? 8 : 4));
+    const bool mt8 = (one || h2) && mtiles >= 8;
+    dim3 grid(cdiv(a.N, 128) * cdiv(mtiles, mt8 ? 8 : 4));
 #define CG_LAUNCH(MODE_, ACT_)                                                                                          \
     do {                                                                                                                \
         if (mt8) hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, 1, 8>), grid, dim3(256), 0, s, a, (const __bf16*)img,    \
@@ -576,8 +596,12 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
                                 mtiles, nchunks, cps, (const __bf16*)nullptr);                                          \
     } while (0)
 #define CG_LAUNCH_H2(MODE_, ACT_)                                                                                       \
-    hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, 3, 4>), grid, dim3(256), 0, s, a, (const __bf16*)img, mtiles, nchunks, \
-                       cps, (const __bf16*)nullptr)
+    do {                                                                                                                \
+        if (mt8) hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, 3, 8>), grid, dim3(256), 0, s, a, (const __bf16*)img,    \
+                                    mtiles, nchunks, cps, (const __bf16*)nullptr);                                      \
+        else hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, 3, 4>), grid, dim3(256), 0, s, a, (const __bf16*)img,        \
+                                mtiles, nchunks, cps, (const __bf16*)nullptr);                                          \
+    } while (0)
     if (h2) {
         if (mode == 2) CG_LAUNCH_H2(2, WN_ACT_NONE);
         else if (a.act == WN_ACT_RELU) CG_LAUNCH_H2(0, WN_ACT_RELU);

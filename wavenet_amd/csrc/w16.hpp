@@ -55,8 +55,16 @@ __device__ __forceinline__ void dma_pieces(char* tile, int lane, int p0, int pst
 }
 
 // MFMA B operand (or A operand: same map) of lane (j, h) for k-step s of a 128-channel row tile: row j, chunk 2 s + h
+// A 16-byte LDS read through an EXPLICIT address-space-3 pointer.  A read through a generic `char*` into the dynamic LDS
+// array is also emitted as ds_read_b128, but its memory operand stays "flat" for hipcc's wait-count pass: flat accesses
+// may return out of order with LDS ones, so every wait in a loop that contains such a read is `s_waitcnt lgkmcnt(0)` --
+// a prefetched fragment set in flight is waited for together with the one being consumed (seen in the .s of every
+// kernel here that double-buffers fragments; the tr reads, whose builtin takes an LDS pointer, got counted waits).
+__device__ __forceinline__ bf16x8 lds_read16(const char* p) {
+    return *(const __attribute__((address_space(3))) bf16x8*)(p);
+}
 __device__ __forceinline__ bf16x8 frag_row(const char* tile, int row, int s, int h) {
-    return *reinterpret_cast<const bf16x8*>(tile + toff(row, 2 * s + h));
+    return lds_read16(tile + toff(row, 2 * s + h));
 }
 
 // Transposed operand: lane (r = lane & 31, hh = lane >> 5) receives channel c0 + r of the 8 consecutive tile rows

@@ -89,6 +89,16 @@ int wn16_embed_fwd(const int32_t* idx, const float* W, const float* bias, uint16
     return embed_fwd16(idx, W, bias, reinterpret_cast<bf16*>(out), B, T, Q, C, wn::as_stream(stream));
 }
 
+size_t wn16_embed_bwd_workspace_bytes(int B, int T) { return B > 0 && T > 0 ? embed_bwd16_ws_bytes(B, T) : 0; }
+int wn16_embed_bwd(const int32_t* idx, const uint16_t* dout, float* dW, float* dbias, int B, int T, int Q, int C, int fw,
+                   void* ws, size_t ws_bytes, void* stream) {
+    wn::ProfScope prof__("wn16_embed_bwd", stream);
+    WN_CHECK_ARG(idx && dout && dW && ws && B > 0 && T > 0, "wn16_embed_bwd: bad argument");
+    WN_CHECK_SHAPE(fw == 2 && C == 128 && Q == 256, "wn16_embed_bwd: needs filter width 2, 128 channels and 256 token values");
+    WN_CHECK_ARG(ws_bytes >= embed_bwd16_ws_bytes(B, T), "wn16_embed_bwd: workspace too small");
+    return embed_bwd16(idx, reinterpret_cast<const bf16*>(dout), dW, dbias, B, T, ws, wn::as_stream(stream));
+}
+
 int wn16_cvt_to_bf16(const float* src, uint16_t* dst, int64_t n, void* stream) {
     WN_CHECK_ARG(src && dst && n > 0, "wn16_cvt_to_bf16: bad argument");
     return cvt_f2b(src, reinterpret_cast<bf16*>(dst), n, wn::as_stream(stream));

@@ -168,7 +168,11 @@ int launch_cgemm(CG16& a, hipStream_t s) {
     {
         bool plain = a.ep == 0 && !a.relu_x && !a.out_f32 && a.M % 256 == 0 && a.ksrc % 64 == 0 && a.ob_col % 128 == 0 &&
                      (a.ob_col == 0 || a.ob_col == 128) && (long long)a.B * a.rows_per_b >= 4096;
-        for (int i = 0; i < a.nsrc && plain; ++i) plain = a.shift[i] == 0;
+        // the sources must be equally spaced (they are: one [L][B][T][C] allocation): a pointer fetched from the
+        // argument table inside the stage loop is a scalar load on lgkmcnt, and with one in the loop hipcc waits
+        // lgkmcnt(0) in front of every MFMA group instead of counting the LDS reads it has in flight
+        a.x_src_stride = a.nsrc > 1 ? a.X[1] - a.X[0] : 0;
+        for (int i = 0; i < a.nsrc && plain; ++i) plain = a.shift[i] == 0 && a.X[i] - a.X[0] == i * a.x_src_stride;
         if (plain && a.x_row0 >= 0 && a.x_row0 + a.rows_per_b <= a.x_rows_per_b) return launch_cgemm256(a, s);
     }
     a.blocks_per_b = (a.rows_per_b + 127) / 128;
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     auto issue = [&](int st, int buf) {
         const int src = st / spk;
         const int k0 = (st - src * spk) * 64;
-        const bf16* xb = a.X[src] + ((long long)b * a.x_rows_per_b) * a.ldx + k0;
+        const bf16* xb = a.X[0] + src * a.x_src_stride + ((long long)b * a.x_rows_per_b) * a.ldx + k0;
         const int sh = a.x_row0 + r0;
         const int hi = a.x_rows_per_b - 1;
         const bf16* wb = a.W + (long long)m0 * a.K + st * 64;
@@ -268,27 +272,49 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.f;
-    issue(0, 0);
-    for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        wait_vm<0>();
-        barrier();
-        if (st + 1 < nst) issue(st + 1, buf ^ 1);
+    // Fragments are double-buffered in registers: the LDS reads of k-step s + 1 are issued before the MFMAs of k-step s,
+    // so a wave's matrix stream never waits for a read it has just issued (with "4 reads, lgkmcnt(0), 4 MFMAs" groups the
+    // two waves of a SIMD each exposed ~150 cycles of LDS latency per 128 cycles of MFMA: 35 % matrix utilisation by PMC).
+    // The one barrier of a stage sits in front of the LAST k-step's MFMAs: by then that k-step's fragments are in
+    // registers, so the stage's buffer is free for the stage after next, and the next stage's buffer has landed, so its
+    // first fragments are fetched under those MFMAs -- the stream continues across the stage boundary.
+    bf16x8 fa[2][2], fb[2][4];
+    auto ld = [&](int buf, int ks, int slot) {
         const char* xb = xt(buf);
         const char* wb = wt(buf);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 bv[4], av[2];
+        for (int nt = 0; nt < 4; ++nt) fb[slot][nt] = lds_read16(xb + boff(128 * wn + 32 * nt + j, 2 * ks + h));
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bv[nt] = *reinterpret_cast<const bf16x8*>(xb + boff(128 * wn + 32 * nt + j, 2 * s + h));
+        for (int mt = 0; mt < 2; ++mt) fa[slot][mt] = lds_read16(wb + boff(64 * wm + 32 * mt + j, 2 * ks + h));
+    };
+    auto mm = [&](int slot) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) av[mt] = *reinterpret_cast<const bf16x8*>(wb + boff(64 * wm + 32 * mt + j, 2 * s + h));
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int mt = 0; mt < 2; ++mt)
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][mt], fb[slot][nt], acc[nt][mt], 0, 0, 0);
+    };
+    issue(0, 0);
+    wait_vm<0>();
+    barrier();
+    if (nst > 1) issue(1, 1);
+    ld(0, 0, 0);
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mt], bv[nt], acc[nt][mt], 0, 0, 0);
+        for (int ks = 0; ks < 3; ++ks) {
+            ld(buf, ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(ks & 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        wait_vm<0>();
+        barrier();
+        ld(buf ^ 1, 0, 0);                               // stale data after the last stage: never used
+        if (st + 2 < nst) issue(st + 2, buf);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1);
+        __builtin_amdgcn_sched_barrier(0);
     }
     // ---- epilogue: two 128-channel halves, each a [256 rows][256 B] tile in the format of w16.hpp, then whole rows ----
     barrier();
@@ -399,56 +425,75 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    if (c_begin < c_end) issue(c_begin, 0);
-    for (int c = c_begin; c < c_end; ++c) {
-        const int buf = (c - c_begin) & 1;
-        wait_vm<0>();
-        barrier();
-        if (c + 1 < c_end) issue(c + 1, buf ^ 1);
-        {
-            const int b = c / cpb;
-            const int r0 = (c - b * cpb) * kWT;
-            bool fix = r0 + kWT > a.R;
-            int sh[2];
+    if (c_begin >= c_end) return;
+    // rows that do not exist (the ragged end of a clip, a dilated tap reaching before its start) contribute nothing
+    auto fixup = [&](int c, int buf) {
+        const int b = c / cpb;
+        const int r0 = (c - b * cpb) * kWT;
+        bool fix = r0 + kWT > a.R;
+        int sh[2];
 #pragma unroll
-            for (int nh = 0; nh < 2; ++nh) {
-                sh[nh] = a.b_r0 + r0 + pr.shift[nh];
-                fix = fix || sh[nh] < 0 || sh[nh] + kWT > a.b_rpb;
-            }
-            if (fix) {                                   // rows that do not exist contribute nothing
-                for (int r = w; r < kWT; r += 8) {
-                    if (r0 + r >= a.R) {
-                        *reinterpret_cast<unsigned*>(tile(buf, 0) + r * 256 + lane * 4) = 0u;
-                        *reinterpret_cast<unsigned*>(tile(buf, 1) + r * 256 + lane * 4) = 0u;
-                    }
-#pragma unroll
-                    for (int nh = 0; nh < 2; ++nh)
-                        if (sh[nh] + r < 0 || sh[nh] + r >= a.b_rpb)
-                            *reinterpret_cast<unsigned*>(tile(buf, 2 + nh) + r * 256 + lane * 4) = 0u;
-                }
-                barrier();
-            }
+        for (int nh = 0; nh < 2; ++nh) {
+            sh[nh] = a.b_r0 + r0 + pr.shift[nh];
+            fix = fix || sh[nh] < 0 || sh[nh] + kWT > a.b_rpb;
         }
+        if (fix) {
+            for (int r = w; r < kWT; r += 8) {
+                if (r0 + r >= a.R) {
+                    *reinterpret_cast<unsigned*>(tile(buf, 0) + r * 256 + lane * 4) = 0u;
+                    *reinterpret_cast<unsigned*>(tile(buf, 1) + r * 256 + lane * 4) = 0u;
+                }
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+                    if (sh[nh] + r < 0 || sh[nh] + r >= a.b_rpb)
+                        *reinterpret_cast<unsigned*>(tile(buf, 2 + nh) + r * 256 + lane * 4) = 0u;
+            }
+            barrier();
+        }
+    };
+    // fragments double-buffered in registers, the stage barrier in front of the last k-step's MFMAs: as in k16_cgemm256
+    bf16x8 fa[2][2], fb[2][4];
+    auto ld = [&](int buf, int ks, int slot) {
         const char* at = tile(buf, wm >> 1);
         const char* bt = tile(buf, 2 + wn);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 av[2], bv[4];
+        for (int mi = 0; mi < 2; ++mi) fa[slot][mi] = frag_tr(at, 16 * ks, 64 * (wm & 1) + 32 * mi, lane);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) av[mi] = frag_tr(at, 16 * ks, 64 * (wm & 1) + 32 * mi, lane);
+        for (int ni = 0; ni < 4; ++ni) fb[slot][ni] = frag_tr(bt, 16 * ks, 32 * ni, lane);
+    };
+    auto mm = [&](int slot) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                bv[ni] = frag_tr(bt, 16 * ks, 32 * ni, lane);
-                if (RELU_B) bv[ni] = relu8(bv[ni]);
-            }
+        for (int ni = 0; ni < 4; ++ni) {
+            const bf16x8 bv = RELU_B ? relu8(fb[slot][ni]) : fb[slot][ni];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot][mi], bv, acc[mi][ni], 0, 0, 0);
         }
+    };
+    issue(c_begin, 0);
+    wait_vm<0>();
+    barrier();
+    fixup(c_begin, 0);
+    if (c_begin + 1 < c_end) issue(c_begin + 1, 1);
+    ld(0, 0, 0);
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            ld(buf, ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(ks & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wait_vm<0>();
+        barrier();
+        if (c + 1 < c_end) fixup(c + 1, buf ^ 1);
+        ld(buf ^ 1, 0, 0);                               // stale after the last stage: never used
+        if (c + 2 < c_end) issue(c + 2, buf);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(1);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    if (c_begin >= c_end) return;
     float* ob = pr.out[wm >> 1][wn];
     if (!ob) return;
 #pragma unroll
@@ -615,6 +660,182 @@ __global__ void k16_embed_fwd(const int32_t* __restrict__ idx, const float* __re
     *reinterpret_cast<bf16x8*>(out + n * C + c0) = o;
 }
 
+// The same gather with the table of a 64-channel slice staged in LDS as [tap][token value][channel] fp32 (2 x Q x 64 x 4 B
+// = 128 KB at Q = 256): the form above reads W[c][q][tap] for 8 channels of one thread 2 KB apart, 16 scattered dwords per
+// 16 bytes written (67 us at config 5 for 33 MB of output).  Here lane = channel while the slice is loaded (conflict-free
+// LDS stores; the 8-byte global reads of a wave hit 64 lines that stay in L1 for the next 15 token values), then a
+// thread adds two 32-byte rows per token and writes 16 bytes; a block covers kEmbTok tokens so that the table load
+// (128 KB from L2) is paid once per 128 KB of output.
+static constexpr int kEmbTok = 1024;
+__global__ __launch_bounds__(256) void k16_embed_fwd_lds(const int32_t* __restrict__ idx, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, bf16* __restrict__ out,
+                                                         long long N, int T, int Q, int C) {
+    extern __shared__ __attribute__((aligned(16))) float etab[];          // [2][Q][64]
+    const int c0 = blockIdx.y * 64;
+    {
+        const int c = threadIdx.x & 63;
+        const float bc = bias ? bias[c0 + c] : 0.f;
+        const float2* wc = reinterpret_cast<const float2*>(W + (long long)(c0 + c) * Q * 2);
+        for (int q = threadIdx.x >> 6; q < Q; q += 4) {
+            const float2 v = wc[q];
+            etab[q * 64 + c] = v.x;                                        // tap 0: the token one step back
+            etab[(Q + q) * 64 + c] = v.y + bc;                             // tap 1 (+ bias, added once per output)
+        }
+    }
+    __syncthreads();
+    const long long n0 = (long long)blockIdx.x * kEmbTok;
+    const int g = threadIdx.x & 7;                                         // 8 channels each
+    for (int i = threadIdx.x >> 3; i < kEmbTok; i += 32) {
+        const long long n = n0 + i;
+        if (n >= N) break;
+        const int t = (int)(n % T);
+        const int q1 = idx[n];
+        const int q0 = t > 0 ? idx[n - 1] : -1;
+        const float4* r1 = reinterpret_cast<const float4*>(etab + (Q + q1) * 64 + 8 * g);
+        float4 lo = r1[0], hi = r1[1];
+        if (q0 >= 0) {
+            const float4* r0 = reinterpret_cast<const float4*>(etab + q0 * 64 + 8 * g);
+            const float4 a = r0[0], b = r0[1];
+            lo.x += a.x; lo.y += a.y; lo.z += a.z; lo.w += a.w;
+            hi.x += b.x; hi.y += b.y; hi.z += b.z; hi.w += b.w;
+        }
+        bf16x8 o;
+        o[0] = (bf16)lo.x; o[1] = (bf16)lo.y; o[2] = (bf16)lo.z; o[3] = (bf16)lo.w;
+        o[4] = (bf16)hi.x; o[5] = (bf16)hi.y; o[6] = (bf16)hi.z; o[7] = (bf16)hi.w;
+        *reinterpret_cast<bf16x8*>(out + n * C + c0 + 8 * g) = o;
+    }
+}
+
+// =============================================================================================
+// k16_embed_bwd: gradient of the first causal layer's table (data.py:61-68 + wavenet.py:298-301, fw = 2) on the matrix
+// cores.  dW[c][q][tap] = sum_n dx[n][c] * [token(n - (1 - tap)) == q] is a contraction over time of a one-hot matrix
+// (256 x n) with dx (n x 128): the A operand of lane (q, k-half) is GENERATED from eight tokens (compare + select, no
+// memory), the B operand is dx read transposed out of LDS exactly as k16_wgrad reads it.  17 GFLOP of bf16 MFMA (7 us of
+// matrix time) replace 33.5 M LDS float atomics behind scattered loads (0.19 ms + a bf16 -> fp32 conversion pass).
+// Tokens come from two padded planes ([2][B][Tp]: the token one step back / the current token of every row, -1 for the
+// first row's missing predecessor and for rows past the end of the clip, which match no q), so every load is
+// unconditional and 16-byte aligned.  Wave w: tap w >> 2, token values 64 (w & 3) .. + 63, all
+// 128 channels: 8 accumulators.  A workgroup's partial table leaves in [tap][q][c] order (coalesced); the reduce kernel
+// sums the partials in a fixed order, transposes into W's [c][q][tap] and takes the bias gradient as the sum over q of
+// tap 1 (every sample has exactly one current token).
+// =============================================================================================
+static constexpr int kEbRows = 64;
+static constexpr int kEbLds = 2 * kEbRows * 256;         // two dx stages
+
+__global__ void k16_embed_pad_tokens(const int32_t* __restrict__ idx, int32_t* __restrict__ tokp, int B, int T, int Tp) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)B * Tp) return;
+    const int b = (int)(i / Tp), t = (int)(i - (long long)b * Tp);
+    // plane 0: the token one step back (tap 0), plane 1: the current token (tap 1); -1 where the row has no such token
+    tokp[i] = (t >= 1 && t < T) ? idx[(long long)b * T + t - 1] : -1;
+    tokp[(long long)B * Tp + i] = t < T ? idx[(long long)b * T + t] : -1;
+}
+
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k16_embed_bwd(const int32_t* __restrict__ tokp, const bf16* __restrict__ dx, float* __restrict__ part, int B, int T,
+                   int Tp) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int tap = w >> 2, qw = 64 * (w & 3);
+    const int cpb = (T + kEbRows - 1) / kEbRows;
+    const int nch = B * cpb;
+    const int c_begin = (int)((long long)nch * blockIdx.x / gridDim.x);
+    const int c_end = (int)((long long)nch * (blockIdx.x + 1) / gridDim.x);
+    auto tile = [&](int buf) { return lds + buf * (kEbRows * 256); };
+    auto issue = [&](int c, int buf) {
+        const int b = c / cpb;
+        const int r0 = (c - b * cpb) * kEbRows;
+        const bf16* xb = dx + (long long)b * T * 128;
+        const int hi = T - 1;
+        dma_pieces(tile(buf), lane, w, 8, 2, [&](int r) {
+            const int t = r0 + r < hi ? r0 + r : hi;                 // ragged end: a valid row, its tokens are -1
+            return xb + (long long)t * 128;
+        });
+    };
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 tk[4][2], tkn[4][2];
+    auto load_tok = [&](int c, i32x4 (&dst)[4][2]) {
+        const int b = c / cpb;
+        const int r0 = (c - b * cpb) * kEbRows;
+        const int32_t* tp = tokp + ((long long)tap * B + b) * Tp + r0 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            dst[ks][0] = *reinterpret_cast<const i32x4*>(tp + 16 * ks);
+            dst[ks][1] = *reinterpret_cast<const i32x4*>(tp + 16 * ks + 4);
+        }
+    };
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    if (c_begin < c_end) {
+        issue(c_begin, 0);
+        load_tok(c_begin, tkn);
+    }
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { tk[ks][0] = tkn[ks][0]; tk[ks][1] = tkn[ks][1]; }
+        wait_vm<0>();
+        barrier();
+        if (c + 1 < c_end) issue(c + 1, buf ^ 1);
+        load_tok(c + 1 < c_end ? c + 1 : c, tkn);
+        const char* bt = tile(buf);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 bv[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bv[ni] = frag_tr(bt, 16 * ks, 32 * ni, lane);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int q = qw + 32 * mi + j;
+                u32x4 a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int t0 = e < 2 ? tk[ks][0][2 * e] : tk[ks][1][2 * e - 4];
+                    const int t1 = e < 2 ? tk[ks][0][2 * e + 1] : tk[ks][1][2 * e - 3];
+                    a[e] = (t0 == q ? 0x3F80u : 0u) | (t1 == q ? 0x3F800000u : 0u);     // bf16 1.0 in the low / high half
+                }
+                const bf16x8 av = __builtin_bit_cast(bf16x8, a);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+    }
+    float* o = part + (long long)blockIdx.x * (2 * 256 * 128) + (long long)tap * (256 * 128);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                o[(qw + 32 * mi + acc_row(r, h)) * 128 + 32 * ni + j] = acc[mi][ni][r];
+}
+
+// dW[c][q][tap] += sum over workgroups of part[wg][tap][q][c]; dbias[c] += sum over q of the tap-1 sums
+__global__ __launch_bounds__(256) void k16_embed_bwd_reduce(const float* __restrict__ part, int nwg, float* __restrict__ dW,
+                                                            float* __restrict__ dbias) {
+    const int q = blockIdx.x;                            // one token value per block: threads = (tap, c)
+    const int tap = threadIdx.x >> 7, c = threadIdx.x & 127;
+    const float* p = part + ((long long)tap * 256 + q) * 128 + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int g = 0;
+    for (; g + 4 <= nwg; g += 4) {
+        s0 += p[(long long)g * 65536]; s1 += p[(long long)(g + 1) * 65536];
+        s2 += p[(long long)(g + 2) * 65536]; s3 += p[(long long)(g + 3) * 65536];
+    }
+    for (; g < nwg; ++g) s0 += p[(long long)g * 65536];
+    const float v = (s0 + s1) + (s2 + s3);
+    dW[((long long)c * 256 + q) * 2 + tap] += v;
+    if (dbias && tap == 1) atomicAdd(&dbias[c], v);
+}
+
 int pack_layers(int L, const float* const* Wf, const float* const* Wg, const float* const* Wp, bf16* img, hipStream_t s) {
     if (L > kMaxProb16) { wn::set_error("w16: more than %d layers", kMaxProb16); return WN_ESHAPE; }
     PackLayersArgs a{};
@@ -646,9 +867,46 @@ int cvt_b2f(const bf16* src, float* dst, long long n, hipStream_t s) {
 }
 int embed_fwd16(const int32_t* idx, const float* W, const float* bias, bf16* out, int B, int T, int Q, int C,
                 hipStream_t s) {
-    const long long n = (long long)B * T * (C / 8);
-    hipLaunchKernelGGL(k16_embed_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, idx, W, bias, out,
-                       (long long)B * T, T, Q, C);
+    const long long N = (long long)B * T;
+    const size_t lds = (size_t)2 * Q * 64 * sizeof(float);
+    if (C % 64 == 0 && lds <= 144 * 1024 && N >= 8 * kEmbTok) {
+        static bool attr = false;
+        if (!attr) {
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k16_embed_fwd_lds),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
+            attr = true;
+        }
+        hipLaunchKernelGGL(k16_embed_fwd_lds, dim3((unsigned)((N + kEmbTok - 1) / kEmbTok), C / 64), dim3(256), lds, s, idx, W,
+                           bias, out, N, T, Q, C);
+        WN_LAUNCH_CHECK();
+        return WN_OK;
+    }
+    const long long n = N * (C / 8);
+    hipLaunchKernelGGL(k16_embed_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, idx, W, bias, out, N, T, Q, C);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+size_t embed_bwd16_ws_bytes(int B, int T) {
+    const int Tp = (T + kEbRows - 1) / kEbRows * kEbRows;
+    return (size_t)2 * B * Tp * sizeof(int32_t) + (size_t)256 * 65536 * sizeof(float) + 256;
+}
+int embed_bwd16(const int32_t* idx, const bf16* dx, float* dW, float* dbias, int B, int T, void* ws, hipStream_t s) {
+    const int Tp = (T + kEbRows - 1) / kEbRows * kEbRows;
+    int32_t* tokp = reinterpret_cast<int32_t*>(ws);
+    float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (((size_t)2 * B * Tp * sizeof(int32_t) + 255) & ~(size_t)255));
+    const long long np = (long long)B * Tp;
+    hipLaunchKernelGGL(k16_embed_pad_tokens, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, idx, tokp, B, T, Tp);
+    const int nch = B * ((T + kEbRows - 1) / kEbRows);
+    const int nwg = nch < 256 ? nch : 256;
+    static bool attr = false;
+    if (!attr) {
+        WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k16_embed_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kEbLds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k16_embed_bwd, dim3(nwg), dim3(512), kEbLds, s, tokp, dx, part, B, T, Tp);
+    hipLaunchKernelGGL(k16_embed_bwd_reduce, dim3(256), dim3(256), 0, s, part, nwg, dW, dbias);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

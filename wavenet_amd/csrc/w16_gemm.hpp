@@ -25,6 +25,7 @@ struct CG16 {
     const bf16* extra; int lde;      // [rows][..], same rows as out, column offset i * ob_col
     int relu_x;                      // relu applied to X on its way to the matrix core
     int blocks_per_b, n_blocks;      // filled by launch_cgemm
+    long long x_src_stride;          // filled by launch_cgemm: X[i] = X[0] + i * x_src_stride (the 256-block kernel)
 };
 int launch_cgemm(CG16& a, hipStream_t s);
 
@@ -48,6 +49,8 @@ int pack_layers(int L, const float* const* Wf, const float* const* Wg, const flo
 int pack_mat(int L, const float* const* src, bf16* dst, int M, int kc, int mode, hipStream_t s);
 int cvt_f2b(const float* src, bf16* dst, long long n, hipStream_t s);
 int cvt_b2f(const bf16* src, float* dst, long long n, hipStream_t s);
+size_t embed_bwd16_ws_bytes(int B, int T);
+int embed_bwd16(const int32_t* idx, const bf16* dx, float* dW, float* dbias, int B, int T, void* ws, hipStream_t s);
 int embed_fwd16(const int32_t* idx, const float* W, const float* bias, bf16* out, int B, int T, int Q, int C, hipStream_t s);
 
 // w16_layer.hip

@@ -316,8 +316,15 @@ class _Embed16Fn(_Fn):
         W, b = ctx.W, ctx.b
         B, T = idx.shape
         dout = dout.contiguous()
-        d32 = torch.empty(dout.shape, device=dout.device, dtype=torch.float32)
         lib = _lib.lib()
+        if W.shape[0] == 128 and W.shape[1] == 256 and ctx.fw == 2:
+            # one-hot contraction on the matrix cores, straight from the bf16 gradient
+            nws = lib.wn16_embed_bwd_workspace_bytes(B, T)
+            ws = torch.empty((nws,), device=dout.device, dtype=torch.uint8)
+            check(lib.wn16_embed_bwd(ptr(idx), ptr(dout), ptr(W.grad), ptr(None if b is None else b.grad), B, T,
+                                     W.shape[1], W.shape[0], ctx.fw, ptr(ws), nws, stream_ptr()), "wn16_embed_bwd")
+            return None, None, None, None, None
+        d32 = torch.empty(dout.shape, device=dout.device, dtype=torch.float32)
         check(lib.wn16_cvt_to_f32(ptr(dout), ptr(d32), dout.numel(), stream_ptr()), "wn16_cvt_to_f32")
         check(lib.wn_embed_bwd(ptr(idx), ptr(d32), ptr(W.grad), ptr(None if b is None else b.grad), B, T,
                                W.shape[1], W.shape[0], ctx.fw, ctx.net._exec(B), stream_ptr()), "wn_embed_bwd")
