@@ -251,9 +251,11 @@ int wn_mulaw_encode_pcm16(const int16_t* pcm, const int32_t* lut65536, int32_t* 
 int wn_mulaw_decode(const int32_t* tokens, const float* table, float* out, int64_t n, int Q, void* stream);
 
 /* ---- the step either side of backward ------------------------- */
-/* *out (device scalar, accumulated) += sum (grad*grad_mult + weight_decay*param)^2: the squared
- * norm GradientClipping sees after the WeightDecay hook (wavenet.py:175-199, 477-480).
- * param may be NULL when weight_decay == 0.                                                     */
+/* out[0] = sum (grad*grad_mult + weight_decay*param)^2: the squared norm GradientClipping sees after the
+ * WeightDecay hook (wavenet.py:175-199, 477-480).  out points at WN_SQNORM_WORDS floats: out[0] is ASSIGNED (no
+ * zeroing by the caller), the rest holds per-workgroup partial sums that one workgroup adds in a fixed order -- no
+ * float atomics, the norm (and with it the clipping rate) is bit-reproducible.  param may be NULL when weight_decay == 0. */
+#define WN_SQNORM_WORDS 264
 int wn_sqnorm(const float* grad, const float* param, int64_t n, float grad_mult, float weight_decay,
               float* out, void* stream);
 /* Chainer Adam with the reference's hooks folded in, in hook order:

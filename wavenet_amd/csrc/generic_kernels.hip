@@ -649,6 +649,10 @@ __global__ void k_sample(const float* __restrict__ prob, const double* __restric
 // ---------------------------------------------------------------------------------------------
 // optimiser step
 // ---------------------------------------------------------------------------------------------
+// Two launches, no atomics: block b leaves its sum in out[kNormPart + b]; one block then adds the partial sums in index
+// order and ASSIGNS out[0].  (A float atomicAdd per block made the norm -- hence the clipping rate, hence every weight --
+// depend on the order in which blocks retired: the last bit of a training step differed from run to run.)
+static constexpr int kNormPart = 8, kNormBlocks = 256;
 __global__ void k_sqnorm(const float* __restrict__ g, const float* __restrict__ p, long long n,
                          float gmult, float wd, float* __restrict__ out) {
     float acc = 0.f;
@@ -665,8 +669,14 @@ __global__ void k_sqnorm(const float* __restrict__ g, const float* __restrict__ 
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int w = 0; w < (int)(blockDim.x / 64); ++w) s += part[w];
-        atomicAdd(out, s);
+        out[kNormPart + blockIdx.x] = s;
     }
+}
+__global__ void k_sqnorm_final(float* __restrict__ out, int nb) {      // one wave
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 64) acc += out[kNormPart + i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) out[0] = acc;
 }
 
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -1091,9 +1101,10 @@ int generic_mulaw_decode(const int32_t* tok, const float* table, float* out, lon
 int generic_sqnorm(const float* g, const float* p, long long n, float gmult, float wd, float* out,
                    hipStream_t s) {
     int blocks = (int)((n + 1023) / 1024);
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > kNormBlocks) blocks = kNormBlocks;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_sqnorm, dim3(blocks), dim3(256), 0, s, g, p, n, gmult, wd, out);
+    hipLaunchKernelGGL(k_sqnorm_final, dim3(1), dim3(64), 0, s, out, blocks);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

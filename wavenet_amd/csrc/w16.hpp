@@ -55,11 +55,10 @@ __device__ __forceinline__ void dma_pieces(char* tile, int lane, int p0, int pst
 }
 
 // MFMA B operand (or A operand: same map) of lane (j, h) for k-step s of a 128-channel row tile: row j, chunk 2 s + h
-// A 16-byte LDS read through an EXPLICIT address-space-3 pointer.  A read through a generic `char*` into the dynamic LDS
-// array is also emitted as ds_read_b128, but its memory operand stays "flat" for hipcc's wait-count pass: flat accesses
-// may return out of order with LDS ones, so every wait in a loop that contains such a read is `s_waitcnt lgkmcnt(0)` --
-// a prefetched fragment set in flight is waited for together with the one being consumed (seen in the .s of every
-// kernel here that double-buffers fragments; the tr reads, whose builtin takes an LDS pointer, got counted waits).
+// A 16-byte LDS read through an explicit address-space-3 pointer.  (Note on waits: with an LDS-DMA anywhere in a loop,
+// hipcc's wait-count pass emits `s_waitcnt lgkmcnt(0)` for every LDS wait of that loop -- it treats the DMA as a flat
+// access that may return out of order with LDS reads -- so a prefetched fragment set in flight is waited for together
+// with the one being consumed; the pointer's address space makes no difference to that.)
 __device__ __forceinline__ bf16x8 lds_read16(const char* p) {
     return *(const __attribute__((address_space(3))) bf16x8*)(p);
 }

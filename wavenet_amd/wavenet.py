@@ -1005,7 +1005,7 @@ class AdamState(object):
         self.t = 0
         self.m = torch.zeros_like(net._arena)
         self.v = torch.zeros_like(net._arena)
-        self._norm = torch.zeros((1,), dtype=torch.float32)
+        self._norm = torch.zeros((_lib.SQNORM_WORDS,), dtype=torch.float32)
 
     def to(self, dev):
         self.m, self.v, self._norm = self.m.to(dev), self.v.to(dev), self._norm.to(dev)
@@ -1029,7 +1029,6 @@ class AdamState(object):
         wd = float(p.weight_decay) if p.weight_decay and p.weight_decay > 0 else 0.0
         norm_ptr = None
         if clip > 0:
-            self._norm.zero_()
             check(lib.wn_sqnorm(ptr(net._grad_arena), ptr(net._arena), n, grad_mult, wd, ptr(self._norm), st),
                   "wn_sqnorm")
             norm_ptr = ptr(self._norm)
@@ -1053,7 +1052,6 @@ class AdamState(object):
         wd = float(p.weight_decay) if p.weight_decay and p.weight_decay > 0 else 0.0
         norm_ptr = None
         if clip > 0:
-            self._norm.zero_()
             check(_lib.lib().wn_sqnorm(ptr(net._grad_arena), ptr(net._arena), net._arena.numel(), grad_mult, wd,
                                        ptr(self._norm), stream_ptr()), "wn_sqnorm")
             norm_ptr = ptr(self._norm)
@@ -1140,7 +1138,7 @@ class RuleState(object):
         # m = first state array (v / h / ms / msg), v = second (AdaDelta's msdx): the names TrainStepGraph snapshots
         self.m = torch.zeros_like(net._arena) if self.rule != 0 else torch.zeros((1,), dtype=torch.float32)
         self.v = torch.zeros_like(net._arena) if self.rule == 3 else torch.zeros((1,), dtype=torch.float32)
-        self._norm = torch.zeros((1,), dtype=torch.float32)
+        self._norm = torch.zeros((_lib.SQNORM_WORDS,), dtype=torch.float32)
 
     def to(self, dev):
         self.m, self.v, self._norm = self.m.to(dev), self.v.to(dev), self._norm.to(dev)
