@@ -184,11 +184,13 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
 
 /* ---- softmax over the channel axis (wavenet.py:592) and A14 (wavenet.py:597-617) ------------ */
 int wn_softmax_fwd(const float* logits, float* prob, int N, int Q, void* stream);
-/* *loss (device scalar) = sum over rows of -log softmax(logits[n])[target[n]] / n_norm; dlogits (may be NULL) =
+/* loss[0] = sum over rows of -log softmax(logits[n])[target[n]] / n_norm (loss points at WN_XENT_LOSS_WORDS floats: the
+ * rest holds per-workgroup sums that one workgroup adds in a fixed order -- no float atomics); dlogits (may be NULL) =
  * (softmax - onehot) / n_norm.  Rows are b*Tw + t, as after the reference's transpose(0,3,2,1) + reshape.  A row whose
  * target is -1 is ignored (no loss, zero gradient) as chainer.functions.softmax_cross_entropy does; so is any other target
  * outside [0, Q) -- nothing is read out of bounds.  n_norm = the number of rows that count (Chainer: labels != -1);
  * n_norm <= 0 means N.                                                                                            */
+#define WN_XENT_LOSS_WORDS 2056
 int wn_softmax_xent(const float* logits, const int32_t* target, float* loss, float* dlogits, int N, int Q,
                     int64_t n_norm, void* stream);
 
@@ -255,7 +257,7 @@ int wn_mulaw_decode(const int32_t* tokens, const float* table, float* out, int64
  * WeightDecay hook (wavenet.py:175-199, 477-480).  out points at WN_SQNORM_WORDS floats: out[0] is ASSIGNED (no
  * zeroing by the caller), the rest holds per-workgroup partial sums that one workgroup adds in a fixed order -- no
  * float atomics, the norm (and with it the clipping rate) is bit-reproducible.  param may be NULL when weight_decay == 0. */
-#define WN_SQNORM_WORDS 264
+#define WN_SQNORM_WORDS 1040
 int wn_sqnorm(const float* grad, const float* param, int64_t n, float grad_mult, float weight_decay,
               float* out, void* stream);
 /* Chainer Adam with the reference's hooks folded in, in hook order:

@@ -1152,29 +1152,43 @@ def test_scale_by_dev_odd_sizes():
 
 
 @pytest.mark.gpu
-def test_weight_gradients_of_the_fast_path_are_bit_reproducible():
-    """Layer, skip-projection and head weight gradients leave their kernels as per-workgroup partial tiles summed in a fixed
-    order (no float atomics): two runs on the same inputs agree bit for bit.  (The embedding table's gradient and the loss
-    still use atomics and are only reproducible to rounding.)"""
-    if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1" or os.environ.get("WAVENET_HIP_GEMM", "bf16x3") != "bf16x3":
-        pytest.skip("fast path with the default GEMM kernels only")
-    p, w, net = build(CFG2, seed=3)
+def test_training_steps_of_the_fast_path_are_bit_reproducible():
+    """No float atomics on the training path: layer, skip-projection and head weight gradients leave their kernels as
+    per-workgroup partial tiles summed in a fixed order, the embedding table's gradient is a one-hot contraction on the
+    matrix cores with a fixed-order reduction, bias gradients / the loss / the gradient norm are per-workgroup sums added
+    in index order.  Two models run the same three updates: loss, every gradient and every weight agree bit for bit."""
+    if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1":
+        pytest.skip("fast path only")
     rs = np.random.RandomState(5)
-    iw = net.input_width
-    tok = rs.randint(0, 256, size=(2, iw + 700)).astype(np.int32)
-    x, tgt = dev(tok[:, :-1]), dev(tok[:, iw:])
     runs = []
-    for _ in range(2):
-        net.zero_grads()
-        c = net.forward_causal_block(x)
-        _, s = net.forward_residual_block(c, t_off=x.shape[1] - tgt.shape[1])
-        net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt).backward()
-        runs.append({ln.name: to_np(ln.W.grad).copy() for ln in net.links()})
-    exact = [k for k in runs[0] if not k.startswith("causal")]
-    assert len(exact) > 100
-    for k in exact:
-        np.testing.assert_array_equal(runs[0][k], runs[1][k], err_msg=k)
-    assert np.abs(runs[0]["causal_0"] - runs[1]["causal_0"]).max() < 1e-6
+    for rep in range(2):
+        p, w, net = build(CFG2, seed=3, bias_scale=0.1)
+        net.update_laerning_rate(1e-3)
+        iw = net.input_width
+        if rep == 0:
+            tok = rs.randint(0, 256, size=(3, 2, iw + 700)).astype(np.int32)
+        rec = []
+        for step in range(3):
+            x, tgt = dev(tok[step][:, :-1]), dev(tok[step][:, iw:])
+            net.zero_grads()
+            c = net.forward_causal_block(x)
+            _, s = net.forward_residual_block(c, t_off=x.shape[1] - tgt.shape[1])
+            loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt)
+            net.backprop(loss)
+            g = {}
+            for ln in net.links():
+                g[ln.name + "/W"] = to_np(ln.W.grad).copy()
+                if ln.b is not None:
+                    g[ln.name + "/b"] = to_np(ln.b.grad).copy()
+            rec.append((to_np(loss).copy(), g, {k: v.copy() for k, v in net.state_dict().items()}))
+        runs.append(rec)
+    assert len(runs[0][0][1]) > 160
+    for (l0, g0, w0), (l1, g1, w1) in zip(*runs):
+        assert l0.tobytes() == l1.tobytes()
+        for k in g0:
+            np.testing.assert_array_equal(g0[k], g1[k], err_msg="gradient " + k)
+        for k in w0:
+            np.testing.assert_array_equal(w0[k], w1[k], err_msg="weight " + k)
 
 
 @pytest.mark.gpu

@@ -11,7 +11,8 @@ from typing import Dict, Optional, Sequence, Tuple
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwavenet_hip.so")
 ABI_VERSION = 2
-SQNORM_WORDS = 264           # WN_SQNORM_WORDS: out[0] + per-workgroup partial sums of wn_sqnorm
+XENT_LOSS_WORDS = 2056      # WN_XENT_LOSS_WORDS: loss[0] + per-workgroup sums of wn_softmax_xent
+SQNORM_WORDS = 1040          # WN_SQNORM_WORDS: out[0] + per-workgroup partial sums of wn_sqnorm
 
 WN_ACT_NONE, WN_ACT_RELU, WN_ACT_ELU = 0, 1, 2
 ACT = {"none": WN_ACT_NONE, None: WN_ACT_NONE, "relu": WN_ACT_RELU, "elu": WN_ACT_ELU}

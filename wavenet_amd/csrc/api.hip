@@ -41,6 +41,7 @@ const unsigned* exec_absmax(const float* x, long long n, hipStream_t s) {
     g_absmax_key[g_absmax_n] = x;
     return slots + g_absmax_n++;
 }
+bool exec_has_scratch(size_t bytes) { return g_exec && g_exec->ws && g_exec->ws_bytes >= bytes + kExecTail; }
 void* exec_scratch(size_t bytes, const char* what) {
     bytes += kExecTail;
     if (!g_exec || !g_exec->ws || g_exec->ws_bytes < bytes) {
@@ -376,12 +377,19 @@ size_t wn_exec_workspace_bytes(const WnStackDesc* d, int Q, int causal_channels,
     const size_t image = 12 * mk + (64u << 10);             // 6 KB per 32 x 32 tile, twice in gate mode, + the 128/128 Wp image
     const size_t nB = B > 0 ? (size_t)B : 1;
     const size_t parts = (256 + nB * ((nprob + 7) / 8) + 64) * (8 * 8 * 16 * 64) * sizeof(float);
+    // embedding gradient: 256 per-workgroup tables (+ the bias sums, + two padded token planes of the one-hot form)
     const size_t tables = causal_channels > 0
-                              ? (size_t)256 * ((size_t)Q * causal_fw * causal_channels + causal_channels) * sizeof(float)
+                              ? (size_t)257 * ((size_t)Q * causal_fw * causal_channels + causal_channels) * sizeof(float) +
+                                    (size_t)2 * nB * ((size_t)(T > 0 ? T : 0) + 128) * sizeof(int32_t) + 1024
                               : 0;
+    // bias gradients: one row of column sums per 256-row chunk (at most 2,048 chunks)
+    size_t maxm = Q > 0 ? (size_t)Q : 0;
+    if (d && d->n_layers > 0) maxm = maxm > (size_t)d->Cs ? maxm : (size_t)d->Cs;
+    for (int i = 0; i < n_head_channels; ++i) maxm = maxm > (size_t)head_channels[i] ? maxm : (size_t)head_channels[i];
+    const size_t colsums = (size_t)2048 * (maxm > 512 ? maxm : 512) * sizeof(float);
     size_t need = image > parts ? image : parts;
     if (tables > need) need = tables;
-    (void)T;
+    if (colsums > need) need = colsums;
     return ((need + 4095) & ~(size_t)4095) + 4096;
 }
 

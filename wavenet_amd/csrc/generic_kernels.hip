@@ -7,7 +7,8 @@
 #include "wn_common.hpp"
 
 namespace wn {
-void* exec_scratch(size_t bytes, const char* what);       // api.hip: the current call's WnExec scratch
+void* exec_scratch(size_t bytes, const char* what);
+bool exec_has_scratch(size_t bytes);       // api.hip: the current call's WnExec scratch
 
 static constexpr int kThreads = 256;
 
@@ -263,8 +264,10 @@ static int launch_wgrad(WgradArgs a, hipStream_t s) {
 }
 
 // column sums:  out[m] += sum_b sum_{t in [tmin,nT)} A(b,t,m)
+// part != NULL: block (x, y) leaves its sums in part[y][m] and k_colsum_reduce adds the blocks in index order (no float
+// atomics: bit-reproducible bias gradients); part == NULL (no WnExec scratch): one atomic per block and column.
 __global__ void k_colsum(const float* __restrict__ A, long long a_bs, int a_t0, int lda, int nB,
-                         int tmin, int nT, int M, float* __restrict__ out, int t_chunk) {
+                         int tmin, int nT, int M, float* __restrict__ out, int t_chunk, float* __restrict__ part_out) {
     // blockDim = (64 columns, 4 row lanes)
     __shared__ float part[4][64];
     int m = blockIdx.x * 64 + threadIdx.x;
@@ -276,8 +279,23 @@ __global__ void k_colsum(const float* __restrict__ A, long long a_bs, int a_t0, 
         for (int t = t0 + threadIdx.y; t < t1; t += 4) acc += A[(long long)b * a_bs + (long long)(a_t0 + t) * lda + m];
     part[threadIdx.y][threadIdx.x] = acc;
     __syncthreads();
-    if (threadIdx.y == 0 && m < M)
-        atomicAdd(&out[m], part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+    if (threadIdx.y == 0 && m < M) {
+        const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (part_out) part_out[(long long)blockIdx.y * M + m] = v;
+        else atomicAdd(&out[m], v);
+    }
+}
+__global__ void k_colsum_reduce(const float* __restrict__ part, int ny, int M, float* __restrict__ out) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int y = 0;
+    for (; y + 4 <= ny; y += 4) {
+        s0 += part[(long long)y * M + m]; s1 += part[(long long)(y + 1) * M + m];
+        s2 += part[(long long)(y + 2) * M + m]; s3 += part[(long long)(y + 3) * M + m];
+    }
+    for (; y < ny; ++y) s0 += part[(long long)y * M + m];
+    out[m] += (s0 + s1) + (s2 + s3);
 }
 
 static int launch_colsum(const float* A, long long a_bs, int a_t0, int lda, int nB, int tmin, int nT,
@@ -285,8 +303,13 @@ static int launch_colsum(const float* A, long long a_bs, int a_t0, int lda, int 
     if (nT <= tmin || nB <= 0) return WN_OK;
     int t_chunk = 256;
     int nchunk = (nT - tmin + t_chunk - 1) / t_chunk;
+    while ((long long)nB * nchunk > 2048) { t_chunk *= 2; nchunk = (nT - tmin + t_chunk - 1) / t_chunk; }
     dim3 grid(cdiv(M, 64), nB * nchunk);
-    hipLaunchKernelGGL(k_colsum, grid, dim3(64, 4), 0, s, A, a_bs, a_t0, lda, nB, tmin, nT, M, out, t_chunk);
+    float* part = exec_has_scratch((size_t)grid.y * M * sizeof(float))
+                      ? reinterpret_cast<float*>(exec_scratch((size_t)grid.y * M * sizeof(float), "column-sum partials"))
+                      : nullptr;
+    hipLaunchKernelGGL(k_colsum, grid, dim3(64, 4), 0, s, A, a_bs, a_t0, lda, nB, tmin, nT, M, out, t_chunk, part);
+    if (part) hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(M, 256)), dim3(256), 0, s, part, (int)grid.y, M, out);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }
@@ -531,6 +554,15 @@ __global__ void k_softmax(const float* __restrict__ logits, float* __restrict__ 
     for (int q = lane; q < Q; q += 64) prob[row * Q + q] = expf(r[q] - m) * inv;
 }
 
+// loss[0] = (sum of the per-block sums, in block order) / n_norm: no float atomics, the loss is bit-reproducible
+static constexpr int kXentPart = 8, kXentBlocks = 2048;
+__global__ void k_xent_final(float* __restrict__ loss, int nb, long long n_norm) {      // one wave
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 64) acc += loss[kXentPart + i];
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) loss[0] = acc / (float)n_norm;
+}
+
 __global__ void k_softmax_xent(const float* __restrict__ logits, const int32_t* __restrict__ target,
                                float* __restrict__ loss, float* __restrict__ dlogits, long long N, int Q, long long n_norm) {
     // one wave per row; rows of up to 256 logits live in registers (one float4 per lane).  Waves stride
@@ -587,10 +619,10 @@ __global__ void k_softmax_xent(const float* __restrict__ logits, const int32_t* 
     }
     if (lane == 0) part[threadIdx.x / 64] = rl_acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {                            // this block's sum; k_xent_final adds the blocks in index order
         float s = 0.f;
         for (int w = 0; w < (int)(blockDim.x / 64); ++w) s += part[w];
-        atomicAdd(loss, s / (float)n_norm);
+        loss[kXentPart + blockIdx.x] = s;
     }
 }
 
@@ -652,7 +684,7 @@ __global__ void k_sample(const float* __restrict__ prob, const double* __restric
 // Two launches, no atomics: block b leaves its sum in out[kNormPart + b]; one block then adds the partial sums in index
 // order and ASSIGNS out[0].  (A float atomicAdd per block made the norm -- hence the clipping rate, hence every weight --
 // depend on the order in which blocks retired: the last bit of a training step differed from run to run.)
-static constexpr int kNormPart = 8, kNormBlocks = 256;
+static constexpr int kNormPart = 8, kNormBlocks = 1024;
 __global__ void k_sqnorm(const float* __restrict__ g, const float* __restrict__ p, long long n,
                          float gmult, float wd, float* __restrict__ out) {
     float acc = 0.f;
@@ -800,8 +832,22 @@ int generic_embed_fwd(const int32_t* idx, const float* W, const float* bias, flo
     return WN_OK;
 }
 
+}  // namespace wn
+namespace w16 {   // w16_gemm.hip: the table gradient as a one-hot contraction on the matrix cores
+size_t embed_bwd_ws_bytes(int B, int T, int C);
+int embed_bwd_mfma(const int32_t* idx, const __bf16* dx, const float* dx_f32, int C, float* dW, float* dbias, int B, int T,
+                   void* ws, hipStream_t s);
+}
+namespace wn {
+
 int generic_embed_bwd(const int32_t* idx, const float* dout, float* dW, float* dbias, int B, int T,
                       int Q, int C, int fw, hipStream_t s) {
+    // filter width 2, 256 token values, 32 / 64 / 128 channels (every BASELINE config): matrix cores, fixed summation
+    // order (bit-reproducible); anything else, or no scratch: per-block tables in LDS
+    if (fw == 2 && Q == 256 && (C == 32 || C == 64 || C == 128) && exec_has_scratch(w16::embed_bwd_ws_bytes(B, T, C))) {
+        void* ws = exec_scratch(w16::embed_bwd_ws_bytes(B, T, C), "the embedding-gradient partial tables");
+        return w16::embed_bwd_mfma(idx, nullptr, dout, C, dW, dbias, B, T, ws, s);
+    }
     int Cs = C;                                            // channel slice whose table fits in LDS
     while (((size_t)Q * fw * Cs + Cs) * sizeof(float) > 150 * 1024 && Cs % 2 == 0 && Cs > 8) Cs /= 2;
     size_t lds = ((size_t)Q * fw * Cs + Cs) * sizeof(float);
@@ -1031,11 +1077,11 @@ int generic_softmax(const float* logits, float* prob, long long N, int Q, hipStr
 
 int generic_softmax_xent(const float* logits, const int32_t* target, float* loss, float* dlogits, long long N,
                          int Q, long long n_norm, hipStream_t s) {
-    WN_HIP(hipMemsetAsync(loss, 0, sizeof(float), s));
     int blocks = cdiv(N, 4);
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > kXentBlocks) blocks = kXentBlocks;
     hipLaunchKernelGGL(k_softmax_xent, dim3(blocks), dim3(256), 0, s, logits, target, loss, dlogits, N, Q,
                        n_norm > 0 ? n_norm : N);
+    hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(64), 0, s, loss, blocks, n_norm > 0 ? n_norm : N);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

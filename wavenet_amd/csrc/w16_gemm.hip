@@ -818,22 +818,138 @@ void k16_embed_bwd(const int32_t* __restrict__ tokp, const bf16* __restrict__ dx
                 o[(qw + 32 * mi + acc_row(r, h)) * 128 + 32 * ni + j] = acc[mi][ni][r];
 }
 
-// dW[c][q][tap] += sum over workgroups of part[wg][tap][q][c]; dbias[c] += sum over q of the tap-1 sums
-__global__ __launch_bounds__(256) void k16_embed_bwd_reduce(const float* __restrict__ part, int nwg, float* __restrict__ dW,
-                                                            float* __restrict__ dbias) {
+// dW[c][q][tap] += sum over workgroups (in index order) of part[wg][tap][q][c]; the tap-1 sums also go to bsum[q][c],
+// from which k16_embed_bias takes dbias[c] += sum over q (every sample has exactly one current token) -- no atomics.
+__global__ void k16_embed_bwd_reduce(const float* __restrict__ part, int nwg, int C, float* __restrict__ dW,
+                                     float* __restrict__ bsum) {
     const int q = blockIdx.x;                            // one token value per block: threads = (tap, c)
-    const int tap = threadIdx.x >> 7, c = threadIdx.x & 127;
-    const float* p = part + ((long long)tap * 256 + q) * 128 + c;
+    const int tap = threadIdx.x / C, c = threadIdx.x - tap * C;
+    const long long wgs = 2ll * 256 * C;
+    const float* p = part + ((long long)tap * 256 + q) * C + c;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int g = 0;
     for (; g + 4 <= nwg; g += 4) {
-        s0 += p[(long long)g * 65536]; s1 += p[(long long)(g + 1) * 65536];
-        s2 += p[(long long)(g + 2) * 65536]; s3 += p[(long long)(g + 3) * 65536];
+        s0 += p[g * wgs]; s1 += p[(g + 1) * wgs];
+        s2 += p[(g + 2) * wgs]; s3 += p[(g + 3) * wgs];
     }
-    for (; g < nwg; ++g) s0 += p[(long long)g * 65536];
+    for (; g < nwg; ++g) s0 += p[g * wgs];
     const float v = (s0 + s1) + (s2 + s3);
     dW[((long long)c * 256 + q) * 2 + tap] += v;
-    if (dbias && tap == 1) atomicAdd(&dbias[c], v);
+    if (bsum && tap == 1) bsum[q * C + c] = v;
+}
+__global__ void k16_embed_bias(const float* __restrict__ bsum, int C, float* __restrict__ dbias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int q = 0; q < 256; ++q) s += bsum[q * C + c];
+    dbias[c] += s;
+}
+
+// The same contraction for an fp32 gradient (the fp32-storage path: 32 NC channels): dx is split into three bf16 parts
+// (h + m + l = x to 2^-24) on its way into LDS, the one-hot operand is exact, so the three MFMAs per tile reproduce the
+// fp32 sum to rounding -- and, unlike per-block tables filled with LDS float atomics, in a fixed order.
+template <int NC>
+__global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k16_embed_bwd_f32(const int32_t* __restrict__ tokp, const float* __restrict__ dx, float* __restrict__ part, int B,
+                       int T, int Tp) {
+    constexpr int C = 32 * NC;
+    __shared__ __attribute__((aligned(1024))) char lds[3 * kEbRows * 256];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int tap = w >> 2, qw = 64 * (w & 3);
+    const int cpb = (T + kEbRows - 1) / kEbRows;
+    const int nch = B * cpb;
+    const int c_begin = (int)((long long)nch * blockIdx.x / gridDim.x);
+    const int c_end = (int)((long long)nch * (blockIdx.x + 1) / gridDim.x);
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    float4 xv[NC];
+    i32x4 tkn[4][2];
+    auto fetch = [&](int c) {
+        const int b = c / cpb;
+        const int r0 = (c - b * cpb) * kEbRows;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int i = threadIdx.x + 512 * k;
+            const int row = i / (C / 4), c4 = i - row * (C / 4);
+            const int t = r0 + row < T - 1 ? r0 + row : T - 1;      // ragged end: a valid row, its tokens are -1
+            xv[k] = *reinterpret_cast<const float4*>(dx + ((long long)b * T + t) * C + 4 * c4);
+        }
+        const int32_t* tp = tokp + ((long long)tap * B + b) * Tp + r0 + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            tkn[ks][0] = *reinterpret_cast<const i32x4*>(tp + 16 * ks);
+            tkn[ks][1] = *reinterpret_cast<const i32x4*>(tp + 16 * ks + 4);
+        }
+    };
+    f32x16 acc[2][NC];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NC; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    if (c_begin < c_end) fetch(c_begin);
+    for (int c = c_begin; c < c_end; ++c) {
+        i32x4 tk[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { tk[ks][0] = tkn[ks][0]; tk[ks][1] = tkn[ks][1]; }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {                   // split this stage's values into the three planes
+            const int i = threadIdx.x + 512 * k;
+            const int row = i / (C / 4), c4 = i - row * (C / 4);
+            const float v[4] = {xv[k].x, xv[k].y, xv[k].z, xv[k].w};
+            bf16x4 ph, pm, pl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bf16 hh = (bf16)v[e];
+                const float r1 = v[e] - (float)hh;
+                const bf16 mm = (bf16)r1;
+                ph[e] = hh; pm[e] = mm; pl[e] = (bf16)(r1 - (float)mm);
+            }
+            const int o = toff(row, (4 * c4) >> 3) + 2 * ((4 * c4) & 7);
+            *reinterpret_cast<bf16x4*>(lds + o) = ph;
+            *reinterpret_cast<bf16x4*>(lds + kEbRows * 256 + o) = pm;
+            *reinterpret_cast<bf16x4*>(lds + 2 * kEbRows * 256 + o) = pl;
+        }
+        __syncthreads();
+        fetch(c + 1 < c_end ? c + 1 : c);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 bv[3][NC];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int ni = 0; ni < NC; ++ni) bv[pl][ni] = frag_tr(lds + pl * kEbRows * 256, 16 * ks, 32 * ni, lane);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int q = qw + 32 * mi + j;
+                u32x4 a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int t0 = e < 2 ? tk[ks][0][2 * e] : tk[ks][1][2 * e - 4];
+                    const int t1 = e < 2 ? tk[ks][0][2 * e + 1] : tk[ks][1][2 * e - 3];
+                    a[e] = (t0 == q ? 0x3F80u : 0u) | (t1 == q ? 0x3F800000u : 0u);
+                }
+                const bf16x8 av = __builtin_bit_cast(bf16x8, a);
+#pragma unroll
+                for (int ni = 0; ni < NC; ++ni) {            // smallest parts first
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[2][ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[1][ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[0][ni], acc[mi][ni], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* o = part + (long long)blockIdx.x * (2 * 256 * C) + (long long)tap * (256 * C);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NC; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                o[(qw + 32 * mi + acc_row(r, h)) * C + 32 * ni + j] = acc[mi][ni][r];
 }
 
 int pack_layers(int L, const float* const* Wf, const float* const* Wg, const float* const* Wp, bf16* img, hipStream_t s) {
@@ -887,28 +1003,51 @@ int embed_fwd16(const int32_t* idx, const float* W, const float* bias, bf16* out
     return WN_OK;
 }
 
-size_t embed_bwd16_ws_bytes(int B, int T) {
+static size_t embed_tok_bytes(int B, int T) {
     const int Tp = (T + kEbRows - 1) / kEbRows * kEbRows;
-    return (size_t)2 * B * Tp * sizeof(int32_t) + (size_t)256 * 65536 * sizeof(float) + 256;
+    return ((size_t)2 * B * Tp * sizeof(int32_t) + 255) & ~(size_t)255;
 }
-int embed_bwd16(const int32_t* idx, const bf16* dx, float* dW, float* dbias, int B, int T, void* ws, hipStream_t s) {
+size_t embed_bwd_ws_bytes(int B, int T, int C) {
+    return embed_tok_bytes(B, T) + (size_t)256 * 2 * 256 * C * sizeof(float) + (size_t)256 * C * sizeof(float) + 256;
+}
+size_t embed_bwd16_ws_bytes(int B, int T) { return embed_bwd_ws_bytes(B, T, 128); }
+
+// dx: bf16 (B,T,128) when dx_f32 == NULL, else fp32 (B,T,C) with C = 32, 64, 96 or 128
+int embed_bwd_mfma(const int32_t* idx, const bf16* dx, const float* dx_f32, int C, float* dW, float* dbias, int B, int T,
+                   void* ws, hipStream_t s) {
     const int Tp = (T + kEbRows - 1) / kEbRows * kEbRows;
     int32_t* tokp = reinterpret_cast<int32_t*>(ws);
-    float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (((size_t)2 * B * Tp * sizeof(int32_t) + 255) & ~(size_t)255));
+    float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + embed_tok_bytes(B, T));
     const long long np = (long long)B * Tp;
     hipLaunchKernelGGL(k16_embed_pad_tokens, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, idx, tokp, B, T, Tp);
     const int nch = B * ((T + kEbRows - 1) / kEbRows);
     const int nwg = nch < 256 ? nch : 256;
-    static bool attr = false;
-    if (!attr) {
-        WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k16_embed_bwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   kEbLds));
-        attr = true;
+    float* bsum = dbias ? part + (size_t)nwg * 2 * 256 * C : nullptr;
+    if (!dx_f32) {
+        static bool attr = false;
+        if (!attr) {
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k16_embed_bwd),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kEbLds));
+            attr = true;
+        }
+        hipLaunchKernelGGL(k16_embed_bwd, dim3(nwg), dim3(512), kEbLds, s, tokp, dx, part, B, T, Tp);
+    } else if (C == 32) {
+        hipLaunchKernelGGL(k16_embed_bwd_f32<1>, dim3(nwg), dim3(512), 0, s, tokp, dx_f32, part, B, T, Tp);
+    } else if (C == 64) {
+        hipLaunchKernelGGL(k16_embed_bwd_f32<2>, dim3(nwg), dim3(512), 0, s, tokp, dx_f32, part, B, T, Tp);
+    } else if (C == 128) {
+        hipLaunchKernelGGL(k16_embed_bwd_f32<4>, dim3(nwg), dim3(512), 0, s, tokp, dx_f32, part, B, T, Tp);
+    } else {
+        wn::set_error("embed_bwd_mfma: %d channels", C);
+        return WN_ESHAPE;
     }
-    hipLaunchKernelGGL(k16_embed_bwd, dim3(nwg), dim3(512), kEbLds, s, tokp, dx, part, B, T, Tp);
-    hipLaunchKernelGGL(k16_embed_bwd_reduce, dim3(256), dim3(256), 0, s, part, nwg, dW, dbias);
+    hipLaunchKernelGGL(k16_embed_bwd_reduce, dim3(256), dim3(2 * C), 0, s, part, nwg, C, dW, bsum);
+    if (dbias) hipLaunchKernelGGL(k16_embed_bias, dim3((C + 63) / 64), dim3(64), 0, s, bsum, C, dbias);
     WN_LAUNCH_CHECK();
     return WN_OK;
+}
+int embed_bwd16(const int32_t* idx, const bf16* dx, float* dW, float* dbias, int B, int T, void* ws, hipStream_t s) {
+    return embed_bwd_mfma(idx, dx, nullptr, 128, dW, dbias, B, T, ws, s);
 }
 
 }  // namespace w16

@@ -50,6 +50,9 @@ int pack_mat(int L, const float* const* src, bf16* dst, int M, int kc, int mode,
 int cvt_f2b(const float* src, bf16* dst, long long n, hipStream_t s);
 int cvt_b2f(const bf16* src, float* dst, long long n, hipStream_t s);
 size_t embed_bwd16_ws_bytes(int B, int T);
+size_t embed_bwd_ws_bytes(int B, int T, int C);
+int embed_bwd_mfma(const int32_t* idx, const bf16* dx, const float* dx_f32, int C, float* dW, float* dbias, int B, int T,
+                   void* ws, hipStream_t s);
 int embed_bwd16(const int32_t* idx, const bf16* dx, float* dW, float* dbias, int B, int T, void* ws, hipStream_t s);
 int embed_fwd16(const int32_t* idx, const float* W, const float* bias, bf16* out, int B, int T, int Q, int C, hipStream_t s);
 

@@ -46,6 +46,7 @@ struct ExecScope {
 };
 int gemm_mode();                       // WN_GEMM_* of the current call (WN_GEMM_FP32 under WAVENET_HIP_FORCE_GENERIC=1)
 void* exec_scratch(size_t bytes, const char* what);   // the caller's scratch; NULL + error text when it is too small
+bool exec_has_scratch(size_t bytes);                    // whether the current call brought that much
 // Device word holding the bits of max |x[i]| (a positive float orders like an unsigned): one pass per array and entry-point
 // call, shared by the launchers below it (the word lives in the last 256 bytes of the caller's scratch); NULL + error text
 // when there is no scratch.  Used by the fp16 split (WN_GEMM_FP16X2) to scale operands whose range is not known in advance.

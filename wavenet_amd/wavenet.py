@@ -220,12 +220,12 @@ class _XentFn(_Fn):
     @staticmethod
     def forward(ctx, logits, target, n_norm=0):
         N, Q = logits.shape
-        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        buf = torch.empty((_lib.XENT_LOSS_WORDS,), device=logits.device, dtype=torch.float32)
         dlog = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
-        check(_lib.lib().wn_softmax_xent(ptr(logits), ptr(target), ptr(loss), ptr(dlog), N, Q, int(n_norm), stream_ptr()),
+        check(_lib.lib().wn_softmax_xent(ptr(logits), ptr(target), ptr(buf), ptr(dlog), N, Q, int(n_norm), stream_ptr()),
               "wn_softmax_xent")
         ctx.dlog = dlog
-        return loss
+        return buf[0]                                               # 0-dim view: buf[1:] are the per-workgroup sums
 
     @staticmethod
     def backward(ctx, dloss):
