@@ -189,6 +189,75 @@ static constexpr int kCMaxBlocks = 256;
 #define WN_LDS_DMA16(src, dst) \
     __builtin_amdgcn_global_load_lds((src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
+// ---- fp16 x 2 split products for the weight-gradient contractions (H2W) ------------------------------------------------
+// The 80 fp32 MFMAs per tile that contract over time (dWf, dWg: [da; dg] x [x[t-d]; x[t]], dWp: dout x z) are half of the
+// kernel's matrix time (5,120 of 10,240 cycles per tile).  Their operands already sit in registers with 16 time steps
+// per lane (rows 2 s + h), which is exactly an f16 MFMA operand pair (k-step ks, element e <-> s = 8 ks + e): each fp32
+// value v s is split into two fp16 parts h + m (22 bits), a product is the three terms m h' + h m' + h h' of
+// v_mfma_f32_32x32x16_f16 (32 cycles for K = 16 against 64 for K = 2): 30 MFMAs = 960 cycles per tile.  The scale s is a
+// power of two chosen PER TILE from the wave's own maximum (gradients: max over da, dg, dout; inputs: max over x[t],
+// x[t-d]; z = tanh sigmoid: 2^12), so that nothing overflows fp16 and the parts lost to fp16's subnormals are below
+// 2^-24 of the tile's maximum; a tile's product leaves the matrix core in its own scale and joins the running fp32
+// accumulator with one fma per element.  Selected by WnExec.precision == WN_GEMM_FP16X2; any other precision keeps
+// the exact-fp32 MFMAs.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+struct H2Op { h16x8 h[2], m[2]; };
+__device__ __forceinline__ float lb_dpp(float v, int which) {
+    int r;
+    switch (which) {
+        case 1: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false); break;
+        case 2: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false); break;
+        case 4: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, false); break;
+        case 8: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, false); break;
+        case 15: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false); break;
+        default: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false); break;
+    }
+    return __int_as_float(r);
+}
+// max over the wave of a non-negative value, uniform
+__device__ __forceinline__ float lb_wave_max(float v) {
+    v = fmaxf(v, lb_dpp(v, 1));
+    v = fmaxf(v, lb_dpp(v, 2));
+    v = fmaxf(v, lb_dpp(v, 4));
+    v = fmaxf(v, lb_dpp(v, 8));
+    v = fmaxf(v, lb_dpp(v, 15));
+    v = fmaxf(v, lb_dpp(v, 31));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// power of two s with s * mx in [2^14, 2^15) (mx = 0 or denormal: the largest finite power of two), and 1 / s
+__device__ __forceinline__ void lb_pow2_scale(float mx, float& s, float& inv) {
+    const int e = (__float_as_int(mx) >> 23) & 0xff;           // biased exponent of mx
+    int f = 268 - e;                                           // 127 + 14 - (e - 127)
+    f = f > 254 ? 254 : (f < 1 ? 1 : f);
+    s = __int_as_float(f << 23);
+    inv = __int_as_float((254 - f) << 23);                     // f = 254: 0 (the tile is all zeros or denormals)
+}
+__device__ __forceinline__ void lb_split16(const float (&v)[16], float s, H2Op& o) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xs = v[8 * ks + e] * s;
+            const _Float16 hh = (_Float16)xs;
+            o.h[ks][e] = hh;
+            o.m[ks][e] = (_Float16)(xs - (float)hh);
+        }
+}
+__device__ __forceinline__ void lb_h2_product(const H2Op& a, const H2Op& b, float u, f32x16& acc) {
+    f32x16 t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {                           // smallest terms first
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.m[ks], b.h[ks], t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[ks], b.m[ks], t, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.h[ks], b.h[ks], t, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = fmaf(t[r], u, acc[r]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_layer_bwd_chainsp: one workgroup of 4 waves per CU (one wave per SIMD, 512 registers, 148 KB of LDS), software-
 // pipelined: the loop body holds the 80 weight-gradient MFMAs of tile n (operands already in registers) AND the whole
@@ -213,7 +282,7 @@ static constexpr int kCMaxBlocks = 256;
 // ---------------------------------------------------------------------------------------------
 // FROM_Z: the forward saved z and sigmoid only; `f` points at z and tanh is recovered as z / sigmoid (z = tanh * sigmoid was
 // rounded once in fp32, so the quotient is tanh to ~1.2e-7 relative; where sigmoid underflowed, da and dg are 0 anyway).
-template <bool HAS_DO, bool HAS_U, bool HAS_DZ, bool FROM_Z>
+template <bool HAS_DO, bool HAS_U, bool HAS_DZ, bool FROM_Z, bool H2W>
 __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
     const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
@@ -458,6 +527,36 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
         }
     };
     auto wgrad = [&](const WOps& w) {
+        if constexpr (H2W) {
+            float mg = 0.f, mx = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                mg = fmaxf(fmaxf(mg, fabsf(w.a_da[s])), fmaxf(fabsf(w.a_dg[s]), (HAS_DO || HAS_U) ? fabsf(w.a_do[s]) : 0.f));
+                mx = fmaxf(mx, fmaxf(fabsf(w.b_xc[s]), fabsf(w.b_xo[s])));
+            }
+            mg = lb_wave_max(mg);
+            mx = lb_wave_max(mx);
+            float sg, ig, sx, ix;
+            lb_pow2_scale(mg, sg, ig);
+            lb_pow2_scale(mx, sx, ix);
+            H2Op oda, odg, oxc, oxo;
+            lb_split16(w.a_da, sg, oda);
+            lb_split16(w.a_dg, sg, odg);
+            lb_split16(w.b_xc, sx, oxc);
+            lb_split16(w.b_xo, sx, oxo);
+            const float u = ig * ix;
+            lb_h2_product(oda, oxc, u, aWf1);
+            lb_h2_product(oda, oxo, u, aWf0);
+            lb_h2_product(odg, oxc, u, aWg1);
+            lb_h2_product(odg, oxo, u, aWg0);
+            if (HAS_DO || HAS_U) {
+                H2Op odo, oz;
+                lb_split16(w.a_do, sg, odo);
+                lb_split16(w.b_z, 4096.f, oz);
+                lb_h2_product(odo, oz, ig * (1.f / 4096.f), aWp);
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             aWf1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w.a_da[s], w.b_xc[s], aWf1, 0, 0, 0);
@@ -735,6 +834,7 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
                          const float* Wp, const float* Vin, const float* Uin, int dU, int vu_t0, const float* dzs,
                          int dz_t0, float* Vout, float* Uout, float* part, int B, int T, int d, int Z, int t_live,
                          int* nwg, hipStream_t s, bool from_z) {
+    const bool h2w = gemm_mode() == WN_GEMM_FP16X2;           // weight-gradient contractions on fp16 x 2 split products
     const int tiles_all = (T + 31) / 32;
     const int tile_lo = t_live > 0 ? t_live / 32 : 0;
     const int tiles_per_b = tiles_all - tile_lo;
@@ -746,17 +846,22 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
     int blocks = (ntiles + kCWaves - 1) / kCWaves;
     if (blocks > kCMaxBlocks) blocks = kCMaxBlocks;
     if (nwg) *nwg = blocks;
-#define CH_LAUNCH2(DO, UU, DZ, FZ)                                                                                 \
+#define CH_LAUNCH3(DO, UU, DZ, FZ, HW)                                                                             \
     do {                                                                                                           \
         static bool attr_set = false;                                                                              \
         if (!attr_set) {                                                                                           \
-            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chainsp<DO, UU, DZ, FZ>),         \
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chainsp<DO, UU, DZ, FZ, HW>),     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kCLdsBytes));                   \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL((k_layer_bwd_chainsp<DO, UU, DZ, FZ>), dim3(blocks), dim3(64 * kCWaves), kCLdsBytes, s, x, f, \
-                           g, Wp, Wf, Wg, Vin, Uin, dU, vu_t0, dzs, dz_t0, Vout, Uout, part, B, T, d, Z, tile_lo,  \
+        hipLaunchKernelGGL((k_layer_bwd_chainsp<DO, UU, DZ, FZ, HW>), dim3(blocks), dim3(64 * kCWaves), kCLdsBytes, s, x, \
+                           f, g, Wp, Wf, Wg, Vin, Uin, dU, vu_t0, dzs, dz_t0, Vout, Uout, part, B, T, d, Z, tile_lo, \
                            tiles_per_b, ntiles);                                                                   \
+    } while (0)
+#define CH_LAUNCH2(DO, UU, DZ, FZ)                            \
+    do {                                                      \
+        if (h2w) CH_LAUNCH3(DO, UU, DZ, FZ, true);            \
+        else CH_LAUNCH3(DO, UU, DZ, FZ, false);               \
     } while (0)
 #define CH_LAUNCH(DO, UU, DZ)                                 \
     do {                                                      \
@@ -775,6 +880,7 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
     }
 #undef CH_LAUNCH
 #undef CH_LAUNCH2
+#undef CH_LAUNCH3
     WN_LAUNCH_CHECK();
     return WN_OK;
 }
