@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
 
     // first half of a tile: everything up to the patches in its slot group; the V/U rows come back in registers
     // (vv, uu) and are stored by the caller.  `grp` holds the tile's f, g, V, U (landed).
+    float w_inv = 1.f;                                 // H2W: 1 / (the weight images' power-of-two scale)
     float vv[16], uu[16];
     auto phase_a = [&](int tile, float* grp, const float4 (&dz4)[4]) {
         float* tf = grp;
@@ -430,9 +431,37 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
             dob[4 * q] = o4.x; dob[4 * q + 1] = o4.y; dob[4 * q + 2] = o4.z; dob[4 * q + 3] = o4.w;
         }
         if (HAS_DO || HAS_U) {
+            if constexpr (H2W) {
+                // dz += Wp^T dout: the lane's 16 channels of dout are an f16 operand pair as they stand (k-step ks, element
+                // e <-> s = 8 ks + e); Wp's image in LDS is pre-split in the same channel order
+                float md = 0.f;
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lWp[bch(s, h) * 32 + j], dob[s], acc, 0, 0, 0);
+                for (int s = 0; s < 16; ++s) md = fmaxf(md, fabsf(dob[s]));
+                md = lb_wave_max(md);
+                float sd, id;
+                lb_pow2_scale(md, sd, id);
+                H2Op od;
+                lb_split16(dob, sd, od);
+                f32x16 t;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = 0.f;
+                const char* ip = reinterpret_cast<const char*>(dyn) + 16384 + lane * 16;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const h16x8 ah = *reinterpret_cast<const h16x8*>(ip + (ks * 2 + 0) * 1024);
+                    const h16x8 am = *reinterpret_cast<const h16x8*>(ip + (ks * 2 + 1) * 1024);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(am, od.h[ks], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, od.m[ks], t, 0, 0, 0);
+                    t = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, od.h[ks], t, 0, 0, 0);
+                }
+                const float u = id * w_inv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = fmaf(t[r], u, acc[r]);
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lWp[bch(s, h) * 32 + j], dob[s], acc, 0, 0, 0);
+            }
         }
         const bool live = valid && t >= Z;
         float da[16], dg[16], zz[16];
@@ -449,16 +478,53 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
             dg[r] = dz * ff[r] * gg[r] * (1.f - gg[r]);
         }
         f32x16 v1, u0;
+        if constexpr (H2W) {
+            // V = dout + [Wf1; Wg1]^T [da; dg], U = [Wf0; Wg0]^T [da; dg]: 24 f16 MFMAs for 64 fp32 ones
+            float mg = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { v1[r] = dob[r]; u0[r] = 0.f; }
+            for (int s = 0; s < 16; ++s) mg = fmaxf(mg, fmaxf(fabsf(da[s]), fabsf(dg[s])));
+            mg = lb_wave_max(mg);
+            float sg, ig;
+            lb_pow2_scale(mg, sg, ig);
+            H2Op oa, og;
+            lb_split16(da, sg, oa);
+            lb_split16(dg, sg, og);
+            f32x16 tv, tu;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float2 wf = *reinterpret_cast<const float2*>(lWf + (bch(s, h) * 32 + j) * 2);
-            const float2 wg = *reinterpret_cast<const float2*>(lWg + (bch(s, h) * 32 + j) * 2);
-            v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, da[s], v1, 0, 0, 0);
-            u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, da[s], u0, 0, 0, 0);
-            v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.y, dg[s], v1, 0, 0, 0);
-            u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.x, dg[s], u0, 0, 0, 0);
+            for (int r = 0; r < 16; ++r) { tv[r] = 0.f; tu[r] = 0.f; }
+            const char* ib = reinterpret_cast<const char*>(dyn) + lane * 16;      // image (mat, tap, ks, part) at 1 KB steps
+#pragma unroll
+            for (int mat = 0; mat < 2; ++mat) {
+                const H2Op& ob = mat == 0 ? oa : og;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const h16x8 a0h = *reinterpret_cast<const h16x8*>(ib + ((((mat * 2 + 0) * 2 + ks) * 2) + 0) * 1024);
+                    const h16x8 a0m = *reinterpret_cast<const h16x8*>(ib + ((((mat * 2 + 0) * 2 + ks) * 2) + 1) * 1024);
+                    const h16x8 a1h = *reinterpret_cast<const h16x8*>(ib + ((((mat * 2 + 1) * 2 + ks) * 2) + 0) * 1024);
+                    const h16x8 a1m = *reinterpret_cast<const h16x8*>(ib + ((((mat * 2 + 1) * 2 + ks) * 2) + 1) * 1024);
+                    tv = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1m, ob.h[ks], tv, 0, 0, 0);
+                    tu = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0m, ob.h[ks], tu, 0, 0, 0);
+                    tv = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, ob.m[ks], tv, 0, 0, 0);
+                    tu = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, ob.m[ks], tu, 0, 0, 0);
+                    tv = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1h, ob.h[ks], tv, 0, 0, 0);
+                    tu = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0h, ob.h[ks], tu, 0, 0, 0);
+                }
+            }
+            const float u = ig * w_inv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { v1[r] = fmaf(tv[r], u, dob[r]); u0[r] = tu[r] * u; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { v1[r] = dob[r]; u0[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float2 wf = *reinterpret_cast<const float2*>(lWf + (bch(s, h) * 32 + j) * 2);
+                const float2 wg = *reinterpret_cast<const float2*>(lWg + (bch(s, h) * 32 + j) * 2);
+                v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.y, da[s], v1, 0, 0, 0);
+                u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf.x, da[s], u0, 0, 0, 0);
+                v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.y, dg[s], v1, 0, 0, 0);
+                u0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wg.x, dg[s], u0, 0, 0, 0);
+            }
         }
         // V, U through the (consumed) V/U slots into row order
 #pragma unroll
@@ -581,12 +647,55 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     const bool any = first < last;
     bool stores_in_flight = false;                     // the last eight vector-memory operations are unconditional V/U stores
     if (any) { fetch_a(first, pbase, dza); fetch_x(first, xc, xo); }
+    if constexpr (H2W) {
+        // fp16 x 2 images of the three weight matrices in A-operand order: 1 KB per (matrix, tap, k-step, part), lane
+        // (j, h) element e = W[cd = bch(8 ks + e, h)][cr = j][tap] (Wp: [cr = bch(..)][cd = j]) scaled by one power of two
+        // taken from the largest weight of the layer (every workgroup sees all of them: 20 values per thread)
+        float mw = 0.f;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        reinterpret_cast<float4*>(lWf)[threadIdx.x + k * kThreads] = s_wf[k];
-        reinterpret_cast<float4*>(lWg)[threadIdx.x + k * kThreads] = s_wg[k];
+        for (int k = 0; k < 2; ++k) {
+            mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wf[k].x), fabsf(s_wf[k].y)), fmaxf(fabsf(s_wf[k].z), fabsf(s_wf[k].w))));
+            mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wg[k].x), fabsf(s_wg[k].y)), fmaxf(fabsf(s_wg[k].z), fabsf(s_wg[k].w))));
+        }
+        mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wp.x), fabsf(s_wp.y)), fmaxf(fabsf(s_wp.z), fabsf(s_wp.w))));
+        mw = lb_wave_max(mw);
+        float* red = wbase + kCWaves * kCWaveFloats - 8;           // last 32 bytes of the slot area: free until tile data lands there
+        if (lane == 0) red[wv] = mw;
+        __syncthreads();
+        mw = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float sw;
+        lb_pow2_scale(mw, sw, w_inv);
+        __syncthreads();
+        char* img = reinterpret_cast<char*>(dyn);
+        auto put = [&](int mat_tap, int kidx, int jj, float v) {      // kidx: the contraction channel, jj: the output row
+            const int hh = (kidx >> 2) & 1, ks = kidx >> 4, e = (kidx & 3) + 4 * ((kidx >> 3) & 1);
+            const float xs = v * sw;
+            const _Float16 hv = (_Float16)xs;
+            const _Float16 mv = (_Float16)(xs - (float)hv);
+            char* dst = img + ((mat_tap * 2 + ks) * 2) * 1024 + (hh * 32 + jj) * 16 + e * 2;
+            *reinterpret_cast<_Float16*>(dst) = hv;
+            *reinterpret_cast<_Float16*>(dst + 1024) = mv;
+        };
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e0 = (threadIdx.x + k * kThreads) * 4;        // flat index into W[cd][cr][tap]
+            const int cd = e0 >> 6, cr = (e0 >> 1) & 31;
+            put(0, cd, cr, s_wf[k].x); put(1, cd, cr, s_wf[k].y); put(0, cd, cr + 1, s_wf[k].z); put(1, cd, cr + 1, s_wf[k].w);
+            put(2, cd, cr, s_wg[k].x); put(3, cd, cr, s_wg[k].y); put(2, cd, cr + 1, s_wg[k].z); put(3, cd, cr + 1, s_wg[k].w);
+        }
+        {
+            const int e0 = threadIdx.x * 4;                           // flat index into Wp[cr][cd]
+            const int cr = e0 >> 5, cd = e0 & 31;
+            put(4, cr, cd, s_wp.x); put(4, cr, cd + 1, s_wp.y); put(4, cr, cd + 2, s_wp.z); put(4, cr, cd + 3, s_wp.w);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            reinterpret_cast<float4*>(lWf)[threadIdx.x + k * kThreads] = s_wf[k];
+            reinterpret_cast<float4*>(lWg)[threadIdx.x + k * kThreads] = s_wg[k];
+        }
+        reinterpret_cast<float4*>(lWp)[threadIdx.x] = s_wp;
     }
-    reinterpret_cast<float4*>(lWp)[threadIdx.x] = s_wp;
     __syncthreads();                                   // (also drains vmcnt: the first tile has landed)
     if (any) {
         if (first + stride < last) fetch_a(first + stride, pbase + 4096, dzb);
