@@ -19,6 +19,7 @@
 // Per tile: 64 + 16 MFMAs (5120 SIMD cycles); 2 KB + 2 KB of x read, 4 KB out + 4 KB z written.
 #include <cstdlib>
 
+#include "h2_ops.hpp"
 #include "wn_kernels.hpp"
 
 namespace wn {
@@ -298,6 +299,226 @@ __global__ __launch_bounds__(256, 4) void k_layer_fwd_mfma32_t1(
         for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(out + row + 8 * q) = make_float4(ao[4 * q], ao[4 * q + 1], ao[4 * q + 2], ao[4 * q + 3]);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same layer on fp16 x 2 split products (WnExec.precision == WN_GEMM_FP16X2, no conv / projection biases):
+// 30 v_mfma_f32_32x32x16_f16 per tile (960 SIMD cycles) instead of 80 fp32 MFMAs (5,120).  Nothing about the data
+// layout changes: a lane's 16 channels of x[t] (ch(s, h), s = 0..15) are an f16 operand pair as they stand (k-step ks,
+// element e <-> s = 8 ks + e), the accumulator register r still holds channel ch(r, h), so z feeds the projection
+// from registers and x[t] is added to its result in place.  x is scaled per tile by the power of two that brings the
+// wave's own maximum below 2^15, z = tanh sigmoid by 2^12; the weights arrive as pre-split images in A-operand order
+// (k_layer_pack_h2: one launch for all layers of a stack, scale = a power of two from the layer's largest weight).
+// Image of a layer: 1 KB per (matrix-tap mt, k-step ks, part): lane (j, hh) element e =
+//     mt 0..3 (Wf tap 0, Wf tap 1, Wg tap 0, Wg tap 1):  W[cd = j][cr = ch(8 ks + e, hh)][tap]
+//     mt 4 (Wp):                                         Wp[cr = j][cd = ch(8 ks + e, hh)]
+// followed by 1 / scale.
+// ---------------------------------------------------------------------------------------------
+static constexpr int kH2ImgBytes = 20 * 1024;
+static constexpr int kH2ImgStride = kH2ImgBytes + 256;      // + the inverse scale
+
+struct PackH2Args { const float* Wf[64]; const float* Wg[64]; const float* Wp[64]; };
+__global__ __launch_bounds__(256) void k_layer_pack_h2(PackH2Args a, char* __restrict__ img_all) {
+    const int l = blockIdx.x;
+    const float* Wf = a.Wf[l];
+    const float* Wg = a.Wg[l];
+    const float* Wp = a.Wp[l];
+    char* img = img_all + (size_t)l * kH2ImgStride;
+    float4 s_wf[2], s_wg[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        s_wf[k] = reinterpret_cast<const float4*>(Wf)[threadIdx.x + k * 256];
+        s_wg[k] = reinterpret_cast<const float4*>(Wg)[threadIdx.x + k * 256];
+    }
+    const float4 s_wp = reinterpret_cast<const float4*>(Wp)[threadIdx.x];
+    float mw = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wf[k].x), fabsf(s_wf[k].y)), fmaxf(fabsf(s_wf[k].z), fabsf(s_wf[k].w))));
+        mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wg[k].x), fabsf(s_wg[k].y)), fmaxf(fabsf(s_wg[k].z), fabsf(s_wg[k].w))));
+    }
+    mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wp.x), fabsf(s_wp.y)), fmaxf(fabsf(s_wp.z), fabsf(s_wp.w))));
+    mw = lb_wave_max(mw);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mw;
+    __syncthreads();
+    mw = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sw, iw;
+    lb_pow2_scale(mw, sw, iw);
+    if (threadIdx.x == 0) *reinterpret_cast<float*>(img + kH2ImgBytes) = iw;
+    auto put = [&](int mt, int kidx, int jj, float v) {          // kidx: the contraction channel, jj: the output row
+        const int hh = (kidx >> 2) & 1, ks = kidx >> 4, e = (kidx & 3) + 4 * ((kidx >> 3) & 1);
+        const float xs = v * sw;
+        const _Float16 hv = (_Float16)xs;
+        const _Float16 mv = (_Float16)(xs - (float)hv);
+        char* dst = img + ((mt * 2 + ks) * 2) * 1024 + (hh * 32 + jj) * 16 + e * 2;
+        *reinterpret_cast<_Float16*>(dst) = hv;
+        *reinterpret_cast<_Float16*>(dst + 1024) = mv;
+    };
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e0 = (threadIdx.x + k * 256) * 4;                 // flat index into W[cd][cr][tap]
+        const int cd = e0 >> 6, cr = (e0 >> 1) & 31;
+        put(0, cr, cd, s_wf[k].x); put(1, cr, cd, s_wf[k].y); put(0, cr + 1, cd, s_wf[k].z); put(1, cr + 1, cd, s_wf[k].w);
+        put(2, cr, cd, s_wg[k].x); put(3, cr, cd, s_wg[k].y); put(2, cr + 1, cd, s_wg[k].z); put(3, cr + 1, cd, s_wg[k].w);
+    }
+    {
+        const int e0 = threadIdx.x * 4;                               // flat index into Wp[cr][cd]
+        const int cr = e0 >> 5, cd = e0 & 31;
+        put(4, cd, cr, s_wp.x); put(4, cd + 1, cr, s_wp.y); put(4, cd + 2, cr, s_wp.z); put(4, cd + 3, cr, s_wp.w);
+    }
+}
+
+template <int SAVE>
+__global__ __launch_bounds__(256, 4) void k_layer_fwd_h2_t1(
+    const float* __restrict__ x, const char* __restrict__ img_g, float* __restrict__ out, float* __restrict__ zout,
+    float* __restrict__ fout, float* __restrict__ gout, int B, int T, int d, int Z, int tile_lo, int tiles_per_b,
+    int ntiles) {
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int wg = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int tile = wg * 4 + wv;
+    const bool tvalid = tile < ntiles;
+    const int tl = tvalid ? tile : ntiles - 1;
+    const int b = tl / tiles_per_b;
+    const int t = (tile_lo + tl - b * tiles_per_b) * 32 + j;
+    const bool valid = tvalid && t < T;
+    const int tc = t < T ? t : T - 1;
+
+    __shared__ __attribute__((aligned(16))) char img[kH2ImgBytes];
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t stage[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) stage[k] = reinterpret_cast<const u32x4_t*>(img_g)[threadIdx.x + 256 * k];
+    const float w_inv = *reinterpret_cast<const float*>(img_g + kH2ImgBytes);
+    float xc[16], xo[16];
+    {
+        const long long rowc = ((long long)b * T + tc) * 32 + 4 * h;
+        const long long rowo = ((long long)b * T + (tc - d >= 0 ? tc - d : 0)) * 32 + 4 * h;
+        const float mc = valid ? 1.f : 0.f, mo = (valid && t - d >= 0) ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(x + rowc + 8 * q);
+            const float4 o = *reinterpret_cast<const float4*>(x + rowo + 8 * q);
+            xc[4 * q + 0] = v.x * mc; xc[4 * q + 1] = v.y * mc; xc[4 * q + 2] = v.z * mc; xc[4 * q + 3] = v.w * mc;
+            xo[4 * q + 0] = o.x * mo; xo[4 * q + 1] = o.y * mo; xo[4 * q + 2] = o.z * mo; xo[4 * q + 3] = o.w * mo;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) reinterpret_cast<u32x4_t*>(img)[threadIdx.x + 256 * k] = stage[k];
+    __syncthreads();
+
+    float mx = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) mx = fmaxf(mx, fmaxf(fabsf(xc[s]), fabsf(xo[s])));
+    mx = lb_wave_max(mx);
+    float sx, ix;
+    lb_pow2_scale(mx, sx, ix);
+    H2Op oc, oo;
+    lb_split16(xc, sx, oc);
+    lb_split16(xo, sx, oo);
+    f32x16 aa, ag;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { aa[r] = 0.f; ag[r] = 0.f; }
+    const char* ib = img + lane * 16;
+    auto frag = [&](int mt, int ks, int part) {
+        return *reinterpret_cast<const h16x8*>(ib + ((mt * 2 + ks) * 2 + part) * 1024);
+    };
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int tap = 0; tap < 2; ++tap) {
+            const H2Op& ob = tap == 0 ? oo : oc;                     // tap 0 multiplies x[t - d]
+            const h16x8 fh = frag(tap, ks, 0), fm = frag(tap, ks, 1);
+            const h16x8 gh = frag(2 + tap, ks, 0), gm = frag(2 + tap, ks, 1);
+            aa = __builtin_amdgcn_mfma_f32_32x32x16_f16(fm, ob.h[ks], aa, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(gm, ob.h[ks], ag, 0, 0, 0);
+            aa = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, ob.m[ks], aa, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, ob.m[ks], ag, 0, 0, 0);
+            aa = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, ob.h[ks], aa, 0, 0, 0);
+            ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, ob.h[ks], ag, 0, 0, 0);
+        }
+    }
+    const float uc = ix * w_inv;
+    const bool live = t >= Z;
+    const long long row = ((long long)b * T + t) * 32 + 4 * h;
+    float zz[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float f4[4], g4[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int r = 4 * q + m;
+            f4[m] = fast_tanh(live ? aa[r] * uc : 0.f);
+            g4[m] = fast_sigmoid(live ? ag[r] * uc : 0.f);
+            zz[r] = f4[m] * g4[m];
+        }
+        if (valid) {
+            if (SAVE == 1) *reinterpret_cast<float4*>(fout + row + 8 * q) = make_float4(f4[0], f4[1], f4[2], f4[3]);
+            if (SAVE >= 1) *reinterpret_cast<float4*>(gout + row + 8 * q) = make_float4(g4[0], g4[1], g4[2], g4[3]);
+            *reinterpret_cast<float4*>(zout + row + 8 * q) = make_float4(zz[4 * q], zz[4 * q + 1], zz[4 * q + 2], zz[4 * q + 3]);
+        }
+    }
+    H2Op oz;
+    lb_split16(zz, 4096.f, oz);
+    f32x16 ao;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ao[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const h16x8 ph = frag(4, ks, 0), pm = frag(4, ks, 1);
+        ao = __builtin_amdgcn_mfma_f32_32x32x16_f16(pm, oz.h[ks], ao, 0, 0, 0);
+        ao = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, oz.m[ks], ao, 0, 0, 0);
+        ao = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, oz.h[ks], ao, 0, 0, 0);
+    }
+    const float up = w_inv * (1.f / 4096.f);
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(out + row + 8 * q) =
+                make_float4(fmaf(ao[4 * q], up, xc[4 * q]), fmaf(ao[4 * q + 1], up, xc[4 * q + 1]),
+                            fmaf(ao[4 * q + 2], up, xc[4 * q + 2]), fmaf(ao[4 * q + 3], up, xc[4 * q + 3]));
+    }
+}
+
+size_t mfma_layer_h2_image_bytes(int L) { return (size_t)L * kH2ImgStride; }
+
+// images of L layers (Cr = Cd = 32, fw = 2) into img: one launch
+int mfma_layer_pack_h2(int L, const float* const* Wf, const float* const* Wg, const float* const* Wp, void* img,
+                       hipStream_t s) {
+    WN_CHECK_SHAPE(L >= 1 && L <= 64, "mfma_layer_pack_h2: 1..64 layers per call");
+    PackH2Args a{};
+    for (int l = 0; l < L; ++l) { a.Wf[l] = Wf[l]; a.Wg[l] = Wg[l]; a.Wp[l] = Wp[l]; }
+    hipLaunchKernelGGL(k_layer_pack_h2, dim3(L), dim3(256), 0, s, a, reinterpret_cast<char*>(img));
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+// layer l of a packed stack; only the one-tile-per-wave form exists (small launches take the fp32 kernel)
+bool mfma_layer_fwd_h2_ok(int B, int T, int t_live) {
+    const int tile_lo = t_live > 0 ? t_live / 32 : 0;
+    const long long nt = (long long)B * ((T + 31) / 32 - tile_lo);
+    return nt >= 4 * 512 && nt < (1ll << 31);
+}
+int mfma_layer_fwd_h2(const float* x, const void* img, int l, float* out, float* z, float* fs, float* gs, int B, int T,
+                      int d, int Z, int t_live, hipStream_t s) {
+    const int tile_lo = t_live > 0 ? t_live / 32 : 0;
+    const int tiles_per_b = (T + 31) / 32 - tile_lo;
+    const int ntiles = B * tiles_per_b;
+    const int blocks = (ntiles + 3) / 4;
+    const char* im = reinterpret_cast<const char*>(img) + (size_t)l * kH2ImgStride;
+#define FWDH_LAUNCH(SAVE)                                                                                        \
+    hipLaunchKernelGGL((k_layer_fwd_h2_t1<SAVE>), dim3(blocks), dim3(256), 0, s, x, im, out, z, fs, gs, B, T, d, Z, \
+                       tile_lo, tiles_per_b, ntiles)
+    if (fs) FWDH_LAUNCH(1);
+    else if (gs) FWDH_LAUNCH(2);
+    else FWDH_LAUNCH(0);
+#undef FWDH_LAUNCH
+    WN_LAUNCH_CHECK();
+    return WN_OK;
 }
 
 bool mfma_layer_supported(int Cr, int Cd, int fw) { return Cr == 32 && Cd == 32 && fw == 2; }

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "h2_ops.hpp"
 #include "wn_kernels.hpp"
 
 namespace wn {
@@ -200,49 +201,6 @@ static constexpr int kCMaxBlocks = 256;
 // 2^-24 of the tile's maximum; a tile's product leaves the matrix core in its own scale and joins the running fp32
 // accumulator with one fma per element.  Selected by WnExec.precision == WN_GEMM_FP16X2; any other precision keeps
 // the exact-fp32 MFMAs.
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-struct H2Op { h16x8 h[2], m[2]; };
-__device__ __forceinline__ float lb_dpp(float v, int which) {
-    int r;
-    switch (which) {
-        case 1: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false); break;
-        case 2: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false); break;
-        case 4: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, false); break;
-        case 8: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, false); break;
-        case 15: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false); break;
-        default: r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false); break;
-    }
-    return __int_as_float(r);
-}
-// max over the wave of a non-negative value, uniform
-__device__ __forceinline__ float lb_wave_max(float v) {
-    v = fmaxf(v, lb_dpp(v, 1));
-    v = fmaxf(v, lb_dpp(v, 2));
-    v = fmaxf(v, lb_dpp(v, 4));
-    v = fmaxf(v, lb_dpp(v, 8));
-    v = fmaxf(v, lb_dpp(v, 15));
-    v = fmaxf(v, lb_dpp(v, 31));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-// power of two s with s * mx in [2^14, 2^15) (mx = 0 or denormal: the largest finite power of two), and 1 / s
-__device__ __forceinline__ void lb_pow2_scale(float mx, float& s, float& inv) {
-    const int e = (__float_as_int(mx) >> 23) & 0xff;           // biased exponent of mx
-    int f = 268 - e;                                           // 127 + 14 - (e - 127)
-    f = f > 254 ? 254 : (f < 1 ? 1 : f);
-    s = __int_as_float(f << 23);
-    inv = __int_as_float((254 - f) << 23);                     // f = 254: 0 (the tile is all zeros or denormals)
-}
-__device__ __forceinline__ void lb_split16(const float (&v)[16], float s, H2Op& o) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float xs = v[8 * ks + e] * s;
-            const _Float16 hh = (_Float16)xs;
-            o.h[ks][e] = hh;
-            o.m[ks][e] = (_Float16)(xs - (float)hh);
-        }
-}
 __device__ __forceinline__ void lb_h2_product(const H2Op& a, const H2Op& b, float u, f32x16& acc) {
     f32x16 t;
 #pragma unroll

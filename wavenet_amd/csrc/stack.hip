@@ -91,12 +91,31 @@ int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, floa
             }
         }
     }
+    // fp16 x 2 split products (WN_GEMM_FP16X2): 32-channel layers without conv / projection biases run the f16-MFMA form
+    // of the fused kernel on weight images split once for the whole stack (into the call's scratch: the skip
+    // contraction re-uses it after the last layer)
+    const void* h2img = nullptr;
+    if (gemm_mode() == WN_GEMM_FP16X2 && L <= 64 && d->Cr == 32 && d->fw == 2 &&
+        exec_has_scratch(mfma_layer_h2_image_bytes(L))) {
+        bool ok = true;
+        for (int l = 0; l < L && ok; ++l)
+            ok = d->cd[l] == 32 && !(d->bf && d->bf[l]) && !(d->bg && d->bg[l]) && !(d->bp && d->bp[l]);
+        if (ok) {
+            void* img = exec_scratch(mfma_layer_h2_image_bytes(L), "the fp16 x 2 layer weight images");
+            if ((rc = mfma_layer_pack_h2(L, d->Wf, d->Wg, d->Wp, img, as_stream(stream)))) return rc;
+            h2img = img;
+        }
+    }
     {
         wn::ProfGroup prof_layers__("wn_layer_fwd", stream);     // one bracket around the L launches
         for (int l = 0; l < L; ++l) {
             float* out = xs + (size_t)l * n * d->Cr;
             int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
-            if (live[l] > 0 || g_only) {
+            if (h2img && mfma_layer_fwd_h2_ok(B, T, live[l])) {
+                wn::ProfScope prof__("wn_layer_fwd", stream);
+                rc = mfma_layer_fwd_h2(in, h2img, l, out, z + zoff, f ? f + zoff : nullptr, g ? g + zoff : nullptr, B, T,
+                                       d->dilation[l], Z, live[l], as_stream(stream));
+            } else if (live[l] > 0 || g_only) {
                 wn::ProfScope prof__("wn_layer_fwd", stream);
                 rc = mfma_layer_fwd(in, d->Wf[l], d->bf ? d->bf[l] : nullptr, d->Wg[l], d->bg ? d->bg[l] : nullptr,
                                     d->Wp[l], d->bp ? d->bp[l] : nullptr, out, z + zoff, f ? f + zoff : nullptr,

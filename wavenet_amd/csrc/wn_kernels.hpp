@@ -61,6 +61,12 @@ int generic_adam(float* p, const float* g, float* m, float* v, long long n, floa
 
 // ---- mfma_layer.hip: fp32-MFMA fused residual layer, Cr = Cd = 32, fw = 2 -------------------
 bool mfma_layer_supported(int Cr, int Cd, int fw);
+size_t mfma_layer_h2_image_bytes(int L);
+int mfma_layer_pack_h2(int L, const float* const* Wf, const float* const* Wg, const float* const* Wp, void* img,
+                       hipStream_t s);
+bool mfma_layer_fwd_h2_ok(int B, int T, int t_live);
+int mfma_layer_fwd_h2(const float* x, const void* img, int l, float* out, float* z, float* fs, float* gs, int B, int T,
+                      int d, int Z, int t_live, hipStream_t s);
 int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg,
                    const float* Wp, const float* bp, float* out, float* z, float* fs, float* gs, int B, int T,
                    int d, int Z, int t_live, hipStream_t s);
