@@ -333,7 +333,7 @@ def main():
         def pmc_bytes(names):
             got = [pmc[k]["hbm_bytes_per_launch"] for k in names if k in pmc]
             return float(sum(got)) if got else None
-        fb = pmc_bytes(["wn::k_layer_fwd_mfma32_t1<0, false>", "wn::k_layer_fwd_mfma32_t1<false, false>"])
+        fb = pmc_bytes(["wn::k_layer_fwd_h2_t1<0>"]) or pmc_bytes(["wn::k_layer_fwd_mfma32_t1<0, false>", "wn::k_layer_fwd_mfma32_t1<false, false>"])
         if fb:
             out["stack_forward"]["layer_traffic_bytes"] = fb
             out["stack_forward"]["layer_traffic_frac"] = fb / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
@@ -349,9 +349,10 @@ def main():
         units = {
             # name: (bound, algorithmic amount per launch, launches per step, kernels for PMC traffic)
             "wn_layer_bwd": ("hbm", es * (3 * Cr + Cs + 2 * Cd) * n_col, nl,
-                             ["wn::k_layer_bwd_chainsp<true, true, true, true>", "wn::k_layer_bwd_chainsp<true, true, true>"]),
+                             ["wn::k_layer_bwd_chainsp<true, true, true, true, true>", "wn::k_layer_bwd_chainsp<true, true, true, true, false>",
+                              "wn::k_layer_bwd_chainsp<true, true, true, true>", "wn::k_layer_bwd_chainsp<true, true, true>"]),
             "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl,
-                             ["wn::k_layer_fwd_mfma32_t1<2, false>", "wn::k_layer_fwd_mfma32_t1<true, false>"]),
+                             ["wn::k_layer_fwd_h2_t1<2>", "wn::k_layer_fwd_mfma32_t1<2, false>", "wn::k_layer_fwd_mfma32_t1<true, false>"]),
             "wn_skip_sum_fwd": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<0, 0, 3, 4>", "wn::k_colgemm_b3<0, 0, 6, 4>", "wn::k_colgemm_b3<0, 0, false, 4>"]),
             "wn_skip_sum_bwd_dw": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_wgrad_b3w<false, 0, 3>", "wn::k_wgrad_b3w<false, 0, 6>", "wn::k_wgrad_b3w<false, 0, false>"]),
             "wn_skip_sum_bwd_dz": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<2, 0, 3, 4>", "wn::k_colgemm_b3<2, 0, 6, 4>", "wn::k_colgemm_b3<2, 0, false, 4>"]),
@@ -366,18 +367,21 @@ def main():
                 break
         # flops one launch of the dominant unit really executes (fp32 MFMA in the layer kernels)
         layer_flops = {"wn_layer_bwd": 2 * 2 * (2 * 2 * Cr * Cd + Cd * Cr) * n_col, "wn_layer_fwd": 2 * (2 * 2 * Cr * Cd + Cd * Cr) * n_col}
+        # matrix peak of the fused layer kernels: fp32 MFMA, or three f16 MFMAs per product under fp16x2
+        layer_peak = 2500.0 / 3.0 if _lib.get_gemm_precision() == "fp16x2" else F32_MFMA_PEAK_TF
         if bound == "hbm":
             ach = amount / (launch_ms * 1e-3) / 1e9
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": launch_ms,
                                "algorithmic_bytes_per_launch": amount,
                                "traffic_frac": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                               "mfma_frac": layer_flops.get(dom, 0) / (launch_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TF,
+                               "mfma_frac": layer_flops.get(dom, 0) / (launch_ms * 1e-3) / 1e12 / layer_peak,
+                               "mfma_peak_TFLOPs": layer_peak,
                                "note": "frac: SURVEY 8(d)'s algorithmic bytes (1,664 B per sample-layer for the backward, "
                                        "1,024 B of them the per-layer dskip read that the deferred skip sum never "
                                        "performs) / launch time / 8 TB/s; traffic_frac: HBM bytes MEASURED by the PMC "
-                                       "passes in profiles/ / launch time / 8 TB/s; mfma_frac: fp32 MFMA flops of the "
-                                       "launch / time / 157.3 TFLOP/s"}
+                                       "passes in profiles/ / launch time / 8 TB/s; mfma_frac: fp32-equivalent flops of the "
+                                       "launch / time / mfma_peak_TFLOPs (157.3 fp32 MFMA; 833 = 2.5 PF / 3 with fp16x2 split products)"}
         else:
             ach = amount / (launch_ms * 1e-3) / 1e12
             peak = {"fp32": F32_MFMA_PEAK_TF, "fp16x2": 2500.0 / 3.0}.get(_lib.get_gemm_precision(), BF16X3_PEAK_TF)

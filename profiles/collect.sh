@@ -4,7 +4,7 @@
 # 1. kernel trace + stats of the default bench command (graph-replayed timed region + op-by-op profiled pass)
 # 2./3. PMC FETCH_SIZE and WRITE_SIZE in their own passes (--kernel-trace only, as the pool requires), op-by-op launches,
 #       config 2 (the headline) and config 5 (--wide-only) in the same passes
-# 4. PMC matrix-core pass: SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE, SQ_INSTS_VALU_MFMA_MOPS_{BF16,F32}
+# 4. PMC matrix-core pass: SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE, SQ_INSTS_VALU_MFMA_MOPS_{BF16,F16,F32}
 # Every pass runs under `timeout`: a profiler pass that hangs must not take the box with it.
 # Results land in gpurun_out/prof_<tag>/ ; the summaries are copied to profiles/ by hand afterwards.
 set -u
@@ -21,7 +21,7 @@ for C in fetch:FETCH_SIZE write:WRITE_SIZE; do
   timeout 420 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/$D -o bench -- python3 $ROOT/bench.py $PMCARGS > /dev/null 2> $OUT/$D.log
   timeout 420 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/${D}_wide -o bench -- python3 $ROOT/bench.py $WIDEARGS > /dev/null 2> $OUT/${D}_wide.log
 done
-MF="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32"
+MF="SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_F32"
 timeout 420 rocprofv3 --kernel-trace --pmc $MF --output-format csv -d $OUT/mfma -o bench -- python3 $ROOT/bench.py $PMCARGS > /dev/null 2> $OUT/mfma.log
 timeout 420 rocprofv3 --kernel-trace --pmc $MF --output-format csv -d $OUT/mfma_wide -o bench -- python3 $ROOT/bench.py $WIDEARGS > /dev/null 2> $OUT/mfma_wide.log
 cd $ROOT

@@ -58,6 +58,7 @@ def traffic(fetch_csv, write_csv, out):
 def mfma(pmc_csv, out):
     busy, act = load(pmc_csv, "SQ_VALU_MFMA_BUSY_CYCLES"), load(pmc_csv, "GRBM_GUI_ACTIVE")
     bf16, f32 = load(pmc_csv, "SQ_INSTS_VALU_MFMA_MOPS_BF16"), load(pmc_csv, "SQ_INSTS_VALU_MFMA_MOPS_F32")
+    f16 = load(pmc_csv, "SQ_INSTS_VALU_MFMA_MOPS_F16")
     res = {}
     for name in sorted(busy):
         b, a = biggest(busy[name]), biggest(act.get(name, []) or busy[name])
@@ -68,7 +69,7 @@ def mfma(pmc_csv, out):
         bsy = sum(v for v, _ in b[:n]) / n
         ent = {"launches_averaged": n, "mfma_busy_cycles": bsy, "active_cycles": cyc,
                "mfma_util": bsy / (cyc * 1024.0) if cyc > 0 else None, "avg_ns_under_pmc": sum(ns for _, ns in b[:n]) / n}
-        for key, rows in (("bf16", bf16.get(name)), ("f32", f32.get(name))):
+        for key, rows in (("bf16", bf16.get(name)), ("f16", f16.get(name)), ("f32", f32.get(name))):
             if rows:
                 bb = biggest(rows)
                 ent["mfma_flops_%s" % key] = 512.0 * sum(v for v, _ in bb) / len(bb)
@@ -76,8 +77,9 @@ def mfma(pmc_csv, out):
     json.dump({"note": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); flops = MOPS x 512",
                "kernels": res}, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["avg_ns_under_pmc"]):
-        print("%-56s util %5.1f %%   %8.1f us   %.3g bf16 flop  %.3g f32 flop" % (
-            k[:56], 100 * (v["mfma_util"] or 0), v["avg_ns_under_pmc"] / 1e3, v.get("mfma_flops_bf16", 0), v.get("mfma_flops_f32", 0)))
+        print("%-56s util %5.1f %%   %8.1f us   %.3g bf16 flop  %.3g f16 flop  %.3g f32 flop" % (
+            k[:56], 100 * (v["mfma_util"] or 0), v["avg_ns_under_pmc"] / 1e3, v.get("mfma_flops_bf16", 0),
+            v.get("mfma_flops_f16", 0), v.get("mfma_flops_f32", 0)))
 
 
 if __name__ == "__main__":
