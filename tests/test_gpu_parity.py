@@ -1284,3 +1284,46 @@ def test_fp16x2_split_follows_the_gradient_range(scale):
         got = to_np(net._grad_arena[off:off + n].view(shape))
         assert np.isfinite(got).all()
         assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-30), (ln.name, kind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("xscale", [2.0 ** 9, 1.0, 2.0 ** -12])
+def test_fp16x2_layer_kernels_follow_the_activation_range(xscale):
+    """Under WN_GEMM_FP16X2 the fused 32-channel layer kernels (forward and chained backward) run on f16 MFMAs with
+    power-of-two scales taken per tile from the wave's own maximum: a residual stream 512 times larger or 4,096 times smaller
+    than usual (the embedding table scaled) gives loss and gradients to the same 1e-4 bar.  Sized so that the launches
+    take the one-tile-per-wave forward (>= 512 workgroups) without any environment override."""
+    if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1":
+        pytest.skip("generic kernels only")
+    over = dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 3, residual_num_blocks=2,
+                softmax_conv_channels=[256, 256])
+    p = R.make_params(**over)
+    w = R.init_weights(p, 77)
+    w["causal_0/W"] = (w["causal_0/W"] * xscale).astype(np.float32)
+    net = WaveNet(Params(p), seed=0)
+    net.load_state_dict(w)
+    net.to_gpu()
+    net.gemm_precision = "fp16x2"
+    B, T, tw = 2, 33000, 600
+    tgt = np.random.RandomState(16).randint(0, 256, (B, tw)).astype(np.int32)
+    idx = np.random.RandomState(15).randint(0, 256, (B, T)).astype(np.int32)
+    loss_ref, _, g = R.train_step_grads(p, w, idx, tgt)
+    c = net.forward_causal_block(idx)
+    _, s = net.forward_residual_block(c, t_off=T - tw)
+    loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt)
+    net.zero_grads()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - loss_ref) < 1e-4 * max(1.0, abs(loss_ref))
+    for ln, kind, off, n, shape in net._spans:
+        want = g["%s/%s" % (ln.name, kind)]
+        got = to_np(net._grad_arena[off:off + n].view(shape))
+        assert np.isfinite(got).all()
+        # The head starts with relu(skip): a skip value within rounding of zero (about one of the window's 307,200 values
+        # per run is) can take either sign on the device, and the gradient element behind it is then wholly present or
+        # absent -- 32 entries of ONE skip-projection gradient move by a few per cent of its largest entry (seen with this
+        # very input at the smallest scale: exact-fp32 kernels and these agree with each other there to 1e-6).  So: every
+        # entry within the bar, except at most 160 entries of a tensor (five such values), which stay within 30 % of its largest.
+        err = np.abs(got - want)
+        bar = 2e-4 * max(np.abs(want).max(), 1e-30)
+        assert (err > bar).sum() <= 160 and err.max() <= 1500 * bar, (ln.name, kind, int((err > bar).sum()), err.max(), bar)

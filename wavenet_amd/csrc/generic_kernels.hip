@@ -285,17 +285,22 @@ __global__ void k_colsum(const float* __restrict__ A, long long a_bs, int a_t0, 
         else atomicAdd(&out[m], v);
     }
 }
+// blockDim = (64 columns, 16 row lanes): lane y adds rows y, y + 16, ... in order, then the 16 lane sums are added in
+// index order -- a fixed summation tree, whatever the launch looks like
 __global__ void k_colsum_reduce(const float* __restrict__ part, int ny, int M, float* __restrict__ out) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int y = 0;
-    for (; y + 4 <= ny; y += 4) {
-        s0 += part[(long long)y * M + m]; s1 += part[(long long)(y + 1) * M + m];
-        s2 += part[(long long)(y + 2) * M + m]; s3 += part[(long long)(y + 3) * M + m];
+    __shared__ float red[16][64];
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    float s = 0.f;
+    if (m < M)
+        for (int y = threadIdx.y; y < ny; y += 16) s += part[(long long)y * M + m];
+    red[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && m < M) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        out[m] += t;
     }
-    for (; y < ny; ++y) s0 += part[(long long)y * M + m];
-    out[m] += (s0 + s1) + (s2 + s3);
 }
 
 static int launch_colsum(const float* A, long long a_bs, int a_t0, int lda, int nB, int tmin, int nT,
@@ -309,7 +314,7 @@ static int launch_colsum(const float* A, long long a_bs, int a_t0, int lda, int 
                       ? reinterpret_cast<float*>(exec_scratch((size_t)grid.y * M * sizeof(float), "column-sum partials"))
                       : nullptr;
     hipLaunchKernelGGL(k_colsum, grid, dim3(64, 4), 0, s, A, a_bs, a_t0, lda, nB, tmin, nT, M, out, t_chunk, part);
-    if (part) hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(M, 256)), dim3(256), 0, s, part, (int)grid.y, M, out);
+    if (part) hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(M, 64)), dim3(64, 16), 0, s, part, (int)grid.y, M, out);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }
@@ -556,11 +561,14 @@ __global__ void k_softmax(const float* __restrict__ logits, float* __restrict__ 
 
 // loss[0] = (sum of the per-block sums, in block order) / n_norm: no float atomics, the loss is bit-reproducible
 static constexpr int kXentPart = 8, kXentBlocks = 2048;
-__global__ void k_xent_final(float* __restrict__ loss, int nb, long long n_norm) {      // one wave
+__global__ void k_xent_final(float* __restrict__ loss, int nb, long long n_norm) {      // 256 threads, fixed tree
+    __shared__ float red[4];
     float acc = 0.f;
-    for (int i = threadIdx.x; i < nb; i += 64) acc += loss[kXentPart + i];
+    for (int i = threadIdx.x; i < nb; i += 256) acc += loss[kXentPart + i];
     acc = wave_sum(acc);
-    if (threadIdx.x == 0) loss[0] = acc / (float)n_norm;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n_norm;
 }
 
 __global__ void k_softmax_xent(const float* __restrict__ logits, const int32_t* __restrict__ target,
@@ -704,11 +712,14 @@ __global__ void k_sqnorm(const float* __restrict__ g, const float* __restrict__ 
         out[kNormPart + blockIdx.x] = s;
     }
 }
-__global__ void k_sqnorm_final(float* __restrict__ out, int nb) {      // one wave
+__global__ void k_sqnorm_final(float* __restrict__ out, int nb) {      // 256 threads, fixed tree
+    __shared__ float red[4];
     float acc = 0.f;
-    for (int i = threadIdx.x; i < nb; i += 64) acc += out[kNormPart + i];
+    for (int i = threadIdx.x; i < nb; i += 256) acc += out[kNormPart + i];
     acc = wave_sum(acc);
-    if (threadIdx.x == 0) out[0] = acc;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -1081,7 +1092,7 @@ int generic_softmax_xent(const float* logits, const int32_t* target, float* loss
     if (blocks > kXentBlocks) blocks = kXentBlocks;
     hipLaunchKernelGGL(k_softmax_xent, dim3(blocks), dim3(256), 0, s, logits, target, loss, dlogits, N, Q,
                        n_norm > 0 ? n_norm : N);
-    hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(64), 0, s, loss, blocks, n_norm > 0 ? n_norm : N);
+    hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(256), 0, s, loss, blocks, n_norm > 0 ? n_norm : N);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }
@@ -1150,7 +1161,7 @@ int generic_sqnorm(const float* g, const float* p, long long n, float gmult, flo
     if (blocks > kNormBlocks) blocks = kNormBlocks;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(k_sqnorm, dim3(blocks), dim3(256), 0, s, g, p, n, gmult, wd, out);
-    hipLaunchKernelGGL(k_sqnorm_final, dim3(1), dim3(64), 0, s, out, blocks);
+    hipLaunchKernelGGL(k_sqnorm_final, dim3(1), dim3(256), 0, s, out, blocks);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

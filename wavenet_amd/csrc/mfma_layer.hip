@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 4) void k_layer_fwd_mfma32_t1(
 // layout changes: a lane's 16 channels of x[t] (ch(s, h), s = 0..15) are an f16 operand pair as they stand (k-step ks,
 // element e <-> s = 8 ks + e), the accumulator register r still holds channel ch(r, h), so z feeds the projection
 // from registers and x[t] is added to its result in place.  x is scaled per tile by the power of two that brings the
-// wave's own maximum below 2^15, z = tanh sigmoid by 2^12; the weights arrive as pre-split images in A-operand order
+// wave's own maximum below 2^15, z = tanh sigmoid by 2^14; the weights arrive as pre-split images in A-operand order
 // (k_layer_pack_h2: one launch for all layers of a stack, scale = a power of two from the layer's largest weight).
 // Image of a layer: 1 KB per (matrix-tap mt, k-step ks, part): lane (j, hh) element e =
 //     mt 0..3 (Wf tap 0, Wf tap 1, Wg tap 0, Wg tap 1):  W[cd = j][cr = ch(8 ks + e, hh)][tap]
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, 4) void k_layer_fwd_h2_t1(
         }
     }
     H2Op oz;
-    lb_split16(zz, 4096.f, oz);
+    lb_split16(zz, 16384.f, oz);
     f32x16 ao;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ao[r] = 0.f;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(256, 4) void k_layer_fwd_h2_t1(
         ao = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, oz.m[ks], ao, 0, 0, 0);
         ao = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, oz.h[ks], ao, 0, 0, 0);
     }
-    const float up = w_inv * (1.f / 4096.f);
+    const float up = w_inv * (1.f / 16384.f);
     if (valid) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -498,10 +498,16 @@ int mfma_layer_pack_h2(int L, const float* const* Wf, const float* const* Wg, co
 }
 
 // layer l of a packed stack; only the one-tile-per-wave form exists (small launches take the fp32 kernel)
+// launches of at least this many workgroups (4 tiles each) take the one-tile-per-wave kernels; smaller ones the looping
+// fp32 kernel.  WAVENET_HIP_FWD_T1_MIN_BLOCKS overrides the threshold (1 = always, used by the parity tests; 0 = never).
+static int t1_min_blocks() {
+    static const int v = getenv("WAVENET_HIP_FWD_T1_MIN_BLOCKS") ? atoi(getenv("WAVENET_HIP_FWD_T1_MIN_BLOCKS")) : 512;
+    return v;
+}
 bool mfma_layer_fwd_h2_ok(int B, int T, int t_live) {
     const int tile_lo = t_live > 0 ? t_live / 32 : 0;
     const long long nt = (long long)B * ((T + 31) / 32 - tile_lo);
-    return nt >= 4 * 512 && nt < (1ll << 31);
+    return t1_min_blocks() > 0 && nt > 0 && (nt + 3) / 4 >= t1_min_blocks() && nt < (1ll << 31);
 }
 int mfma_layer_fwd_h2(const float* x, const void* img, int l, float* out, float* z, float* fs, float* gs, int B, int T,
                       int d, int Z, int t_live, hipStream_t s) {
@@ -539,7 +545,7 @@ int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float
     const bool hb = bf || bg || bp;
     // enough workgroups to give every CU two to four of them (8-16 waves): one tile per wave; otherwise the looping kernel.
     // WAVENET_HIP_FWD_T1_MIN_BLOCKS overrides the threshold (1 = always, used by the parity tests; 0 = never).
-    static const int t1_min = getenv("WAVENET_HIP_FWD_T1_MIN_BLOCKS") ? atoi(getenv("WAVENET_HIP_FWD_T1_MIN_BLOCKS")) : 512;
+    const int t1_min = t1_min_blocks();
     if (t1_min > 0 && blocks >= t1_min) {
 #define FWD1_LAUNCH(SAVE, BIAS)                                                                              \
     hipLaunchKernelGGL((k_layer_fwd_mfma32_t1<SAVE, BIAS>), dim3(blocks), dim3(256), 0, s, x, Wf, bf, Wg, bg, Wp, bp, \

@@ -197,7 +197,7 @@ static constexpr int kCMaxBlocks = 256;
 // value v s is split into two fp16 parts h + m (22 bits), a product is the three terms m h' + h m' + h h' of
 // v_mfma_f32_32x32x16_f16 (32 cycles for K = 16 against 64 for K = 2): 30 MFMAs = 960 cycles per tile.  The scale s is a
 // power of two chosen PER TILE from the wave's own maximum (gradients: max over da, dg, dout; inputs: max over x[t],
-// x[t-d]; z = tanh sigmoid: 2^12), so that nothing overflows fp16 and the parts lost to fp16's subnormals are below
+// x[t-d]; z = tanh sigmoid: 2^14), so that nothing overflows fp16 and the parts lost to fp16's subnormals are below
 // 2^-24 of the tile's maximum; a tile's product leaves the matrix core in its own scale and joins the running fp32
 // accumulator with one fma per element.  Selected by WnExec.precision == WN_GEMM_FP16X2; any other precision keeps
 // the exact-fp32 MFMAs.
@@ -576,8 +576,8 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
             if (HAS_DO || HAS_U) {
                 H2Op odo, oz;
                 lb_split16(w.a_do, sg, odo);
-                lb_split16(w.b_z, 4096.f, oz);
-                lb_h2_product(odo, oz, ig * (1.f / 4096.f), aWp);
+                lb_split16(w.b_z, 16384.f, oz);
+                lb_h2_product(odo, oz, ig * (1.f / 16384.f), aWp);
             }
             return;
         }
