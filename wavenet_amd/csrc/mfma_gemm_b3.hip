@@ -330,14 +330,42 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
             load_x(c + 1);
         }
         const char* Ab = lds + ((c & 1) * MT) * TB + lane * 16;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+        // The A fragments of m-tile mt + 1 are requested while the MFMAs of m-tile mt run.  (Left to itself hipcc sinks every
+        // ds_read next to its first use: "read, s_waitcnt lgkmcnt(0), three MFMAs" 16 times per chunk, one exposed LDS
+        // latency per 96 cycles of matrix work -- 48 % matrix utilisation by PMC.  With an LDS-DMA in the loop every wait
+        // is lgkmcnt(0), so the order has to be: wait for tile mt's fragments (the empty asm is that use), THEN request
+        // tile mt + 1's, then multiply.)
+        constexpr bool PIPE = ONE || H2;                 // six terms at three workgroups per CU: no registers for a second set
+        bf16x8 fr[PIPE ? 2 : 1][2][3];
+        auto ldA = [&](int mt, bf16x8 (&f)[2][3]) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const char* p = Ab + mt * TB + ks * (TB / 2);
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(p);
-                const bf16x8 am = *reinterpret_cast<const bf16x8*>(p + (ONE ? 0 : 1024));
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(p + ((ONE || H2) ? 0 : 2048));
+                f[ks][0] = *reinterpret_cast<const bf16x8*>(p);
+                if (!ONE) f[ks][1] = *reinterpret_cast<const bf16x8*>(p + 1024);
+                if (!ONE && !H2) f[ks][2] = *reinterpret_cast<const bf16x8*>(p + 2048);
+            }
+        };
+        if (PIPE) ldA(0, fr[0]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            bf16x8 (&f)[2][3] = fr[PIPE ? (mt & 1) : 0];
+            if (PIPE) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    asm volatile("" ::"v"(f[ks][0]));
+                    if (!ONE) asm volatile("" ::"v"(f[ks][1]));
+                }
+                if (mt + 1 < MT) ldA(mt + 1, fr[PIPE ? ((mt + 1) & 1) : 0]);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                ldA(mt, f);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 ah = f[ks][0];
+                const bf16x8 am = ONE ? f[ks][0] : f[ks][1];
+                const bf16x8 al = (ONE || H2) ? f[ks][0] : f[ks][2];
                 if (H2) {                                  // fp16 two-way split: wm xh + wh xm + wh xh
                     const f16x8 fah = __builtin_bit_cast(f16x8, ah), fam = __builtin_bit_cast(f16x8, am);
                     const f16x8 fxh = __builtin_bit_cast(f16x8, xh[ks]), fxm = __builtin_bit_cast(f16x8, xm[ks]);
@@ -356,6 +384,7 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
                 }
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[ks], acc[mt], 0, 0, 0);
             }
+            if (PIPE) __builtin_amdgcn_sched_barrier(0);
         }
     }
     if constexpr (MODE == 5 && MT == 8) {

@@ -820,10 +820,13 @@ void k16_embed_bwd(const int32_t* __restrict__ tokp, const bf16* __restrict__ dx
 
 // dW[c][q][tap] += sum over workgroups (in index order) of part[wg][tap][q][c]; the tap-1 sums also go to bsum[q][c],
 // from which k16_embed_bias takes dbias[c] += sum over q (every sample has exactly one current token) -- no atomics.
-__global__ void k16_embed_bwd_reduce(const float* __restrict__ part, int nwg, int C, float* __restrict__ dW,
-                                     float* __restrict__ bsum) {
-    const int q = blockIdx.x;                            // one token value per block: threads = (tap, c)
-    const int tap = threadIdx.x / C, c = threadIdx.x - tap * C;
+__global__ __launch_bounds__(256) void k16_embed_bwd_reduce(const float* __restrict__ part, int nwg, int C,
+                                                            float* __restrict__ dW, float* __restrict__ bsum) {
+    // 256 threads = (q within the block, tap, c): 256 / (2 C) token values per block
+    const int per = 2 * C;
+    const int q = blockIdx.x * (256 / per) + threadIdx.x / per;
+    const int tc = threadIdx.x % per;
+    const int tap = tc / C, c = tc - tap * C;
     const long long wgs = 2ll * 256 * C;
     const float* p = part + ((long long)tap * 256 + q) * C + c;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -1041,7 +1044,7 @@ int embed_bwd_mfma(const int32_t* idx, const bf16* dx, const float* dx_f32, int 
         wn::set_error("embed_bwd_mfma: %d channels", C);
         return WN_ESHAPE;
     }
-    hipLaunchKernelGGL(k16_embed_bwd_reduce, dim3(256), dim3(2 * C), 0, s, part, nwg, C, dW, bsum);
+    hipLaunchKernelGGL(k16_embed_bwd_reduce, dim3(2 * C), dim3(256), 0, s, part, nwg, C, dW, bsum);   // 256 q x 2 C threads
     if (dbias) hipLaunchKernelGGL(k16_embed_bias, dim3((C + 63) / 64), dim3(64), 0, s, bsum, C, dbias);
     WN_LAUNCH_CHECK();
     return WN_OK;
