@@ -240,8 +240,8 @@ __device__ __forceinline__ void lb_h2_product(const H2Op& a, const H2Op& b, floa
 // ---------------------------------------------------------------------------------------------
 // FROM_Z: the forward saved z and sigmoid only; `f` points at z and tanh is recovered as z / sigmoid (z = tanh * sigmoid was
 // rounded once in fp32, so the quotient is tanh to ~1.2e-7 relative; where sigmoid underflowed, da and dg are 0 anyway).
-template <bool HAS_DO, bool HAS_U, bool HAS_DZ, bool FROM_Z, bool H2W>
-__global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
+template <bool HAS_DO, bool HAS_U, bool HAS_DZ, bool FROM_Z, bool H2W, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
     const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
     const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
     const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, int vu_t0,
@@ -259,17 +259,19 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    float* pbase = wbase + wv * kCWaveFloats;        // group k: pbase + 4096 k = {f | dout, g | z, V | da, U | dg}
+    static_assert(NW == 4 || (NW == 8 && H2W), "eight waves: the f16 form only");
+    // NW == 4: two slot groups per wave (software pipeline); NW == 8: one (two waves per SIMD hide each other's stalls)
+    float* pbase = wbase + wv * (NW == 4 ? kCWaveFloats : 4096);   // group k: pbase + 4096 k = {f | dout, g | z, V | da, U | dg}
     int first, stride, last;
     if ((gridDim.x & 7) == 0) {
         const int per_xcd = (ntiles + 7) >> 3;
         const int xcd = blockIdx.x & 7;
-        stride = (gridDim.x >> 3) * 4;
-        first = xcd * per_xcd + (blockIdx.x >> 3) * 4 + wv;
+        stride = (gridDim.x >> 3) * NW;
+        first = xcd * per_xcd + (blockIdx.x >> 3) * NW + wv;
         last = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
     } else {
-        stride = gridDim.x * 4;
-        first = blockIdx.x * 4 + wv;
+        stride = gridDim.x * NW;
+        first = blockIdx.x * NW + wv;
         last = ntiles;
     }
     const int lr = lane >> 3, lp = lane & 7;
@@ -592,35 +594,37 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     };
 
     // ---- prologue: weights -> LDS, first tile's operands, its first half -----------------------------------
-    constexpr int kThreads = 256;
-    float4 s_wf[2], s_wg[2];
+    constexpr int kThreads = 64 * NW;
+    constexpr int NK = 512 / kThreads;                  // float4 pieces of Wf (and of Wg) per thread
+    float4 s_wf[NK], s_wg[NK];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NK; ++k) {
         s_wf[k] = reinterpret_cast<const float4*>(Wf)[threadIdx.x + k * kThreads];
         s_wg[k] = reinterpret_cast<const float4*>(Wg)[threadIdx.x + k * kThreads];
     }
-    const float4 s_wp = reinterpret_cast<const float4*>(Wp)[threadIdx.x];
+    const float4 s_wp = reinterpret_cast<const float4*>(Wp)[threadIdx.x & 255];
     float4 dza[4], dzb[4];
     float xc[16], xo[16];
     const bool any = first < last;
     bool stores_in_flight = false;                     // the last eight vector-memory operations are unconditional V/U stores
-    if (any) { fetch_a(first, pbase, dza); fetch_x(first, xc, xo); }
+    if (any && NW == 4) { fetch_a(first, pbase, dza); fetch_x(first, xc, xo); }
     if constexpr (H2W) {
         // fp16 x 2 images of the three weight matrices in A-operand order: 1 KB per (matrix, tap, k-step, part), lane
         // (j, h) element e = W[cd = bch(8 ks + e, h)][cr = j][tap] (Wp: [cr = bch(..)][cd = j]) scaled by one power of two
         // taken from the largest weight of the layer (every workgroup sees all of them: 20 values per thread)
         float mw = 0.f;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < NK; ++k) {
             mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wf[k].x), fabsf(s_wf[k].y)), fmaxf(fabsf(s_wf[k].z), fabsf(s_wf[k].w))));
             mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wg[k].x), fabsf(s_wg[k].y)), fmaxf(fabsf(s_wg[k].z), fabsf(s_wg[k].w))));
         }
         mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wp.x), fabsf(s_wp.y)), fmaxf(fabsf(s_wp.z), fabsf(s_wp.w))));
         mw = lb_wave_max(mw);
-        float* red = wbase + kCWaves * kCWaveFloats - 8;           // last 32 bytes of the slot area: free until tile data lands there
+        float* red = wbase + (NW == 4 ? kCWaves * kCWaveFloats : 8 * 4096) - 8;   // last 32 bytes of the slot area: free until tile data lands there
         if (lane == 0) red[wv] = mw;
         __syncthreads();
         mw = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (NW == 8) mw = fmaxf(mw, fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
         float sw;
         lb_pow2_scale(mw, sw, w_inv);
         __syncthreads();
@@ -635,26 +639,99 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
             *reinterpret_cast<_Float16*>(dst + 1024) = mv;
         };
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < NK; ++k) {
             const int e0 = (threadIdx.x + k * kThreads) * 4;        // flat index into W[cd][cr][tap]
             const int cd = e0 >> 6, cr = (e0 >> 1) & 31;
             put(0, cd, cr, s_wf[k].x); put(1, cd, cr, s_wf[k].y); put(0, cd, cr + 1, s_wf[k].z); put(1, cd, cr + 1, s_wf[k].w);
             put(2, cd, cr, s_wg[k].x); put(3, cd, cr, s_wg[k].y); put(2, cd, cr + 1, s_wg[k].z); put(3, cd, cr + 1, s_wg[k].w);
         }
-        {
+        if (threadIdx.x < 256) {
             const int e0 = threadIdx.x * 4;                           // flat index into Wp[cr][cd]
             const int cr = e0 >> 5, cd = e0 & 31;
             put(4, cr, cd, s_wp.x); put(4, cr, cd + 1, s_wp.y); put(4, cr, cd + 2, s_wp.z); put(4, cr, cd + 3, s_wp.w);
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < NK; ++k) {
             reinterpret_cast<float4*>(lWf)[threadIdx.x + k * kThreads] = s_wf[k];
             reinterpret_cast<float4*>(lWg)[threadIdx.x + k * kThreads] = s_wg[k];
         }
-        reinterpret_cast<float4*>(lWp)[threadIdx.x] = s_wp;
+        if (threadIdx.x < 256) reinterpret_cast<float4*>(lWp)[threadIdx.x] = s_wp;
     }
     __syncthreads();                                   // (also drains vmcnt: the first tile has landed)
+    if constexpr (NW == 8) {
+        // Two waves per SIMD, no software pipeline: with f16 MFMAs the matrix time a pipelined wave used to cover its own
+        // VALU / LDS / memory stalls with is gone (matrix pipe 7 % busy); the sibling wave covers them instead.  One slot
+        // group per wave: a tile's inputs land in it, become the patches, and are consumed before the next fetch.
+        // Register budget 256 (two waves per SIMD): the transposed operands are taken, split and multiplied in two steps
+        // (the four conv-tap products, then dWp), and x is fetched only after the first half of the tile.
+        for (int tile = first; tile < last; tile += stride) {
+            const int b = tile / tiles_per_b;
+            const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
+            fetch_a(tile, pbase, dza);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            phase_a(tile, pbase, dza);
+            store_vu(tile);
+            fetch_x(tile, xc, xo);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                float a_da[16], a_dg[16], b_xc[16], b_xo[16];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // x has landed (the V / U stores with it)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int r = 2 * s + h;
+                    const int tt = t0 + r;
+                    const int po = r * 32 + ((((j >> 2) ^ (r & 7)) << 2) | (j & 3));
+                    a_da[s] = pbase[2048 + po]; a_dg[s] = pbase[3072 + po];
+                    b_xc[s] = xc[s] * (tt < T ? 1.f : 0.f);
+                    b_xo[s] = xo[s] * ((tt < T && tt - d >= 0) ? 1.f : 0.f);
+                }
+                float mg = 0.f, mx = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    mg = fmaxf(mg, fmaxf(fabsf(a_da[s]), fabsf(a_dg[s])));
+                    mx = fmaxf(mx, fmaxf(fabsf(b_xc[s]), fabsf(b_xo[s])));
+                }
+                mg = lb_wave_max(mg);
+                mx = lb_wave_max(mx);
+                float sg, ig, sx, ix;
+                lb_pow2_scale(mg, sg, ig);
+                lb_pow2_scale(mx, sx, ix);
+                H2Op oda, odg, oxc, oxo;
+                lb_split16(a_da, sg, oda);
+                lb_split16(a_dg, sg, odg);
+                lb_split16(b_xc, sx, oxc);
+                lb_split16(b_xo, sx, oxo);
+                const float u = ig * ix;
+                lb_h2_product(oda, oxc, u, aWf1);
+                lb_h2_product(oda, oxo, u, aWf0);
+                lb_h2_product(odg, oxc, u, aWg1);
+                lb_h2_product(odg, oxo, u, aWg0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (HAS_DO || HAS_U) {
+                float a_do[16], b_z[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int r = 2 * s + h;
+                    const int po = r * 32 + ((((j >> 2) ^ (r & 7)) << 2) | (j & 3));
+                    a_do[s] = pbase[po]; b_z[s] = pbase[1024 + po];
+                }
+                float md = 0.f;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) md = fmaxf(md, fabsf(a_do[s]));
+                md = lb_wave_max(md);
+                float sd, id;
+                lb_pow2_scale(md, sd, id);
+                H2Op odo, oz;
+                lb_split16(a_do, sd, odo);
+                lb_split16(b_z, 16384.f, oz);
+                lb_h2_product(odo, oz, id * (1.f / 16384.f), aWp);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the patches are consumed: the slots may be fetched into
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
     if (any) {
         if (first + stride < last) fetch_a(first + stride, pbase + 4096, dzb);
         phase_a(first, pbase, dza);
@@ -692,9 +769,10 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
         wgrad(w);
     }
 
+    }
     // ---- sum the five accumulators over the waves (tree through the slot groups) -----
     __syncthreads();
-    for (int half = 2; half >= 1; half >>= 1) {
+    for (int half = NW / 2; half >= 1; half >>= 1) {
         if (wv >= half && wv < 2 * half) {
             float* red = wbase + (wv - half) * kPartFloats;
 #pragma unroll
@@ -910,20 +988,31 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
     WN_CHECK_ARG(tiles_per_b > 0, "mfma_layer_bwd_chain: no live column");
     WN_CHECK_ARG(Vin || Uin || dzs, "mfma_layer_bwd_chain: no incoming gradient");
     const int ntiles = (int)nt;
-    int blocks = (ntiles + kCWaves - 1) / kCWaves;
+    // WAVENET_HIP_BWD_WAVES=8 selects the experimental two-waves-per-SIMD form of the f16 kernel (one slot group per
+    // wave, no software pipeline, 256 registers: 21 spilled).  Measured on config 2: 1.54 ms against 1.46 ms for the
+    // software-pipelined one-wave-per-SIMD form on the same box -- without a prefetch inside the wave its two
+    // vmcnt(0) waits per tile are exposed, and one sibling wave does not cover them.  Kept for the next attempt.
+    static const int waves_env = getenv("WAVENET_HIP_BWD_WAVES") ? atoi(getenv("WAVENET_HIP_BWD_WAVES")) : 4;
+    const int nw = (h2w && waves_env == 8) ? 8 : 4;
+    int blocks = (ntiles + nw - 1) / nw;
     if (blocks > kCMaxBlocks) blocks = kCMaxBlocks;
     if (nwg) *nwg = blocks;
-#define CH_LAUNCH3(DO, UU, DZ, FZ, HW)                                                                             \
+#define CH_LAUNCH4(DO, UU, DZ, FZ, HW, NW_)                                                                        \
     do {                                                                                                           \
         static bool attr_set = false;                                                                              \
         if (!attr_set) {                                                                                           \
-            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chainsp<DO, UU, DZ, FZ, HW>),     \
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chainsp<DO, UU, DZ, FZ, HW, NW_>), \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kCLdsBytes));                   \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL((k_layer_bwd_chainsp<DO, UU, DZ, FZ, HW>), dim3(blocks), dim3(64 * kCWaves), kCLdsBytes, s, x, \
-                           f, g, Wp, Wf, Wg, Vin, Uin, dU, vu_t0, dzs, dz_t0, Vout, Uout, part, B, T, d, Z, tile_lo, \
-                           tiles_per_b, ntiles);                                                                   \
+        hipLaunchKernelGGL((k_layer_bwd_chainsp<DO, UU, DZ, FZ, HW, NW_>), dim3(blocks), dim3(64 * NW_), kCLdsBytes, s, \
+                           x, f, g, Wp, Wf, Wg, Vin, Uin, dU, vu_t0, dzs, dz_t0, Vout, Uout, part, B, T, d, Z,       \
+                           tile_lo, tiles_per_b, ntiles);                                                          \
+    } while (0)
+#define CH_LAUNCH3(DO, UU, DZ, FZ, HW)                          \
+    do {                                                        \
+        if (HW && nw == 8) CH_LAUNCH4(DO, UU, DZ, FZ, true, 8); \
+        else CH_LAUNCH4(DO, UU, DZ, FZ, HW, 4);                 \
     } while (0)
 #define CH_LAUNCH2(DO, UU, DZ, FZ)                            \
     do {                                                      \
@@ -948,6 +1037,7 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
 #undef CH_LAUNCH
 #undef CH_LAUNCH2
 #undef CH_LAUNCH3
+#undef CH_LAUNCH4
     WN_LAUNCH_CHECK();
     return WN_OK;
 }
