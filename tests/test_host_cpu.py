@@ -26,6 +26,9 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     assert _lib.lib().wn_abi_version() == 2
     assert not hasattr(lib, "wn_set_gemm_precision")          # ABI v2: no process-wide arithmetic mode
+    # scalar results that carry their own scratch: the binding's sizes are the header's
+    assert int(re.search(r"#define WN_SQNORM_WORDS (\d+)", hdr).group(1)) == _lib.SQNORM_WORDS
+    assert int(re.search(r"#define WN_XENT_LOSS_WORDS (\d+)", hdr).group(1)) == _lib.XENT_LOSS_WORDS
 
 
 def test_argument_errors_do_not_need_a_gpu():
