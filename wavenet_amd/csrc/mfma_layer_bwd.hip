@@ -182,6 +182,10 @@ __global__ __launch_bounds__(256, 2) void k_layer_bwd_p1(
 //   4. (this one) one wave per SIMD, software-pipelined: 45 us.
 // =============================================================================================
 static constexpr int kCWaves = 4;
+#ifdef WN_BWD_STAMPS
+__device__ unsigned long long g_bwd_stamps[1024 * 8];
+#define BST(v) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); } while (0)
+#endif
 static constexpr int kCWaveFloats = 8192;                       // two groups of four 4 KB slots per wave
 static constexpr int kCWFloats = 2048 + 2048 + 1024;            // Wf, Wg, Wp
 static constexpr int kCLdsBytes = (kCWFloats + kCWaves * kCWaveFloats) * 4;
@@ -256,6 +260,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
     float* lWg = dyn + 2048;
     float* lWp = dyn + 4096;
     float* wbase = dyn + kCWFloats;
+#ifdef WN_BWD_STAMPS
+    unsigned long long st_k0 = 0, st_k1 = 0, st_k2 = 0, st_k3 = 0, st_k4 = 0, st_loop_end = 0;
+    BST(st_k0);
+#endif
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -659,6 +667,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
         if (threadIdx.x < 256) reinterpret_cast<float4*>(lWp)[threadIdx.x] = s_wp;
     }
     __syncthreads();                                   // (also drains vmcnt: the first tile has landed)
+#ifdef WN_BWD_STAMPS
+    unsigned long long st_wait = 0, st_take = 0, st_body = 0, st_n = 0, st_t0 = 0, st_t1 = 0;
+    BST(st_k1);
+#endif
     if constexpr (NW == 8) {
         // Two waves per SIMD, no software pipeline: with f16 MFMAs the matrix time a pipelined wave used to cover its own
         // VALU / LDS / memory stalls with is gone (matrix pipe 7 % busy); the sibling wave covers them instead.  One slot
@@ -742,16 +754,29 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
     // 80 accumulator registers every iteration); the last tile's weight gradients follow the loop.
     int it = 0;
     int tile = first;
+#ifdef WN_BWD_STAMPS
+    BST(st_t0);
+#endif
     for (; tile + stride < last; tile += stride, ++it) {
         float* grp = pbase + (it & 1) * 4096;          // patches of `tile`
         float* ngrp = pbase + ((it + 1) & 1) * 4096;   // f, g, V, U of tile + stride
         // what the previous body fetched (this tile's x, the next tile's f, g, V, U, dz) has had a whole body to land;
         // its V/U stores were issued last and may stay in flight
+#ifdef WN_BWD_STAMPS
+        unsigned long long c0, c1, c2, c3;
+        BST(c0);
+#endif
         if (stores_in_flight) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef WN_BWD_STAMPS
+        BST(c1);
+#endif
         WOps w;
         take(tile, grp, xc, xo, w);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the patches are in registers: their slots are free
+#ifdef WN_BWD_STAMPS
+        BST(c2);
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) dza[q] = dzb[q];
         fetch_x(tile + stride, xc, xo);
@@ -760,7 +785,14 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
         wgrad(w);
         phase_a(tile + stride, ngrp, dza);
         stores_in_flight = store_vu(tile + stride);
+#ifdef WN_BWD_STAMPS
+        BST(c3);
+        st_wait += c1 - c0; st_take += c2 - c1; st_body += c3 - c2; ++st_n;
+#endif
     }
+#ifdef WN_BWD_STAMPS
+    BST(st_loop_end);
+#endif
     if (any) {
         if (stores_in_flight) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -770,6 +802,18 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
     }
 
     }
+#ifdef WN_BWD_STAMPS
+    BST(st_k2);
+    if constexpr (NW == 4) {
+        st_t1 = st_loop_end;
+        const int gw = blockIdx.x * NW + wv;
+        if (lane == 0 && gw < 1024) {
+            g_bwd_stamps[gw * 8 + 0] = st_wait; g_bwd_stamps[gw * 8 + 1] = st_take; g_bwd_stamps[gw * 8 + 2] = st_body;
+            g_bwd_stamps[gw * 8 + 3] = st_n; g_bwd_stamps[gw * 8 + 4] = st_t1 - st_t0;
+            g_bwd_stamps[gw * 8 + 5] = st_k1 - st_k0; g_bwd_stamps[gw * 8 + 6] = st_t0 - st_k1; g_bwd_stamps[gw * 8 + 7] = st_k2 - st_loop_end;
+        }
+    }
+#endif
     // ---- sum the five accumulators over the waves (tree through the slot groups) -----
     __syncthreads();
     for (int half = NW / 2; half >= 1; half >>= 1) {
@@ -1069,3 +1113,9 @@ int mfma_chain_combine(const float* V, const float* U, float* dx, int B, int T, 
 }
 
 }  // namespace wn
+
+#ifdef WN_BWD_STAMPS
+extern "C" int wn_debug_bwd_stamps(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wn::g_bwd_stamps), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
