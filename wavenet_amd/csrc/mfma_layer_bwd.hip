@@ -615,7 +615,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
     float xc[16], xo[16];
     const bool any = first < last;
     bool stores_in_flight = false;                     // the last eight vector-memory operations are unconditional V/U stores
-    if (any && NW == 4) { fetch_a(first, pbase, dza); fetch_x(first, xc, xo); }
+    if (!H2W && any && NW == 4) { fetch_a(first, pbase, dza); fetch_x(first, xc, xo); }
     if constexpr (H2W) {
         // fp16 x 2 images of the three weight matrices in A-operand order: 1 KB per (matrix, tap, k-step, part), lane
         // (j, h) element e = W[cd = bch(8 ks + e, h)][cr = j][tap] (Wp: [cr = bch(..)][cd = j]) scaled by one power of two
@@ -630,12 +630,15 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
         mw = lb_wave_max(mw);
         float* red = wbase + (NW == 4 ? kCWaves * kCWaveFloats : 8 * 4096) - 8;   // last 32 bytes of the slot area: free until tile data lands there
         if (lane == 0) red[wv] = mw;
-        __syncthreads();
+        // the first tile's fetch goes out only now, behind the weight loads (which the maximum above has waited for), and
+        // the exchange of the four maxima uses an LDS-only barrier: splitting and scattering the images (~2 k cycles) runs
+        // under the fetch's HBM round trip instead of behind it (a __syncthreads() here would drain it)
+        if (any && NW == 4) { fetch_a(first, pbase, dza); fetch_x(first, xc, xo); }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         mw = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
         if (NW == 8) mw = fmaxf(mw, fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
         float sw;
         lb_pow2_scale(mw, sw, w_inv);
-        __syncthreads();
         char* img = reinterpret_cast<char*>(dyn);
         auto put = [&](int mat_tap, int kidx, int jj, float v) {      // kidx: the contraction channel, jj: the output row
             const int hh = (kidx >> 2) & 1, ks = kidx >> 4, e = (kidx & 3) + 4 * ((kidx >> 3) & 1);
