@@ -268,6 +268,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     static_assert(NW == 4 || (NW == 8 && H2W), "eight waves: the f16 form only");
+    constexpr bool PL = H2W && NW == 4;
     // NW == 4: two slot groups per wave (software pipeline); NW == 8: one (two waves per SIMD hide each other's stalls)
     float* pbase = wbase + wv * (NW == 4 ? kCWaveFloats : 4096);   // group k: pbase + 4096 k = {f | dout, g | z, V | da, U | dg}
     int first, stride, last;
@@ -341,14 +342,21 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
         const int b = tile / tiles_per_b;
         const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
         if (t0 - d >= 0 && t0 + 32 <= T) {               // interior tile: rows 2s+h are 256 B apart from one base
-            const float* pc = x + ((long long)b * T + t0 + h) * 32 + j;
-            const float* po = pc - (long long)d * 32;
+            if constexpr (PL) {                          // rows 16 (s >> 3) + 8 h + (s & 7): the k order of the tr reads
+                const float* pc = x + ((long long)b * T + t0 + 8 * h) * 32 + j;
+                const float* po = pc - (long long)d * 32;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) { xc[s] = pc[s * 64]; xo[s] = po[s * 64]; }
+                for (int s = 0; s < 16; ++s) { xc[s] = pc[(16 * (s >> 3) + (s & 7)) * 32]; xo[s] = po[(16 * (s >> 3) + (s & 7)) * 32]; }
+            } else {
+                const float* pc = x + ((long long)b * T + t0 + h) * 32 + j;
+                const float* po = pc - (long long)d * 32;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) { xc[s] = pc[s * 64]; xo[s] = po[s * 64]; }
+            }
         } else {
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
-                const int tt = t0 + 2 * s + h;
+                const int tt = t0 + (PL ? 16 * (s >> 3) + 8 * h + (s & 7) : 2 * s + h);
                 const int ttc = tt < T ? tt : T - 1;
                 const int tto = ttc - d >= 0 ? ttc - d : 0;
                 xc[s] = x[((long long)b * T + ttc) * 32 + j];
@@ -364,6 +372,11 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
     // first half of a tile: everything up to the patches in its slot group; the V/U rows come back in registers
     // (vv, uu) and are stored by the caller.  `grp` holds the tile's f, g, V, U (landed).
     float w_inv = 1.f;                                 // H2W: 1 / (the weight images' power-of-two scale)
+    // PL (H2W, four waves): a tile's dout, z, da, dg leave phase_a already split, as fp16 planes (h at +0, m at +2 KB of the
+    // 4 KB slot, 64-byte rows, the 8-byte piece c of row r at position c ^ ((r >> 2) & 7)), and the weight-gradient
+    // operands are taken from them TRANSPOSED by ds_read_b64_tr_b16 -- no second split, no transposing scalar reads.
+    float pa_ig = 0.f, pa_id = 0.f;                    // 1 / scale of (da, dg) and of dout of the tile phase_a saw last
+    float wg_ig = 0.f, wg_id = 0.f;                    // ... of the tile whose weight gradients come next
     float vv[16], uu[16];
     auto phase_a = [&](int tile, float* grp, const float4 (&dz4)[4]) {
         float* tf = grp;
@@ -378,6 +391,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
         const bool uin = HAS_U && valid && t + dU < T && t + dU >= vu_t0;
         f32x16 acc;
         float ff[16], gg[16], dob[16];
+        H2Op od, oa, og;                                 // H2W: dout, da, dg split (kept for the planes)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int o = j * 32 + (((2 * q + h) ^ (j & 7)) << 2);
@@ -408,7 +422,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
                 md = lb_wave_max(md);
                 float sd, id;
                 lb_pow2_scale(md, sd, id);
-                H2Op od;
+                pa_id = id;
                 lb_split16(dob, sd, od);
                 f32x16 t;
 #pragma unroll
@@ -454,7 +468,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
             mg = lb_wave_max(mg);
             float sg, ig;
             lb_pow2_scale(mg, sg, ig);
-            H2Op oa, og;
+            pa_ig = ig;
             lb_split16(da, sg, oa);
             lb_split16(dg, sg, og);
             f32x16 tv, tu;
@@ -508,6 +522,33 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
             vv[4 * k] = a.x; vv[4 * k + 1] = a.y; vv[4 * k + 2] = a.z; vv[4 * k + 3] = a.w;
             uu[4 * k] = c.x; uu[4 * k + 1] = c.y; uu[4 * k + 2] = c.z; uu[4 * k + 3] = c.w;
         }
+        if constexpr (PL) {
+            // the four arrays as fp16 planes (see PL).  Lane (j, h) owns row j; k-step ks of an H2Op holds channels
+            // 16 ks + 4 h + 0..3 (dwords 0, 1) and 16 ks + 8 + 4 h + 0..3 (dwords 2, 3): 8-byte pieces 4 ks + 2 grp + h.
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            H2Op oz;
+            lb_split16(zz, 16384.f, oz);
+            char* const rowb = reinterpret_cast<char*>(grp) + j * 64;
+            const int key = (j >> 2) & 7;
+            auto put_planes = [&](int slot, const H2Op& o, bool zero) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    u32x4_t hv = __builtin_bit_cast(u32x4_t, o.h[ks]), mv = __builtin_bit_cast(u32x4_t, o.m[ks]);
+                    if (zero) { hv = u32x4_t{0u, 0u, 0u, 0u}; mv = hv; }
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int pos = ((4 * ks + 2 * g2 + h) ^ key) * 8;
+                        *reinterpret_cast<u32x2_t*>(rowb + slot * 4096 + pos) = u32x2_t{hv[2 * g2], hv[2 * g2 + 1]};
+                        *reinterpret_cast<u32x2_t*>(rowb + slot * 4096 + 2048 + pos) = u32x2_t{mv[2 * g2], mv[2 * g2 + 1]};
+                    }
+                }
+            };
+            if (HAS_DO || HAS_U) { put_planes(0, od, !valid); put_planes(1, oz, false); }
+            put_planes(2, oa, false);
+            put_planes(3, og, false);
+            return;
+        }
         // the four patches: dout (0 beyond T), z, da, dg
         const float mvj = valid ? 1.f : 0.f;
 #pragma unroll
@@ -559,6 +600,60 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
             w.b_xc[s] = xc[s] * (tt < T ? 1.f : 0.f);
             w.b_xo[s] = xo[s] * ((tt < T && tt - d >= 0) ? 1.f : 0.f);
         }
+    };
+    struct WOpsT { H2Op da, dg, dov, z; };
+    auto take_t = [&](const float* grp, WOpsT& w) {
+        const char* base = reinterpret_cast<const char*>(grp);
+        const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+        auto frag = [&](int slot, int plane, int ks) {
+            const int rb = 16 * ks + 8 * (g >> 1);
+            const int c = 4 * (g & 1) + p;                           // logical 8-byte piece: channels 16 (g & 1) + 4 p ..
+            const int r0 = rb + q, r1 = rb + 4 + q;
+            typedef short s16x4_t __attribute__((ext_vector_type(4)));
+            typedef short s16x8_t __attribute__((ext_vector_type(8)));
+            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
+                base + slot * 4096 + plane * 2048 + r0 * 64 + ((c ^ ((r0 >> 2) & 7)) * 8)));
+            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(
+                base + slot * 4096 + plane * 2048 + r1 * 64 + ((c ^ ((r1 >> 2) & 7)) * 8)));
+            s16x8_t v;
+            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+            return __builtin_bit_cast(h16x8, v);
+        };
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (HAS_DO || HAS_U) {
+                w.dov.h[ks] = frag(0, 0, ks); w.dov.m[ks] = frag(0, 1, ks);
+                w.z.h[ks] = frag(1, 0, ks); w.z.m[ks] = frag(1, 1, ks);
+            }
+            w.da.h[ks] = frag(2, 0, ks); w.da.m[ks] = frag(2, 1, ks);
+            w.dg.h[ks] = frag(3, 0, ks); w.dg.m[ks] = frag(3, 1, ks);
+        }
+    };
+    // x[t], x[t-d] of the tile (rows in tr order), masked, split with the wave's own scale; then the five products
+    auto wgrad_t = [&](int tile, const WOpsT& w, const float (&xc)[16], const float (&xo)[16]) {
+        const int b = tile / tiles_per_b;
+        const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
+        float bxc[16], bxo[16];
+        float mx = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int tt = t0 + 16 * (s >> 3) + 8 * h + (s & 7);
+            bxc[s] = xc[s] * (tt < T ? 1.f : 0.f);
+            bxo[s] = xo[s] * ((tt < T && tt - d >= 0) ? 1.f : 0.f);
+            mx = fmaxf(mx, fmaxf(fabsf(bxc[s]), fabsf(bxo[s])));
+        }
+        mx = lb_wave_max(mx);
+        float sx, ix;
+        lb_pow2_scale(mx, sx, ix);
+        H2Op oxc, oxo;
+        lb_split16(bxc, sx, oxc);
+        lb_split16(bxo, sx, oxo);
+        const float u = wg_ig * ix;
+        lb_h2_product(w.da, oxc, u, aWf1);
+        lb_h2_product(w.da, oxo, u, aWf0);
+        lb_h2_product(w.dg, oxc, u, aWg1);
+        lb_h2_product(w.dg, oxo, u, aWg0);
+        if (HAS_DO || HAS_U) lb_h2_product(w.dov, w.z, wg_id * (1.f / 16384.f), aWp);
     };
     auto wgrad = [&](const WOps& w) {
         if constexpr (H2W) {
@@ -775,7 +870,16 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
         BST(c1);
 #endif
         WOps w;
-        take(tile, grp, xc, xo, w);
+        WOpsT wt;
+        float xcw[16], xow[16];                           // this tile's x (the registers are fetched into again below)
+        if constexpr (PL) {
+            take_t(grp, wt);
+            wg_ig = pa_ig; wg_id = pa_id;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) { xcw[s] = xc[s]; xow[s] = xo[s]; }
+        } else {
+            take(tile, grp, xc, xo, w);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the patches are in registers: their slots are free
 #ifdef WN_BWD_STAMPS
         BST(c2);
@@ -785,7 +889,8 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
         fetch_x(tile + stride, xc, xo);
         if (tile + 2 * stride < last) fetch_a(tile + 2 * stride, grp, dzb);
         // one basic block: 80 weight-gradient MFMAs of `tile` and the first half of the next tile
-        wgrad(w);
+        if constexpr (PL) wgrad_t(tile, wt, xcw, xow);
+        else wgrad(w);
         phase_a(tile + stride, ngrp, dza);
         stores_in_flight = store_vu(tile + stride);
 #ifdef WN_BWD_STAMPS
@@ -799,9 +904,16 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
     if (any) {
         if (stores_in_flight) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        WOps w;
-        take(tile, pbase + (it & 1) * 4096, xc, xo, w);
-        wgrad(w);
+        if constexpr (PL) {
+            WOpsT wt;
+            take_t(pbase + (it & 1) * 4096, wt);
+            wg_ig = pa_ig; wg_id = pa_id;
+            wgrad_t(tile, wt, xc, xo);
+        } else {
+            WOps w;
+            take(tile, pbase + (it & 1) * 4096, xc, xo, w);
+            wgrad(w);
+        }
     }
 
     }
