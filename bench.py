@@ -349,7 +349,8 @@ def main():
         units = {
             # name: (bound, algorithmic amount per launch, launches per step, kernels for PMC traffic)
             "wn_layer_bwd": ("hbm", es * (3 * Cr + Cs + 2 * Cd) * n_col, nl,
-                             ["wn::k_layer_bwd_chainsp<true, true, true, true, true>", "wn::k_layer_bwd_chainsp<true, true, true, true, false>",
+                             ["wn::k_layer_bwd_chainsp<true, true, true, true, true, 4>", "wn::k_layer_bwd_chainsp<true, true, true, true, false, 4>",
+                              "wn::k_layer_bwd_chainsp<true, true, true, true, true>", "wn::k_layer_bwd_chainsp<true, true, true, true, false>",
                               "wn::k_layer_bwd_chainsp<true, true, true, true>", "wn::k_layer_bwd_chainsp<true, true, true>"]),
             "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl,
                              ["wn::k_layer_fwd_h2_t1<2>", "wn::k_layer_fwd_mfma32_t1<2, false>", "wn::k_layer_fwd_mfma32_t1<true, false>"]),
