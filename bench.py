@@ -32,6 +32,20 @@ B_PER_GPU, T = 8, 16384
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 F32_MFMA_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
 BF16X3_PEAK_TF = 2500.0 / 6.0  # fp32-equivalent peak of a 6-term bf16 split product on the ~2.5 PF dense bf16 MFMA
+# what the matrix cores multiply in each mode of WnExec.precision (storage and accumulation are fp32 in all of them)
+GEMM_MODE_TEXT = {
+    "fp32": "every contraction on fp32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products",
+    "bf16x3": "skip-path and head contractions on bf16x3 split products (three bf16 parts per operand, six "
+              "v_mfma_f32_32x32x16_bf16 per product, error <= 3*2^-27 relative per product); the fused 32-channel layer "
+              "kernels (dilated convs, gate, residual projection, their backward) on exact fp32-input MFMA",
+    "fp16x2": "EVERY contraction of the step except the head convolutions -- the fused layer forward, the chained layer "
+              "backward, the skip sum, dz, dWs -- on fp16x2 split products: operands scaled by a power of two (per tile "
+              "from the wave's own maximum in the layer kernels, from a measured absmax on the skip path) and split into "
+              "two fp16 parts, three v_mfma_f32_32x32x16_f16 per product (error <= 2^-21 relative per product + 2^-24 of "
+              "the tile maximum), fp32 accumulation; head convolutions on bf16x3 (six terms).  Not the reference's fp32 "
+              "products: held to the same parity bars (logits 1e-4, every gradient 1e-4 relative, tokens bit-exact)",
+    "bf16": "operands rounded to bf16 once, fp32 accumulation (config 5's arithmetic; not fp32-accurate)",
+}
 
 
 def make_batch(rank, world, iw):
@@ -191,17 +205,33 @@ def main():
     ap.add_argument("--decode-samples", type=int, default=16000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
+    ap.add_argument("--no-exact-fp32", action="store_true", help="skip the exact-fp32-MFMA timing of the same step")
     ap.add_argument("--no-wide", action="store_true", help="skip the config-5 (128/512 channels, bf16 operands) side measurement")
     ap.add_argument("--no-graph", action="store_true", help="time op-by-op launches instead of hipGraph replays")
     ap.add_argument("--wide-only", action="store_true", help="only the config-5 side measurement (profiling passes)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: start the N ranks as CHILD processes (one per GPU, torch.distributed.run on
+        # 127.0.0.1) and pass rank 0's JSON line through.  Nothing in this process has touched the GPU yet (no HIP call,
+        # no torch.cuda query), and nothing is exec'ed: the launcher is a subprocess and we exit with its code.
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
+        env.setdefault("OMP_NUM_THREADS", "8")
+        raise SystemExit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
     if os.environ.get("WAVENET_BENCH_SHARE_GPU") == "1":      # test hook: several ranks on one device over gloo
         local = 0
     torch.cuda.set_device(local)
@@ -284,12 +314,10 @@ def main():
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": spinup,
         "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "gemm_mode": {"fp32": "exact fp32 MFMA",
-                      "bf16x3": "bf16x3 split products (six terms), fp32 accumulate (fp32-accurate; layer kernels exact fp32 MFMA)",
-                      "fp16x2": "skip-path contractions on fp16x2 split products (three terms, operands scaled by a power "
-                                "of two from their measured range), head on bf16x3, fp32 accumulate (fp32-accurate: same 1e-4 "
-                                "parity bars; layer kernels exact fp32 MFMA)",
-                      "bf16": "bf16 operands"}[_lib.get_gemm_precision()],
+        "gemm_mode": GEMM_MODE_TEXT[_lib.get_gemm_precision()],
+        "dtype_note": "dtype names STORAGE and ACCUMULATION (fp32 tensors in HBM, fp32 MFMA accumulators); what the matrix "
+                      "cores multiply is in gemm_mode; exact_fp32_ms_per_step is the same step with every contraction on "
+                      "fp32-input MFMA (v_mfma_f32_32x32x2_f32)",
         "config": {"workload": "cfg2 train step: 4 blocks x 10 dilations (1..512), 32 residual / 256 skip ch, "
                                "16 kHz, %d clips x 16384 samples per GPU, loss over last 12290 columns, "
                                "fwd + bwd + clip + Adam%s" % (B_PER_GPU, " + RCCL all-reduce" if world > 1 else ""),
@@ -301,6 +329,21 @@ def main():
         "entry_point_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
     }
 
+    if rank == 0 and world == 1 and not args.no_exact_fp32 and _lib.get_gemm_precision() != "fp32":
+        # ---- the same step with every contraction on fp32-input MFMA (the reference's own arithmetic): 10 graph replays
+        try:
+            net.gemm_precision = "fp32"
+            g32 = TrainStepGraph(net, x, tgt)
+            dt32 = timed(lambda: g32.step(), 10, 3)
+            out["exact_fp32_ms_per_step"] = dt32 * 1e3
+            out["exact_fp32_samples_per_s"] = samples / dt32
+            del g32
+        except Exception as e:
+            out["exact_fp32_ms_per_step"] = None
+            sys.stderr.write("exact-fp32 step failed (%s: %s)\n" % (type(e).__name__, e))
+        finally:
+            net.gemm_precision = None
+            torch.cuda.empty_cache()
     if rank == 0 and world == 1:
         # ---- fused residual-stack forward (the north star's roofline target) -------------------
         with torch.no_grad():
@@ -326,15 +369,31 @@ def main():
                     "read-modify-write; the deferred skip sum does not move those bytes, so frac_of_hbm_8TBps can exceed 1: "
                     "layer_traffic_frac is the layer kernel's measured HBM bytes / its time / 8 TB/s",
         }
-        tfile = next((f for f in (os.path.join(ROOT, "profiles", "r2_hbm_traffic.json"),
-                                  os.path.join(ROOT, "profiles", "r1_hbm_traffic.json")) if os.path.exists(f)), None)
-        pmc = json.load(open(tfile))["kernels"] if tfile else {}
+        # measured HBM bytes per launch: the newest rocprofv3 PMC summary committed under profiles/ (PMC counters cannot be
+        # collected from inside the bench); `traffic_source` says which file, and the file says which commit it measured
+        import glob
+        import re
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_hbm_traffic.json")),
+                        key=lambda f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)))
+        tfile = tfiles[-1] if tfiles else None
+        tdoc = json.load(open(tfile)) if tfile else {}
+        pmc = tdoc.get("kernels", {})
+        traffic_source = {"file": os.path.relpath(tfile, ROOT), "measured_at_commit": tdoc.get("commit"),
+                          "note": tdoc.get("note")} if tfile else None
 
-        def pmc_bytes(names):
-            got = [pmc[k]["hbm_bytes_per_launch"] for k in names if k in pmc]
-            return float(sum(got)) if got else None
-        fb = pmc_bytes(["wn::k_layer_fwd_h2_t1<0>"]) or pmc_bytes(["wn::k_layer_fwd_mfma32_t1<0, false>", "wn::k_layer_fwd_mfma32_t1<false, false>"])
+        def pmc_find(patterns):
+            """(kernel name, HBM bytes per launch) of the first pattern that matches a kernel of the PMC summary; among the
+            matches of one pattern the kernel with the most profiled launches.  Patterns are regular expressions on the
+            demangled name, written so that a new trailing template parameter does not break them."""
+            for pat in patterns:
+                hits = [(v.get("fetch_launches_averaged", 0), k) for k, v in pmc.items() if re.match(pat, k)]
+                if hits:
+                    k = max(hits)[1]
+                    return k, float(pmc[k]["hbm_bytes_per_launch"])
+            return None, None
+        fk, fb = pmc_find([r"wn::k_layer_fwd_h2\w*<0\b", r"wn::k_layer_fwd_mfma32_t1<0\b"])
         if fb:
+            out["stack_forward"]["layer_traffic_kernel"] = fk
             out["stack_forward"]["layer_traffic_bytes"] = fb
             out["stack_forward"]["layer_traffic_frac"] = fb / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         # ---- roofline of the dominant unit of the TIMED REGION (the training step) -------------------
@@ -347,33 +406,26 @@ def main():
         n_colw = B_PER_GPU * (T - iw)
         es = 4
         units = {
-            # name: (bound, algorithmic amount per launch, launches per step, kernels for PMC traffic)
-            "wn_layer_bwd": ("hbm", es * (3 * Cr + Cs + 2 * Cd) * n_col, nl,
-                             ["wn::k_layer_bwd_chainsp<true, true, true, true, true, 4>", "wn::k_layer_bwd_chainsp<true, true, true, true, false, 4>",
-                              "wn::k_layer_bwd_chainsp<true, true, true, true, true>", "wn::k_layer_bwd_chainsp<true, true, true, true, false>",
-                              "wn::k_layer_bwd_chainsp<true, true, true, true>", "wn::k_layer_bwd_chainsp<true, true, true>"]),
-            "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl,
-                             ["wn::k_layer_fwd_h2_t1<2>", "wn::k_layer_fwd_mfma32_t1<2, false>", "wn::k_layer_fwd_mfma32_t1<true, false>"]),
-            "wn_skip_sum_fwd": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<0, 0, 3, 4>", "wn::k_colgemm_b3<0, 0, 6, 4>", "wn::k_colgemm_b3<0, 0, false, 4>"]),
-            "wn_skip_sum_bwd_dw": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_wgrad_b3w<false, 0, 3>", "wn::k_wgrad_b3w<false, 0, 6>", "wn::k_wgrad_b3w<false, 0, false>"]),
-            "wn_skip_sum_bwd_dz": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, ["wn::k_colgemm_b3<2, 0, 3, 4>", "wn::k_colgemm_b3<2, 0, 6, 4>", "wn::k_colgemm_b3<2, 0, false, 4>"]),
+            # name: (bound, algorithmic amount per launch, launches per step, kernel-name patterns for the PMC traffic)
+            "wn_layer_bwd": ("hbm", es * (3 * Cr + Cs + 2 * Cd) * n_col, nl, [r"wn::k_layer_bwd_chain\w*<true\b", r"wn::k_layer_bwd_chain"]),
+            "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl, [r"wn::k_layer_fwd_h2\w*<2\b", r"wn::k_layer_fwd_mfma32_t1<2\b"]),
+            "wn_skip_sum_fwd": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, [r"wn::k_colgemm_b3<0, 0,"]),
+            "wn_skip_sum_bwd_dw": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, [r"wn::k_wgrad_b3w<false, 0,"]),
+            "wn_skip_sum_bwd_dz": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, [r"wn::k_colgemm_b3<2, 0,"]),
         }
         dom = max(units, key=lambda k: per_step.get(k, 0.0))
         bound, amount, launches, knames = units[dom]
         launch_ms = per_step[dom] / launches
-        traffic = None
-        for kn in knames:                                   # first name the PMC summary knows (names change with templates)
-            if kn in pmc:
-                traffic = float(pmc[kn]["hbm_bytes_per_launch"])
-                break
-        # flops one launch of the dominant unit really executes (fp32 MFMA in the layer kernels)
+        traffic_kernel, traffic = pmc_find(knames)
+        # fp32-equivalent flops of one launch of the dominant unit
         layer_flops = {"wn_layer_bwd": 2 * 2 * (2 * 2 * Cr * Cd + Cd * Cr) * n_col, "wn_layer_fwd": 2 * (2 * 2 * Cr * Cd + Cd * Cr) * n_col}
         # matrix peak of the fused layer kernels: fp32 MFMA, or three f16 MFMAs per product under fp16x2
         layer_peak = 2500.0 / 3.0 if _lib.get_gemm_precision() == "fp16x2" else F32_MFMA_PEAK_TF
         if bound == "hbm":
             ach = amount / (launch_ms * 1e-3) / 1e9
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "launch_ms": launch_ms,
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_kernel": traffic_kernel,
+                               "traffic_source": traffic_source, "launch_ms": launch_ms,
                                "algorithmic_bytes_per_launch": amount,
                                "traffic_frac": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                                "mfma_frac": layer_flops.get(dom, 0) / (launch_ms * 1e-3) / 1e12 / layer_peak,
@@ -387,22 +439,27 @@ def main():
             ach = amount / (launch_ms * 1e-3) / 1e12
             peak = {"fp32": F32_MFMA_PEAK_TF, "fp16x2": 2500.0 / 3.0}.get(_lib.get_gemm_precision(), BF16X3_PEAK_TF)
             out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak,
-                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                               "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_kernel": traffic_kernel,
+                               "traffic_source": traffic_source,
                                "launch_ms": launch_ms, "flops_per_launch": amount,
                                "note": "fp32-equivalent flops; peak = dense 16-bit MFMA / terms of the split product"}
         out["mfma_units"] = {k: {"ms": per_step[k], "TFLOPs": units[k][1] / (per_step[k] * 1e-3) / 1e12}
                              for k in units if units[k][0] == "mfma" and k in per_step}
         # ---- AR decode, config 4: 16k samples on one GPU, persistent per-layer state -----------
         if not args.no_decode:
-            # decode with the seeded initial weights (not the ones the timed steps just trained), so that the first 256
-            # tokens can be held against the committed oracle trace tests/golden/cfg4_decode_trace.npz
+            # decode with the seeded initial weights (not the ones the timed steps just trained), so that the first tokens
+            # (2,048 of them) can be held against the committed oracle trace tests/golden/cfg4_decode_trace.npz
             n = args.decode_samples
             u = np.random.RandomState(7).random_sample(n)
             gold = None
             gf = os.path.join(ROOT, "tests", "golden", "cfg4_decode_trace.npz")
-            if os.path.exists(gf) and n >= 256:
+            if os.path.exists(gf):
                 gold = np.load(gf)
-                u[:256] = gold["uniforms"]
+                ng = int(gold["tokens"].shape[0])
+                if n >= ng:
+                    u[:ng] = gold["uniforms"]
+                else:
+                    gold = None
             net.load_state_dict(FasterWaveNet(p, seed=1234).state_dict())
             net.generate(64, u)                                           # warm-up (creates the handle)
             torch.cuda.synchronize()
@@ -414,9 +471,10 @@ def main():
                                   "workload": "cfg4: faster_wavenet queue-cached decode, window 4094, 1 GPU",
                                   "token_checksum": int(toks.sum().item())}
             if gold is not None:
-                first = toks[:256].cpu().numpy()
-                out["ar_generate"]["golden_first_256_tokens_match"] = bool(np.array_equal(first, gold["tokens"].astype(np.int32)))
-                out["ar_generate"]["golden_first_256_checksum"] = [int(first.sum()), int(gold["tokens"].astype(np.int64).sum())]
+                first = toks[:ng].cpu().numpy()
+                out["ar_generate"]["golden_tokens_compared"] = ng
+                out["ar_generate"]["golden_tokens_match"] = bool(np.array_equal(first, gold["tokens"].astype(np.int32)))
+                out["ar_generate"]["golden_checksum"] = [int(first.sum()), int(gold["tokens"].astype(np.int64).sum())]
         if not args.no_wide:
             out["wide_channel"] = wide_channel_step(rank, world)
         if not args.no_cpu_baseline:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 2
+#define WN_ABI_VERSION 3
 #define WN_OK      0
 #define WN_EARG   -1
 #define WN_ESHAPE -2
@@ -64,14 +64,28 @@ const char* wn_last_error(void);
  * Storage stays fp32 in all of them; the fused 32-channel layer kernels always multiply in fp32.
  * ws / ws_bytes: device scratch, at least wn_exec_workspace_bytes() for the model and batch; its contents are dead when the
  * call's kernels have run, so ONE buffer per stream serves every call on that stream (never one buffer for two streams).
- * ex == NULL means { WN_GEMM_BF16X3, NULL, 0 }: fine for calls that need no scratch, WN_EARG (with the byte count) otherwise. */
+ * flags (ABI 3; the library reads NO environment variable and keeps no switch of its own -- what used to be
+ * WAVENET_HIP_FORCE_GENERIC / _NO_FUSED_WIDE / _FWD_T1_MIN_BLOCKS inside the .so are per-call fields here):
+ *   WN_EXEC_FORCE_GENERIC   every kernel of the call from the any-shape correctness path (generic_kernels.hip), fp32
+ *   WN_EXEC_NO_FUSED_WIDE   the 128/128-channel bf16-operand layer forward as two launches instead of one (diagnostic)
+ * fwd_t1_min_blocks: launch size (workgroups of four 32-column tiles) from which the fused 32-channel layer forward takes its
+ * one-tile-per-wave form; 0 = the library's default (512: every CU gets two to four workgroups), n > 0 = n (1 = always:
+ * parity tests of that kernel at small sizes), < 0 = never.
+ * ex == NULL means { WN_GEMM_BF16X3, 0, NULL, 0, 0 }: fine for calls that need no scratch, WN_EARG (with the byte count)
+ * otherwise. */
 enum { WN_GEMM_FP32 = 0, WN_GEMM_BF16X3 = 1, WN_GEMM_BF16 = 2, WN_GEMM_FP16X2 = 3 };
+#define WN_EXEC_FORCE_GENERIC 1u
+#define WN_EXEC_NO_FUSED_WIDE 2u
 typedef struct WnExec {
     int precision;
+    unsigned flags;
     void* ws;
     size_t ws_bytes;
+    int fwd_t1_min_blocks;
+    int reserved;                     /* 0 */
 } WnExec;
-/* 1 if the fp32-MFMA fast path covers this residual-layer shape, 0 if the generic path runs */
+/* 1 if the fused MFMA kernels cover this residual-layer shape (a pure shape query; a call with WN_EXEC_FORCE_GENERIC
+ * runs the generic kernels whatever this says), 0 if the generic / wide paths run */
 int wn_layer_fast_path(int Cr, int Cd, int fw);
 
 /* ---- A10: first causal layer on integer tokens (data.py:61-68 one-hot + wavenet.py:298-301) ----
@@ -165,7 +179,7 @@ typedef struct WnStackDesc {
  * with dout == NULL.  Loss and gradients are unchanged.                                              */
 /* 1 if wn_stack_bwd needs tanh saved (f); 0 if every layer runs on the fused 32-channel kernels without conv / projection
  * biases: then f may be NULL in both calls (only z and sigmoid are kept; tanh = z / sigmoid is recovered by the backward). */
-int wn_stack_saves_tanh(const WnStackDesc* d);
+int wn_stack_saves_tanh(const WnStackDesc* d, const WnExec* ex);
 int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, float* f, float* g,
                  float* skip, int B, int T, int t_off, int compat_zero_prefix, int window_only, const WnExec* ex, void* stream);
 size_t wn_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T);
@@ -189,7 +203,8 @@ int wn_softmax_fwd(const float* logits, float* prob, int N, int Q, void* stream)
  * (softmax - onehot) / n_norm.  Rows are b*Tw + t, as after the reference's transpose(0,3,2,1) + reshape.  A row whose
  * target is -1 is ignored (no loss, zero gradient) as chainer.functions.softmax_cross_entropy does; so is any other target
  * outside [0, Q) -- nothing is read out of bounds.  n_norm = the number of rows that count (Chainer: labels != -1);
- * n_norm <= 0 means N.                                                                                            */
+ * n_norm == 0 means N; n_norm < 0 (ABI 3): counted on the device from the labels (rows with a label in [0, Q), at least
+ * 1), for targets the host never saw -- one extra small launch, no synchronisation.                                 */
 #define WN_XENT_LOSS_WORDS 2056
 int wn_softmax_xent(const float* logits, const int32_t* target, float* loss, float* dlogits, int N, int Q,
                     int64_t n_norm, void* stream);
@@ -220,6 +235,7 @@ typedef struct WnDecoderDesc {
     const float* const* Ws; const float* const* bs;
     const float* const* head_W; const float* const* head_b;                     /* n_head      */
     int head_act;                     /* WN_ACT_ELU for FasterWaveNet, WN_ACT_RELU for WaveNet  */
+    unsigned flags;                   /* WN_EXEC_FORCE_GENERIC: never the specialised 32/256-channel decode kernel */
 } WnDecoderDesc;
 
 int wn_decoder_create(void** handle, const WnDecoderDesc* desc, void* stream);

@@ -12,6 +12,7 @@ hardware counted (SQ_INSTS_VALU_MFMA_MOPS_* x 512).
 Only the largest launches of each kernel (the benchmark-sized ones) are averaged."""
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
 
@@ -48,8 +49,8 @@ def traffic(fetch_csv, write_csv, out):
             ent["avg_ns_under_pmc"] = sum(ns for _, ns in big) / len(big)
         ent["hbm_bytes_per_launch"] = ent.get("fetch_bytes_per_launch", 0.0) + ent.get("write_bytes_per_launch", 0.0)
         res[name] = ent
-    json.dump({"note": "FETCH_SIZE x2 (gfx950 correction), KiB -> bytes; largest-grid launches only", "kernels": res},
-              open(out, "w"), indent=1)
+    json.dump({"note": "FETCH_SIZE x2 (gfx950 correction), KiB -> bytes; largest-grid launches only",
+               "commit": os.environ.get("WN_PROFILE_COMMIT"), "kernels": res}, open(out, "w"), indent=1)
     for k, v in res.items():
         print("%-56s %10.1f MB read %10.1f MB written" % (k[:56], v.get("fetch_bytes_per_launch", 0) / 1e6,
                                                          v.get("write_bytes_per_launch", 0) / 1e6))
@@ -75,7 +76,7 @@ def mfma(pmc_csv, out):
                 ent["mfma_flops_%s" % key] = 512.0 * sum(v for v, _ in bb) / len(bb)
         res[name] = ent
     json.dump({"note": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); flops = MOPS x 512",
-               "kernels": res}, open(out, "w"), indent=1)
+               "commit": os.environ.get("WN_PROFILE_COMMIT"), "kernels": res}, open(out, "w"), indent=1)
     for k, v in sorted(res.items(), key=lambda kv: -kv[1]["avg_ns_under_pmc"]):
         print("%-56s util %5.1f %%   %8.1f us   %.3g bf16 flop  %.3g f16 flop  %.3g f32 flop" % (
             k[:56], 100 * (v["mfma_util"] or 0), v["avg_ns_under_pmc"] / 1e3, v.get("mfma_flops_bf16", 0),

@@ -80,9 +80,9 @@ CFG2 = dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_cha
             residual_num_blocks=4, softmax_conv_channels=[256, 256])
 
 
-def cfg4_decode_trace(n=256, margin=2e-5):
+def cfg4_decode_trace(n=2048, margin=2e-5):
     """BASELINE config 4 (train_audio/generate.py:24-43 with --fast at config 2's 4 x 10 topology, window 4094): the
-    oracle's literal queue-cached generation for 256 steps.  Weights: the product's own seeded initialisation
+    oracle's literal queue-cached generation for 2,048 steps (round 2: 256; the first 256 are unchanged).  Weights: the product's own seeded initialisation
     (``WaveNet(Params, seed=1234)``, CPU only -- identical to the oracle's ``init_weights(p, 1234)``, asserted) so that
     bench.py can reproduce them without importing the oracle.  Uniforms start as ``RandomState(7).random_sample``; a draw
     that lands within ``margin`` of a boundary of the step's cumulative distribution is replaced by the next draw of a

@@ -42,7 +42,7 @@ def to_np(t):
 _SCRATCH = {}
 
 
-def EX(precision=None, nbytes=160 << 20):
+def EX(precision=None, nbytes=160 << 20, flags=None, t1_min_blocks=None):
     """WnExec for tests that call the C ABI directly: the module-default GEMM precision (or the given one) and a scratch
     buffer that lives as long as the test process."""
     import ctypes as C
@@ -51,6 +51,8 @@ def EX(precision=None, nbytes=160 << 20):
         _SCRATCH[nbytes] = torch.empty((nbytes,), device="cuda", dtype=torch.uint8)
     ex = _lib.WnExec()
     ex.precision = _lib.GEMM_PRECISIONS.index(precision or _lib.get_gemm_precision())
+    ex.flags = _lib.default_exec_flags() if flags is None else flags
+    ex.fwd_t1_min_blocks = _lib.default_fwd_t1_min_blocks() if t1_min_blocks is None else t1_min_blocks
     ex.ws, ex.ws_bytes = _SCRATCH[nbytes].data_ptr(), nbytes
     _SCRATCH["last"] = ex
     return C.byref(ex)

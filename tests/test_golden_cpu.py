@@ -79,6 +79,6 @@ def test_cfg4_decode_fixture_first_steps_and_weights():
     toks = R.generate(p, w, 3, z["uniforms"], fast=True, fast_head_act="elu", trace=tr)
     np.testing.assert_array_equal(toks, z["tokens"][:3].astype(np.int32))
     np.testing.assert_allclose(tr[0], z["probs_every8"][0], atol=1e-6)
-    assert z["tokens"].shape == (256,) and z["uniforms"].shape == (256,)
+    assert z["tokens"].shape == (2048,) and z["uniforms"].shape == (2048,) and z["probs_every8"].shape == (256, 256)
     cdf = np.cumsum(tr[2].astype(np.float64)); cdf /= cdf[-1]
     assert np.abs(cdf - z["uniforms"][2]).min() >= float(z["margin"])

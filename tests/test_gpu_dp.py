@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 
 OVER = dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 5,
             residual_num_blocks=2, softmax_conv_channels=[256, 256])
-B_PER, EXTRA, STEPS = 2, 150, 3
+CFG2 = dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 10,
+            residual_num_blocks=4, softmax_conv_channels=[256, 256])          # BASELINE configs[2]'s stack: 614,656 floats
+STEPS = 3
 
 
 def _free_port():
@@ -24,14 +26,14 @@ def _free_port():
     return p
 
 
-def _batches(iw):
+def _batches(iw, B_PER, EXTRA):
     rs = np.random.RandomState(3)
     T = iw + EXTRA
     return [(rs.randint(0, 256, (2 * B_PER, T)).astype(np.int32), rs.randint(0, 256, (2 * B_PER, EXTRA)).astype(np.int32))
             for _ in range(STEPS)]
 
 
-def _worker(rank, world, port, tmp, use_graph):
+def _worker(rank, world, port, tmp, use_graph, over, B_PER, EXTRA):
     import torch.distributed as dist
     from oracle import wavenet_ref as R
     from wavenet_amd import Params, TrainStepGraph, WaveNet
@@ -41,7 +43,7 @@ def _worker(rank, world, port, tmp, use_graph):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        p = R.make_params(**OVER)
+        p = R.make_params(**over)
         w = R.init_weights(p, 11)
         net = WaveNet(Params(p), seed=100 + rank)
         if rank == 0:
@@ -54,7 +56,7 @@ def _worker(rank, world, port, tmp, use_graph):
         assert net.optimizer.t == 5
         iw = net.input_width
         lo, hi = dp.shard(2 * B_PER)
-        batches = _batches(iw)
+        batches = _batches(iw, B_PER, EXTRA)
         dev = lambda a: torch.as_tensor(a).cuda()
         if use_graph:
             g = TrainStepGraph(net, dev(batches[0][0][lo:hi]), dev(batches[0][1][lo:hi]))
@@ -91,9 +93,11 @@ def _worker(rank, world, port, tmp, use_graph):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("use_graph", [True, False])
-def test_two_ranks_on_one_gpu_follow_the_global_batch_step(tmp_path, use_graph):
+@pytest.mark.parametrize("use_graph,over,B_PER,EXTRA", [(True, OVER, 2, 150), (False, OVER, 2, 150), (True, CFG2, 1, 100)])
+def test_two_ranks_on_one_gpu_follow_the_global_batch_step(tmp_path, use_graph, over, B_PER, EXTRA):
+    """The third case is BASELINE configs[2]'s own 4 x 10 stack (the 614,656-float arena all-reduced between the two
+    graphs), one clip per rank."""
     import torch.multiprocessing as mp
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), use_graph), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), use_graph, over, B_PER, EXTRA), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "ok0") and os.path.exists(tmp_path / "ok1")

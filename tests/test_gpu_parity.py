@@ -1254,6 +1254,13 @@ def test_cross_entropy_ignores_label_minus_one_like_chainer_and_rejects_other_ba
     # a device-resident target is trusted for its range but still cannot make the kernel read out of bounds
     l2 = net.cross_entropy(dev(logits), dev(bad))
     assert np.isfinite(float(l2))
+    # device-resident targets with ignored rows: the count of rows that enter the mean is taken on the device, so loss and
+    # gradient are the host-array path's (they used to be divided by N)
+    lt2 = dev(logits).requires_grad_(True)
+    l3 = net.cross_entropy(lt2, dev(tgt))
+    l3.backward()
+    assert abs(float(l3.detach()) - float(ref)) < 1e-5
+    np.testing.assert_allclose(to_np(lt2.grad)[:, :, 0, :].transpose(0, 2, 1).reshape(B * Tw, Q), x.grad.numpy(), atol=1e-7)
 
 
 @pytest.mark.gpu

@@ -24,8 +24,27 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libwavenet_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert _lib.lib().wn_abi_version() == 2
+    assert _lib.lib().wn_abi_version() == 3 == int(re.search(r"#define WN_ABI_VERSION (\d+)", hdr).group(1))
     assert not hasattr(lib, "wn_set_gemm_precision")          # ABI v2: no process-wide arithmetic mode
+    # ABI v3: no switch read from the process environment inside the library (they are WnExec.flags / fields now)
+    csrc = os.path.join(ROOT, "wavenet_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".hpp")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    # the binding's WnExec / WnDecoderDesc have the header's fields, in order
+    def fields(name):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                for part in decl.split(","):
+                    out.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", part)[-1])
+        return out
+    assert fields("WnExec") == [f[0] for f in _lib.WnExec._fields_]
+    assert fields("WnDecoderDesc") == [f[0] for f in _lib.WnDecoderDesc._fields_]
+    assert fields("WnStackDesc") == [f[0] for f in _lib.WnStackDesc._fields_]
     # scalar results that carry their own scratch: the binding's sizes are the header's
     assert int(re.search(r"#define WN_SQNORM_WORDS (\d+)", hdr).group(1)) == _lib.SQNORM_WORDS
     assert int(re.search(r"#define WN_XENT_LOSS_WORDS (\d+)", hdr).group(1)) == _lib.XENT_LOSS_WORDS

@@ -10,7 +10,7 @@ from typing import Dict, Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwavenet_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 XENT_LOSS_WORDS = 2056      # WN_XENT_LOSS_WORDS: loss[0] + per-workgroup sums of wn_softmax_xent
 SQNORM_WORDS = 1040          # WN_SQNORM_WORDS: out[0] + per-workgroup partial sums of wn_sqnorm
 
@@ -34,13 +34,14 @@ class WnDecoderDesc(C.Structure):
         ("causal_W", _pp), ("causal_b", _pp),
         ("Wf", _pp), ("bf", _pp), ("Wg", _pp), ("bg", _pp), ("Wp", _pp), ("bp", _pp), ("Ws", _pp), ("bs", _pp),
         ("head_W", _pp), ("head_b", _pp),
-        ("head_act", _i),
+        ("head_act", _i), ("flags", C.c_uint),
     ]
 
 
 class WnExec(C.Structure):
     """Per-call options of the entry points that hold a channel GEMM or need scratch (include/wavenet_hip.h)."""
-    _fields_ = [("precision", _i), ("ws", _p), ("ws_bytes", C.c_size_t)]
+    _fields_ = [("precision", _i), ("flags", C.c_uint), ("ws", _p), ("ws_bytes", C.c_size_t),
+                ("fwd_t1_min_blocks", _i), ("reserved", _i)]
 
 
 _ex = C.POINTER(WnExec)
@@ -70,7 +71,7 @@ _SIGS = {
     "wn_skip_sum_bwd_dz": (_i, [_i, _pp, _ip, _p, _pp, _i, _i, _i, _i, _i, _ex, _p]),
     "wn_skip_sum_bwd_dw": (_i, [_i, _pp, _ip, _p, _pp, _pp, _i, _i, _i, _i, _i, _ex, _p]),
     "wn_stack_fwd": (_i, [C.POINTER(WnStackDesc), _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _ex, _p]),
-    "wn_stack_saves_tanh": (_i, [C.POINTER(WnStackDesc)]),
+    "wn_stack_saves_tanh": (_i, [C.POINTER(WnStackDesc), _ex]),
     "wn_stack_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(WnStackDesc), _i, _i]),
     "wn_stack_bwd": (_i, [C.POINTER(WnStackDesc)] + [_p] * 8 + [_pp] * 8 + [_p, C.c_size_t, _i, _i, _i, _i, _ex, _p]),
     "wn_exec_workspace_bytes": (C.c_size_t, [C.POINTER(WnStackDesc), _i, _i, _i, _ip, _i, _i, _i]),
@@ -192,6 +193,25 @@ def stream_ptr() -> Optional[int]:
 
 
 GEMM_PRECISIONS = ("fp32", "bf16x3", "bf16", "fp16x2")
+WN_EXEC_FORCE_GENERIC, WN_EXEC_NO_FUSED_WIDE = 1, 2
+
+
+def default_exec_flags() -> int:
+    """WnExec.flags for models that do not set ``net.exec_flags`` themselves.  The library reads no environment variable
+    (ABI 3); these two diagnostic switches are host policy, read here, and travel with every call:
+    WAVENET_HIP_FORCE_GENERIC=1 (any-shape correctness kernels everywhere), WAVENET_HIP_NO_FUSED_WIDE=1."""
+    f = 0
+    if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1":
+        f |= WN_EXEC_FORCE_GENERIC
+    if os.environ.get("WAVENET_HIP_NO_FUSED_WIDE"):
+        f |= WN_EXEC_NO_FUSED_WIDE
+    return f
+
+
+def default_fwd_t1_min_blocks() -> int:
+    """WnExec.fwd_t1_min_blocks default: 0 (the library's own threshold) or WAVENET_HIP_FWD_T1_MIN_BLOCKS."""
+    return int(os.environ.get("WAVENET_HIP_FWD_T1_MIN_BLOCKS", "0") or 0)
+
 _default_precision = {"fp32": "fp32", "bf16": "bf16", "bf16x3": "bf16x3"}.get(os.environ.get("WAVENET_HIP_GEMM", ""), "fp16x2")
 
 

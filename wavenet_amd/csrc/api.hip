@@ -51,15 +51,15 @@ void* exec_scratch(size_t bytes, const char* what) {
     }
     return g_exec->ws;
 }
-// test hook: WAVENET_HIP_FORCE_GENERIC=1 routes every call to the generic kernels
-static bool force_generic() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("WAVENET_HIP_FORCE_GENERIC");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
+// WnExec.flags of the current call (no process state: the library reads no environment variable)
+bool exec_flag(unsigned f) { return g_exec && (g_exec->flags & f) != 0; }
+static bool force_generic() { return exec_flag(WN_EXEC_FORCE_GENERIC); }
+int exec_fwd_t1_min_blocks() {
+    const int v = g_exec ? g_exec->fwd_t1_min_blocks : 0;
+    return v == 0 ? 512 : v;
 }
+// the fused 32-channel kernels for this shape, unless the call pins the generic path
+bool layer_fast_path(int Cr, int Cd, int fw) { return !force_generic() && mfma_layer_supported(Cr, Cd, fw); }
 }  // namespace wn
 
 using namespace wn;
@@ -72,9 +72,7 @@ extern "C" {
 int wn_abi_version(void) { return WN_ABI_VERSION; }
 const char* wn_last_error(void) { return g_err; }
 
-int wn_layer_fast_path(int Cr, int Cd, int fw) {
-    return (!force_generic() && mfma_layer_supported(Cr, Cd, fw)) ? 1 : 0;
-}
+int wn_layer_fast_path(int Cr, int Cd, int fw) { return mfma_layer_supported(Cr, Cd, fw) ? 1 : 0; }
 
 int wn_embed_fwd(const int32_t* idx, const float* W, const float* bias, float* out, int B, int T, int Q, int C,
                  int fw, void* stream) {
@@ -119,7 +117,7 @@ int wn_layer_fwd(const float* x, const float* Wf, const float* bf, const float* 
     WN_CHECK_ARG(Z >= 0, "wn_layer_fwd: Z < 0");
     WN_CHECK_ARG((f_save == nullptr) == (g_save == nullptr), "wn_layer_fwd: f_save and g_save go together");
     WN_CHECK_ARG(out != x, "wn_layer_fwd: out must not alias x (taps read x[t-d])");
-    if (wn_layer_fast_path(Cr, Cd, fw))
+    if (layer_fast_path(Cr, Cd, fw))
         return mfma_layer_fwd(x, Wf, bf, Wg, bg, Wp, bp, out, z, f_save, g_save, B, T, d, Z, 0, as_stream(stream));
     if (!force_generic() && wide_layer_supported(Cr, Cd, fw) && (f_save || Cd <= Cr))
         return wide_layer_fwd(x, Wf, bf, Wg, bg, Wp, bp, out, z, f_save, g_save, B, T, Cr, Cd, fw, d, Z,
@@ -138,7 +136,7 @@ size_t wn_layer_bwd_workspace_floats(int B, int T, int Cr, int Cd, int fw) {
 }  // extern "C"
 namespace wn {
 bool wide_layer_in_use(int Cr, int Cd, int fw) {
-    return !wn_layer_fast_path(Cr, Cd, fw) && !force_generic() && wide_layer_supported(Cr, Cd, fw);
+    return !layer_fast_path(Cr, Cd, fw) && !force_generic() && wide_layer_supported(Cr, Cd, fw);
 }
 }  // namespace wn
 extern "C" {
@@ -154,7 +152,7 @@ int wn_layer_bwd(const float* x, const float* f, const float* g, const float* Wf
     POS(B); POS(T); POS(Cr); POS(Cd); POS(fw); POS(d);
     WN_CHECK_ARG(Z >= 0, "wn_layer_bwd: Z < 0");
     WN_CHECK_ARG(dout || dz_skip, "wn_layer_bwd: both dout and dz_skip are NULL");
-    if (wn_layer_fast_path(Cr, Cd, fw)) {
+    if (layer_fast_path(Cr, Cd, fw)) {
         int rc = mfma_layer_bwd(x, f, g, Wf, Wg, Wp, dout, dz_skip, dx, dWf, dWg, dWp, dab_ws, B, T, d, Z,
                                 as_stream(stream));
         if (rc) return rc;

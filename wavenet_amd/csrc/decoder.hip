@@ -44,8 +44,7 @@ struct Decoder {
 
 // the shape decoder_fast.hip is written for (BASELINE.json config 4 with the reference's default biases)
 static bool fast_shape(const WnDecoderDesc* d) {
-    const char* e = getenv("WAVENET_HIP_FORCE_GENERIC");
-    if (e && e[0] == '1') return false;
+    if (d->flags & WN_EXEC_FORCE_GENERIC) return false;
     if (!(d->Q == 256 && d->n_causal == 1 && d->fw_causal == 2 && d->fw == 2 && d->Cr == 32 && d->Cs == 256 &&
           d->n_head == 1 && d->head_channels[0] == 256 && d->head_channels[1] == 256 &&
           d->n_blocks * d->n_layers <= 128))

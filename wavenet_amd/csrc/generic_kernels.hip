@@ -561,6 +561,20 @@ __global__ void k_softmax(const float* __restrict__ logits, float* __restrict__ 
 
 // loss[0] = (sum of the per-block sums, in block order) / n_norm: no float atomics, the loss is bit-reproducible
 static constexpr int kXentPart = 8, kXentBlocks = 2048;
+// n_norm < 0: the number of rows that count was left in loss[1] by k_xent_count (labels in [0, Q))
+__global__ void k_xent_count(const int32_t* __restrict__ target, long long N, int Q, float* __restrict__ loss) {
+    __shared__ int red[16];
+    int c = 0;
+    for (long long i = threadIdx.x; i < N; i += blockDim.x) c += (target[i] >= 0 && target[i] < Q) ? 1 : 0;
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+        loss[1] = (float)(s > 0 ? s : 1);
+    }
+}
 __global__ void k_xent_final(float* __restrict__ loss, int nb, long long n_norm) {      // 256 threads, fixed tree
     __shared__ float red[4];
     float acc = 0.f;
@@ -568,7 +582,7 @@ __global__ void k_xent_final(float* __restrict__ loss, int nb, long long n_norm)
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n_norm;
+    if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (n_norm < 0 ? loss[1] : (float)n_norm);
 }
 
 __global__ void k_softmax_xent(const float* __restrict__ logits, const int32_t* __restrict__ target,
@@ -579,12 +593,12 @@ __global__ void k_softmax_xent(const float* __restrict__ logits, const int32_t* 
     int lane = threadIdx.x & 63;
     __shared__ float part[16];
     float rl_acc = 0.f;
+    const float invN = 1.f / (n_norm < 0 ? loss[1] : (float)n_norm);
     for (long long row = (long long)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64; row < N;
          row += (long long)gridDim.x * (blockDim.x / 64)) {
         float rl = 0.f;
         const float* r = logits + row * Q;
         const int tg = target[row];
-        const float invN = 1.f / (float)n_norm;
         if (tg < 0 || tg >= Q) {
             // Chainer's softmax_cross_entropy ignores label -1 (no loss, no gradient, not counted in the mean: n_norm); any
             // other label outside [0, Q) is treated the same way here instead of reading out of bounds
@@ -1090,9 +1104,11 @@ int generic_softmax_xent(const float* logits, const int32_t* target, float* loss
                          int Q, long long n_norm, hipStream_t s) {
     int blocks = cdiv(N, 4);
     if (blocks > kXentBlocks) blocks = kXentBlocks;
-    hipLaunchKernelGGL(k_softmax_xent, dim3(blocks), dim3(256), 0, s, logits, target, loss, dlogits, N, Q,
-                       n_norm > 0 ? n_norm : N);
-    hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(256), 0, s, loss, blocks, n_norm > 0 ? n_norm : N);
+    // n_norm > 0: that many rows count; 0: all N; < 0: counted on the device (labels in [0, Q)), one small launch
+    const long long nn = n_norm > 0 ? n_norm : (n_norm == 0 ? N : -1);
+    if (nn < 0) hipLaunchKernelGGL(k_xent_count, dim3(1), dim3(1024), 0, s, target, N, Q, loss);
+    hipLaunchKernelGGL(k_softmax_xent, dim3(blocks), dim3(256), 0, s, logits, target, loss, dlogits, N, Q, nn);
+    hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(256), 0, s, loss, blocks, nn);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

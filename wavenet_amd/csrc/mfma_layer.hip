@@ -499,11 +499,8 @@ int mfma_layer_pack_h2(int L, const float* const* Wf, const float* const* Wg, co
 
 // layer l of a packed stack; only the one-tile-per-wave form exists (small launches take the fp32 kernel)
 // launches of at least this many workgroups (4 tiles each) take the one-tile-per-wave kernels; smaller ones the looping
-// fp32 kernel.  WAVENET_HIP_FWD_T1_MIN_BLOCKS overrides the threshold (1 = always, used by the parity tests; 0 = never).
-static int t1_min_blocks() {
-    static const int v = getenv("WAVENET_HIP_FWD_T1_MIN_BLOCKS") ? atoi(getenv("WAVENET_HIP_FWD_T1_MIN_BLOCKS")) : 512;
-    return v;
-}
+// fp32 kernel.  WnExec.fwd_t1_min_blocks overrides the threshold (1 = always, used by the parity tests; < 0 = never).
+static int t1_min_blocks() { return exec_fwd_t1_min_blocks(); }
 bool mfma_layer_fwd_h2_ok(int B, int T, int t_live) {
     const int tile_lo = t_live > 0 ? t_live / 32 : 0;
     const long long nt = (long long)B * ((T + 31) / 32 - tile_lo);
@@ -544,7 +541,7 @@ int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float
     int blocks = (ntiles + 3) / 4;
     const bool hb = bf || bg || bp;
     // enough workgroups to give every CU two to four of them (8-16 waves): one tile per wave; otherwise the looping kernel.
-    // WAVENET_HIP_FWD_T1_MIN_BLOCKS overrides the threshold (1 = always, used by the parity tests; 0 = never).
+    // WnExec.fwd_t1_min_blocks overrides the threshold (1 = always, used by the parity tests; < 0 = never).
     const int t1_min = t1_min_blocks();
     if (t1_min > 0 && blocks >= t1_min) {
 #define FWD1_LAUNCH(SAVE, BIAS)                                                                              \

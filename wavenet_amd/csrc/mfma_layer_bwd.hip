@@ -244,8 +244,8 @@ __device__ __forceinline__ void lb_h2_product(const H2Op& a, const H2Op& b, floa
 // ---------------------------------------------------------------------------------------------
 // FROM_Z: the forward saved z and sigmoid only; `f` points at z and tanh is recovered as z / sigmoid (z = tanh * sigmoid was
 // rounded once in fp32, so the quotient is tanh to ~1.2e-7 relative; where sigmoid underflowed, da and dg are 0 anyway).
-template <bool HAS_DO, bool HAS_U, bool HAS_DZ, bool FROM_Z, bool H2W, int NW>
-__global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
+template <bool HAS_DO, bool HAS_U, bool HAS_DZ, bool FROM_Z, bool H2W>
+__global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
     const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
     const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, int vu_t0,
@@ -267,10 +267,10 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    static_assert(NW == 4 || (NW == 8 && H2W), "eight waves: the f16 form only");
-    constexpr bool PL = H2W && NW == 4;
-    // NW == 4: two slot groups per wave (software pipeline); NW == 8: one (two waves per SIMD hide each other's stalls)
-    float* pbase = wbase + wv * (NW == 4 ? kCWaveFloats : 4096);   // group k: pbase + 4096 k = {f | dout, g | z, V | da, U | dg}
+    constexpr int NW = kCWaves;
+    constexpr bool PL = H2W;
+    // two slot groups per wave (software pipeline)
+    float* pbase = wbase + wv * kCWaveFloats;   // group k: pbase + 4096 k = {f | dout, g | z, V | da, U | dg}
     int first, stride, last;
     if ((gridDim.x & 7) == 0) {
         const int per_xcd = (ntiles + 7) >> 3;
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
     float xc[16], xo[16];
     const bool any = first < last;
     bool stores_in_flight = false;                     // the last eight vector-memory operations are unconditional V/U stores
-    if (!H2W && any && NW == 4) { fetch_a(first, pbase, dza); fetch_x(first, xc, xo); }
+    if (!H2W && any) { fetch_a(first, pbase, dza); fetch_x(first, xc, xo); }
     if constexpr (H2W) {
         // fp16 x 2 images of the three weight matrices in A-operand order: 1 KB per (matrix, tap, k-step, part), lane
         // (j, h) element e = W[cd = bch(8 ks + e, h)][cr = j][tap] (Wp: [cr = bch(..)][cd = j]) scaled by one power of two
@@ -723,15 +723,14 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
         }
         mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wp.x), fabsf(s_wp.y)), fmaxf(fabsf(s_wp.z), fabsf(s_wp.w))));
         mw = lb_wave_max(mw);
-        float* red = wbase + (NW == 4 ? kCWaves * kCWaveFloats : 8 * 4096) - 8;   // last 32 bytes of the slot area: free until tile data lands there
+        float* red = wbase + kCWaves * kCWaveFloats - 8;   // last 32 bytes of the slot area: free until tile data lands there
         if (lane == 0) red[wv] = mw;
         // the first tile's fetch goes out only now, behind the weight loads (which the maximum above has waited for), and
         // the exchange of the four maxima uses an LDS-only barrier: splitting and scattering the images (~2 k cycles) runs
         // under the fetch's HBM round trip instead of behind it (a __syncthreads() here would drain it)
-        if (any && NW == 4) { fetch_a(first, pbase, dza); fetch_x(first, xc, xo); }
+        if (any) { fetch_a(first, pbase, dza); fetch_x(first, xc, xo); }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         mw = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        if (NW == 8) mw = fmaxf(mw, fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
         float sw;
         lb_pow2_scale(mw, sw, w_inv);
         char* img = reinterpret_cast<char*>(dyn);
@@ -769,79 +768,6 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
     unsigned long long st_wait = 0, st_take = 0, st_body = 0, st_n = 0, st_t0 = 0, st_t1 = 0;
     BST(st_k1);
 #endif
-    if constexpr (NW == 8) {
-        // Two waves per SIMD, no software pipeline: with f16 MFMAs the matrix time a pipelined wave used to cover its own
-        // VALU / LDS / memory stalls with is gone (matrix pipe 7 % busy); the sibling wave covers them instead.  One slot
-        // group per wave: a tile's inputs land in it, become the patches, and are consumed before the next fetch.
-        // Register budget 256 (two waves per SIMD): the transposed operands are taken, split and multiplied in two steps
-        // (the four conv-tap products, then dWp), and x is fetched only after the first half of the tile.
-        for (int tile = first; tile < last; tile += stride) {
-            const int b = tile / tiles_per_b;
-            const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
-            fetch_a(tile, pbase, dza);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            phase_a(tile, pbase, dza);
-            store_vu(tile);
-            fetch_x(tile, xc, xo);
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                float a_da[16], a_dg[16], b_xc[16], b_xo[16];
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // x has landed (the V / U stores with it)
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int r = 2 * s + h;
-                    const int tt = t0 + r;
-                    const int po = r * 32 + ((((j >> 2) ^ (r & 7)) << 2) | (j & 3));
-                    a_da[s] = pbase[2048 + po]; a_dg[s] = pbase[3072 + po];
-                    b_xc[s] = xc[s] * (tt < T ? 1.f : 0.f);
-                    b_xo[s] = xo[s] * ((tt < T && tt - d >= 0) ? 1.f : 0.f);
-                }
-                float mg = 0.f, mx = 0.f;
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    mg = fmaxf(mg, fmaxf(fabsf(a_da[s]), fabsf(a_dg[s])));
-                    mx = fmaxf(mx, fmaxf(fabsf(b_xc[s]), fabsf(b_xo[s])));
-                }
-                mg = lb_wave_max(mg);
-                mx = lb_wave_max(mx);
-                float sg, ig, sx, ix;
-                lb_pow2_scale(mg, sg, ig);
-                lb_pow2_scale(mx, sx, ix);
-                H2Op oda, odg, oxc, oxo;
-                lb_split16(a_da, sg, oda);
-                lb_split16(a_dg, sg, odg);
-                lb_split16(b_xc, sx, oxc);
-                lb_split16(b_xo, sx, oxo);
-                const float u = ig * ix;
-                lb_h2_product(oda, oxc, u, aWf1);
-                lb_h2_product(oda, oxo, u, aWf0);
-                lb_h2_product(odg, oxc, u, aWg1);
-                lb_h2_product(odg, oxo, u, aWg0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (HAS_DO || HAS_U) {
-                float a_do[16], b_z[16];
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    const int r = 2 * s + h;
-                    const int po = r * 32 + ((((j >> 2) ^ (r & 7)) << 2) | (j & 3));
-                    a_do[s] = pbase[po]; b_z[s] = pbase[1024 + po];
-                }
-                float md = 0.f;
-#pragma unroll
-                for (int s = 0; s < 16; ++s) md = fmaxf(md, fabsf(a_do[s]));
-                md = lb_wave_max(md);
-                float sd, id;
-                lb_pow2_scale(md, sd, id);
-                H2Op odo, oz;
-                lb_split16(a_do, sd, odo);
-                lb_split16(b_z, 16384.f, oz);
-                lb_h2_product(odo, oz, id * (1.f / 16384.f), aWp);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the patches are consumed: the slots may be fetched into
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else {
     if (any) {
         if (first + stride < last) fetch_a(first + stride, pbase + 4096, dzb);
         phase_a(first, pbase, dza);
@@ -915,11 +841,9 @@ __global__ __launch_bounds__(64 * NW, 1) void k_layer_bwd_chainsp(
             wgrad(w);
         }
     }
-
-    }
 #ifdef WN_BWD_STAMPS
     BST(st_k2);
-    if constexpr (NW == 4) {
+    {
         st_t1 = st_loop_end;
         const int gw = blockIdx.x * NW + wv;
         if (lane == 0 && gw < 1024) {
@@ -1147,31 +1071,21 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
     WN_CHECK_ARG(tiles_per_b > 0, "mfma_layer_bwd_chain: no live column");
     WN_CHECK_ARG(Vin || Uin || dzs, "mfma_layer_bwd_chain: no incoming gradient");
     const int ntiles = (int)nt;
-    // WAVENET_HIP_BWD_WAVES=8 selects the experimental two-waves-per-SIMD form of the f16 kernel (one slot group per
-    // wave, no software pipeline, 256 registers: 21 spilled).  Measured on config 2: 1.54 ms against 1.46 ms for the
-    // software-pipelined one-wave-per-SIMD form on the same box -- without a prefetch inside the wave its two
-    // vmcnt(0) waits per tile are exposed, and one sibling wave does not cover them.  Kept for the next attempt.
-    static const int waves_env = getenv("WAVENET_HIP_BWD_WAVES") ? atoi(getenv("WAVENET_HIP_BWD_WAVES")) : 4;
-    const int nw = (h2w && waves_env == 8) ? 8 : 4;
+    const int nw = kCWaves;
     int blocks = (ntiles + nw - 1) / nw;
     if (blocks > kCMaxBlocks) blocks = kCMaxBlocks;
     if (nwg) *nwg = blocks;
-#define CH_LAUNCH4(DO, UU, DZ, FZ, HW, NW_)                                                                        \
+#define CH_LAUNCH3(DO, UU, DZ, FZ, HW)                                                                            \
     do {                                                                                                           \
         static bool attr_set = false;                                                                              \
         if (!attr_set) {                                                                                           \
-            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chainsp<DO, UU, DZ, FZ, HW, NW_>), \
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chainsp<DO, UU, DZ, FZ, HW>),      \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kCLdsBytes));                   \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL((k_layer_bwd_chainsp<DO, UU, DZ, FZ, HW, NW_>), dim3(blocks), dim3(64 * NW_), kCLdsBytes, s, \
+        hipLaunchKernelGGL((k_layer_bwd_chainsp<DO, UU, DZ, FZ, HW>), dim3(blocks), dim3(256), kCLdsBytes, s,       \
                            x, f, g, Wp, Wf, Wg, Vin, Uin, dU, vu_t0, dzs, dz_t0, Vout, Uout, part, B, T, d, Z,       \
                            tile_lo, tiles_per_b, ntiles);                                                          \
-    } while (0)
-#define CH_LAUNCH3(DO, UU, DZ, FZ, HW)                          \
-    do {                                                        \
-        if (HW && nw == 8) CH_LAUNCH4(DO, UU, DZ, FZ, true, 8); \
-        else CH_LAUNCH4(DO, UU, DZ, FZ, HW, 4);                 \
     } while (0)
 #define CH_LAUNCH2(DO, UU, DZ, FZ)                            \
     do {                                                      \
@@ -1196,7 +1110,6 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
 #undef CH_LAUNCH
 #undef CH_LAUNCH2
 #undef CH_LAUNCH3
-#undef CH_LAUNCH4
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

@@ -19,7 +19,7 @@ static int zero_prefix(int T, int d, int fw) {           // wavenet.py:303-340
 // reads z and sigmoid only (tanh = z / sigmoid)
 static bool chain_capable(const WnStackDesc* d) {
     for (int l = 0; l < d->n_layers; ++l)
-        if (!wn_layer_fast_path(d->Cr, d->cd[l], d->fw) || (d->bf && d->bf[l]) || (d->bg && d->bg[l]) || (d->bp && d->bp[l]))
+        if (!layer_fast_path(d->Cr, d->cd[l], d->fw) || (d->bf && d->bf[l]) || (d->bg && d->bg[l]) || (d->bp && d->bp[l]))
             return false;
     return true;
 }
@@ -35,7 +35,10 @@ using namespace wn;
 
 extern "C" {
 
-int wn_stack_saves_tanh(const WnStackDesc* d) { return (check_desc(d) == WN_OK && chain_capable(d)) ? 0 : 1; }
+int wn_stack_saves_tanh(const WnStackDesc* d, const WnExec* ex) {
+    wn::ExecScope exec__(ex);
+    return (check_desc(d) == WN_OK && chain_capable(d)) ? 0 : 1;
+}
 
 size_t wn_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T) {
     if (!d || B <= 0 || T <= 0) return 0;
@@ -81,7 +84,7 @@ int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, floa
         // layers without conv / projection biases
         bool fast = true;
         for (int l = 0; l < L && fast; ++l)
-            fast = wn_layer_fast_path(d->Cr, d->cd[l], d->fw) != 0 && !(d->bf && d->bf[l]) && !(d->bg && d->bg[l]) &&
+            fast = layer_fast_path(d->Cr, d->cd[l], d->fw) && !(d->bf && d->bf[l]) && !(d->bg && d->bg[l]) &&
                    !(d->bp && d->bp[l]);
         if (fast) {
             live[L - 1] = (t_off / 32) * 32;
@@ -145,7 +148,15 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
     int rc = check_desc(d);
     if (rc) return rc;
     WN_CHECK_ARG(x && xs && z && g && ws && dWf && dWg && dWp, "wn_stack_bwd: NULL argument");
-    WN_CHECK_ARG(f || chain_capable(d), "wn_stack_bwd: this stack's backward needs tanh saved (wn_stack_saves_tanh)");
+    // ---- chained path: every layer on the MFMA kernels and no conv / projection bias GRADIENTS asked for.  It is the only
+    // path that recovers tanh from z / sigmoid, so f may be NULL exactly when it is taken (a desc without biases but with
+    // non-NULL dbf / dbg / dbp tables takes the per-layer path, which reads f).
+    bool chain = true;
+    for (int l = 0; l < d->n_layers && chain; ++l)
+        chain = layer_fast_path(d->Cr, d->cd[l], d->fw) && !(dbf && dbf[l]) && !(dbg && dbg[l]) && !(dbp && dbp[l]);
+    WN_CHECK_ARG(f || (chain && chain_capable(d)),
+                 "wn_stack_bwd: this stack's backward needs tanh saved (wn_stack_saves_tanh; bias-gradient tables select the "
+                 "per-layer path, which reads f)");
     WN_CHECK_ARG(dout || dskip, "wn_stack_bwd: no incoming gradient");
     WN_CHECK_ARG(ws_bytes >= wn_stack_bwd_workspace_bytes(d, B, T), "wn_stack_bwd: workspace too small");
     const size_t n = (size_t)B * T;
@@ -164,10 +175,6 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
     }
     float* gbuf[2] = {dab + lw, dab + lw + n * d->Cr};
     const int Tw = T - t_off;
-    // ---- chained path: every layer on the MFMA kernels and no conv / projection bias gradients --------------
-    bool chain = true;
-    for (int l = 0; l < L && chain; ++l)
-        chain = wn_layer_fast_path(d->Cr, d->cd[l], d->fw) && !(dbf && dbf[l]) && !(dbg && dbg[l]) && !(dbp && dbp[l]);
     if (dskip) {
         if (chain && d->Cs % 32 == 0) {
             // the chained layer kernels take dz as 0 below t_off and never read it there: only the loss window is computed

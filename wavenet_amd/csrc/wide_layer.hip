@@ -87,7 +87,7 @@ int wide_layer_fwd(const float* x, const float* Wf, const float* bf, const float
         }
         a.wsk = fw; a.M = Cd; a.ldo = Cd; a.out[0] = z;
         a.gate_z = z; a.gate_f = fs; a.gate_s = gs; a.gate_Z = Z;
-        static const bool no_fused = getenv("WAVENET_HIP_NO_FUSED_WIDE") != nullptr;     // diagnostic switch
+        const bool no_fused = exec_flag(WN_EXEC_NO_FUSED_WIDE);                          // diagnostic switch
         if (!no_fused && gemm_mode() == 2 && Cr == 128 && Cd == 128) {
             // bf16 operands, 128/128 channels (config 5): the residual projection runs in the same kernel, on z taken from
             // registers -- one launch per layer, z is written but never read back

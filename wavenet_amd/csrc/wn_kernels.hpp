@@ -44,7 +44,10 @@ struct ExecScope {
     explicit ExecScope(const WnExec* ex);
     ~ExecScope();
 };
-int gemm_mode();                       // WN_GEMM_* of the current call (WN_GEMM_FP32 under WAVENET_HIP_FORCE_GENERIC=1)
+int gemm_mode();                       // WN_GEMM_* of the current call (WN_GEMM_FP32 under WN_EXEC_FORCE_GENERIC)
+bool exec_flag(unsigned f);            // WnExec.flags of the current call
+int exec_fwd_t1_min_blocks();          // WnExec.fwd_t1_min_blocks with the default filled in
+bool layer_fast_path(int Cr, int Cd, int fw);   // fused 32-channel kernels for this shape in the current call
 void* exec_scratch(size_t bytes, const char* what);   // the caller's scratch; NULL + error text when it is too small
 bool exec_has_scratch(size_t bytes);                    // whether the current call brought that much
 // Device word holding the bits of max |x[i]| (a positive float orders like an unsigned): one pass per array and entry-point

@@ -79,6 +79,7 @@ class FasterWaveNet(WaveNet):
         for k in ("causal_W", "causal_b", "Wf", "bf", "Wg", "bg", "Wp", "bp", "Ws", "bs", "head_W", "head_b"):
             setattr(d, k, C.cast(keep[k], C.POINTER(C.c_void_p)))
         d.head_act = ACT[self.fast_head_activation]
+        d.flags = _lib.default_exec_flags() if self.exec_flags is None else int(self.exec_flags)
         return d, keep
 
     def _decoder(self):

@@ -57,6 +57,9 @@ class TrainStepGraph(object):
             torch.cuda.synchronize()
             with torch.no_grad():
                 net._arena.copy_(keep[0]); opt.m.copy_(keep[1]); opt.v.copy_(keep[2])
+            # whatever images the warm-up derived from the weights (the bf16 operand images of storage='bf16') are stale
+            # now, and must be rebuilt INSIDE the capture: a replay has no host code that could repack them
+            net._weights_changed()
             # thread_local: API calls of other threads (an RCCL watchdog, a data loader) must not invalidate the capture
             with torch.cuda.graph(self._g1, stream=self._stream, capture_error_mode="thread_local"):
                 self.loss = self._fwd_bwd()
@@ -92,6 +95,7 @@ class TrainStepGraph(object):
 
     def _opt(self):
         self.net.optimizer.update(self._gmult, lr_dev=self._lr)
+        self.net._weights_changed()
 
     def step(self, x=None, tgt=None):
         """One training step on (x, tgt) (default: the batch already in the static buffers).  Returns the loss

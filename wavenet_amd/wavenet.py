@@ -138,7 +138,7 @@ class _EmbedFn(_Fn):
         B, T = idx.shape
         dout = dout.contiguous()
         check(_lib.lib().wn_embed_bwd(ptr(idx), ptr(dout), ptr(W.grad), ptr(None if b is None else b.grad), B, T,
-                                      W.shape[1], W.shape[0], ctx.fw, ctx.net._exec(B), stream_ptr()), "wn_embed_bwd")
+                                      W.shape[1], W.shape[0], ctx.fw, ctx.net._exec(B, T), stream_ptr()), "wn_embed_bwd")
         return None, None, None, None, None
 
 
@@ -257,11 +257,11 @@ class _StackFn(_Fn):
         xs = torch.empty((L, B, T, Cr), device=dev_, dtype=torch.float32)
         z = torch.empty((B * T * ncd,), device=dev_, dtype=torch.float32)
         # tanh is saved only when the backward cannot take the chained path (which recovers it as z / sigmoid)
-        f = torch.empty_like(z) if train and _lib.lib().wn_stack_saves_tanh(desc) else None
+        f = torch.empty_like(z) if train and _lib.lib().wn_stack_saves_tanh(desc, net._exec(B, T)) else None
         g = torch.empty_like(z) if train else None
         skip = torch.empty((B, T - t_off, net._Cs), device=dev_, dtype=torch.float32)
         check(_lib.lib().wn_stack_fwd(desc, ptr(x), ptr(xs), ptr(z), ptr(f), ptr(g), ptr(skip), B, T, t_off,
-                                      1 if net.compat_zero_prefix else 0, 1 if window_only else 0, net._exec(B),
+                                      1 if net.compat_zero_prefix else 0, 1 if window_only else 0, net._exec(B, T),
                                       stream_ptr()), "wn_stack_fwd")
         ctx.net, ctx.t_off, ctx.shape, ctx.window_only = net, t_off, (B, T, Cr), bool(window_only)
         ctx.saved = (x, xs, z, f, g) if train else None
@@ -288,7 +288,7 @@ class _StackFn(_Fn):
         dx = torch.empty((B, T, Cr), device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         check(lib.wn_stack_bwd(desc, ptr(x), ptr(xs), ptr(z), ptr(f), ptr(g), ptr(dout), ptr(dskip), ptr(dx),
                                gt["wf"], gt["bf"], gt["wg"], gt["bg"], gt["wp"], gt["bp"], gt["ws"], gt["bs"],
-                               ptr(ws), nbytes, B, T, t_off, 1 if net.compat_zero_prefix else 0, net._exec(B),
+                               ptr(ws), nbytes, B, T, t_off, 1 if net.compat_zero_prefix else 0, net._exec(B, T),
                                stream_ptr()), "wn_stack_bwd")
         ctx.saved = None
         return dx, None, None, None, None, None
@@ -327,7 +327,7 @@ class _Embed16Fn(_Fn):
         d32 = torch.empty(dout.shape, device=dout.device, dtype=torch.float32)
         check(lib.wn16_cvt_to_f32(ptr(dout), ptr(d32), dout.numel(), stream_ptr()), "wn16_cvt_to_f32")
         check(lib.wn_embed_bwd(ptr(idx), ptr(d32), ptr(W.grad), ptr(None if b is None else b.grad), B, T,
-                               W.shape[1], W.shape[0], ctx.fw, ctx.net._exec(B), stream_ptr()), "wn_embed_bwd")
+                               W.shape[1], W.shape[0], ctx.fw, ctx.net._exec(B, T), stream_ptr()), "wn_embed_bwd")
         return None, None, None, None, None
 
 
@@ -545,6 +545,8 @@ class WaveNet(object):
         self.params = params
         self.storage = storage
         self.gemm_precision = None          # None: the module default (wavenet_amd.set_gemm_precision) at call time
+        self.exec_flags = None              # None: _lib.default_exec_flags(); else WN_EXEC_* bits for every call of this model
+        self.fwd_t1_min_blocks = None       # None: _lib.default_fwd_t1_min_blocks() (WnExec.fwd_t1_min_blocks)
         self._scratch, self._scratch_keep = {}, []
         self._pack16 = None
         self._w16_stale = True
@@ -668,25 +670,31 @@ class WaveNet(object):
     def _weights_changed(self):
         self._w16_stale = True
 
-    def _exec(self, B: int = 8):
+    def _exec(self, B: int = 8, T: int = 0):
         """WnExec for a library call on the current stream: this model's GEMM precision (``self.gemm_precision``, or the
-        module default) and a scratch buffer owned by (model, stream).  Buffers are never freed or moved once handed out
-        -- a captured graph keeps the pointer -- a larger batch gets a new, larger one."""
+        module default), its flags, and a scratch buffer owned by (model, stream), sized by ``wn_exec_workspace_bytes``
+        for the largest (B, T) seen so far.  Buffers are never freed or moved once handed out -- a captured graph keeps
+        the pointer -- a larger batch or a longer window gets a new, larger one."""
         lib = _lib.lib()
         key = (stream_ptr() or 0, self._arena.device.index)
         ent = self._scratch.get(key)
-        if ent is None or ent[1] < B:
+        if ent is None or ent[1] < B or ent[2] < T:
             p = self.params
             hc = int_array(p.softmax_conv_channels)
+            B, T = max(B, 8, ent[1] if ent else 0), max(T, ent[2] if ent else 0)
             nbytes = lib.wn_exec_workspace_bytes(self._stack_desc(), p.quantization_steps, p.causal_conv_channels[0],
-                                                 p.causal_conv_filter_width, hc, len(p.softmax_conv_channels), max(B, 8), 0)
+                                                 p.causal_conv_filter_width, hc, len(p.softmax_conv_channels), B, T)
             buf = torch.empty((nbytes,), device=self._arena.device, dtype=torch.uint8)
             self._scratch_keep.append(buf)
-            ent = (buf, max(B, 8))
+            ent = (buf, B, T)
             self._scratch[key] = ent
         ex = _lib.WnExec()
-        ex.precision = _lib.GEMM_PRECISIONS.index(self.gemm_precision or _lib.get_gemm_precision())
+        ex.flags = _lib.default_exec_flags() if self.exec_flags is None else int(self.exec_flags)
+        prec = self.gemm_precision or _lib.get_gemm_precision()
+        ex.precision = _lib.GEMM_PRECISIONS.index("fp32" if ex.flags & _lib.WN_EXEC_FORCE_GENERIC else prec)
         ex.ws, ex.ws_bytes = ent[0].data_ptr(), ent[0].numel()
+        ex.fwd_t1_min_blocks = (_lib.default_fwd_t1_min_blocks() if self.fwd_t1_min_blocks is None
+                                else int(self.fwd_t1_min_blocks))
         return C.byref(ex)
 
     def _pack16_if_stale(self):
@@ -924,7 +932,7 @@ class WaveNet(object):
             raise Exception("target_signal_data cannot be Variable")
         raw = self.to_variable(raw_network_output)
         _need_gpu(raw)
-        n_norm = 0
+        n_norm = -1            # device-resident targets: the rows that count (label != -1) are counted on the device
         if not isinstance(target_signal_data, torch.Tensor):
             # a host array (what the reference requires): labels are checked here -- Chainer type-checks them too -- and
             # -1 is chainer's ignore_label: such rows carry no loss and do not count in the mean
