@@ -258,10 +258,17 @@ class RefWaveNet:
             total = total + skip                         # int 0 seed, fixed order
         return out, total
 
-    def forward_softmax_block(self, x, apply_softmax=True, act="relu"):   # wavenet.py:584-593
+    def forward_softmax_block(self, x, apply_softmax=True, act="relu", first_relu_mask=None):   # wavenet.py:584-593
+        """``first_relu_mask`` (a 0/1 tensor shaped like x; a checker's device, not a reference feature): the ReLU in front of
+        the first head convolution is applied as a product with this mask instead of being re-decided from x.  Used by
+        the large-window parity test: a skip value within rounding distance of 0 makes a whole gradient term present in
+        one implementation and absent in the other, so gradients are compared at the SAME mask (the device's)."""
         out = x
         for i in range(len(self.p["softmax_conv_channels"]) - 1):
-            out = F.relu(out) if act == "relu" else F.elu(out)   # faster_wavenet.py:108
+            if i == 0 and first_relu_mask is not None and act == "relu":
+                out = out * first_relu_mask
+            else:
+                out = F.relu(out) if act == "relu" else F.elu(out)   # faster_wavenet.py:108
             W, b = self._W("softmax_%d" % i)
             out = F.conv2d(out, W, b)
         if apply_softmax:
@@ -281,13 +288,14 @@ class RefWaveNet:
         tgt = torch.as_tensor(np.asarray(target).reshape(-1).astype(np.int64))
         return F.cross_entropy(rows, tgt)
 
-    def train_loss(self, onehot, target):
+    def train_loss(self, onehot, target, first_relu_mask=None):
         """Loop body of train_audio/train.py:66-78 (forward + loss)."""
         tw = target.shape[1]
         out = self.forward_causal_block(onehot)
         out, skip = self.forward_residual_block(out)
         skip = skip[:, :, :, skip.shape[3] - tw:]        # slice_1d, train.py:73
-        logits = self.forward_softmax_block(skip, apply_softmax=False)
+        self.last_skip = skip.detach()
+        logits = self.forward_softmax_block(skip, apply_softmax=False, first_relu_mask=first_relu_mask)
         return self.cross_entropy(logits, target), logits
 
 
@@ -297,10 +305,14 @@ def onehot_t(idx: np.ndarray, Q: int, dtype=torch.float32) -> torch.Tensor:
     return torch.tensor(onehot_pixel_image(idx, Q), dtype=dtype)
 
 
-def train_step_grads(p, weights, idx_in, target, dtype=torch.float32):
-    """loss, logits and d loss / d every parameter (wavenet.py:515-519 backward)."""
+def train_step_grads(p, weights, idx_in, target, dtype=torch.float32, first_relu_mask=None, keep=None):
+    """loss, logits and d loss / d every parameter (wavenet.py:515-519 backward).  ``first_relu_mask`` (B, Cs, 1, Tw):
+    see RefWaveNet.forward_softmax_block; ``keep`` (a dict) receives the skip sum of the loss window."""
     net = RefWaveNet(p, weights, dtype=dtype, requires_grad=True)
-    loss, logits = net.train_loss(onehot_t(idx_in, p["quantization_steps"], dtype), target)
+    mask = None if first_relu_mask is None else torch.as_tensor(np.asarray(first_relu_mask), dtype=dtype)
+    loss, logits = net.train_loss(onehot_t(idx_in, p["quantization_steps"], dtype), target, first_relu_mask=mask)
+    if keep is not None:
+        keep["skip"] = net.last_skip.numpy()
     loss.backward()
     grads = {k: (v.grad.numpy().copy() if v.grad is not None else np.zeros(v.shape, v.detach().numpy().dtype))
              for k, v in net.w.items()}
