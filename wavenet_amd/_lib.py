@@ -9,7 +9,7 @@ import os
 from typing import Dict, Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwavenet_hip.so")
+LIB_PATH = os.environ.get("WAVENET_HIP_LIB") or os.path.join(_HERE, "libwavenet_hip.so")   # (override: same-box A/B of two builds)
 ABI_VERSION = 3
 XENT_LOSS_WORDS = 2056      # WN_XENT_LOSS_WORDS: loss[0] + per-workgroup sums of wn_softmax_xent
 SQNORM_WORDS = 1040          # WN_SQNORM_WORDS: out[0] + per-workgroup partial sums of wn_sqnorm
