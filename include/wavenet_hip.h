@@ -57,17 +57,21 @@ const char* wn_last_error(void);
  *   WN_GEMM_BF16X3  every operand split into three bf16 parts, six products (fp32-accurate; what NULL selects)
  *   WN_GEMM_BF16    operands rounded to bf16 once, fp32 accumulation
  *   WN_GEMM_FP16X2  the skip contraction and its two backward GEMMs: operands scaled by a power of two and split into two
- *                   fp16 parts, three products (fp32-accurate to 2^-21 at half the matrix work of BF16X3).  Weights and
- *                   tanh*sigmoid outputs use fixed scales (a weight outside +-2^7 makes the launch fall back to BF16X3),
- *                   gradients the power of two that fits their absolute maximum, measured on the device by one extra
- *                   pass (no host synchronisation).  The head convolutions keep the BF16X3 split.
- * Storage stays fp32 in all of them; the fused 32-channel layer kernels always multiply in fp32.
+ *                   fp16 parts, three products (fp32-accurate to 2^-21 at half the matrix work of BF16X3).  tanh*sigmoid
+ *                   outputs use a fixed scale (|z| <= 1); weights and gradients the power of two that fits their absolute
+ *                   maximum, measured on the device by one small extra pass each (no host synchronisation; ABI 3: the
+ *                   weights too -- a fixed 2^8 used to saturate weights above ~254).  The fused 32-channel layer kernels
+ *                   run the same split products with per-tile scales taken from the wave's own maximum.  The head
+ *                   convolutions keep the BF16X3 split.
+ * Storage and accumulation stay fp32 in all of them; under FP32 / BF16X3 / BF16 the fused 32-channel layer kernels multiply
+ * in exact fp32 (v_mfma_f32_32x32x2_f32).
  * ws / ws_bytes: device scratch, at least wn_exec_workspace_bytes() for the model and batch; its contents are dead when the
  * call's kernels have run, so ONE buffer per stream serves every call on that stream (never one buffer for two streams).
  * flags (ABI 3; the library reads NO environment variable and keeps no switch of its own -- what used to be
  * WAVENET_HIP_FORCE_GENERIC / _NO_FUSED_WIDE / _FWD_T1_MIN_BLOCKS inside the .so are per-call fields here):
  *   WN_EXEC_FORCE_GENERIC   every kernel of the call from the any-shape correctness path (generic_kernels.hip), fp32
  *   WN_EXEC_NO_FUSED_WIDE   the 128/128-channel bf16-operand layer forward as two launches instead of one (diagnostic)
+ *   WN_EXEC_NO_FWD_GROUPS   see the define
  * fwd_t1_min_blocks: launch size (workgroups of four 32-column tiles) from which the fused 32-channel layer forward takes its
  * one-tile-per-wave form; 0 = the library's default (512: every CU gets two to four workgroups), n > 0 = n (1 = always:
  * parity tests of that kernel at small sizes), < 0 = never.
@@ -76,6 +80,8 @@ const char* wn_last_error(void);
 enum { WN_GEMM_FP32 = 0, WN_GEMM_BF16X3 = 1, WN_GEMM_BF16 = 2, WN_GEMM_FP16X2 = 3 };
 #define WN_EXEC_FORCE_GENERIC 1u
 #define WN_EXEC_NO_FUSED_WIDE 2u
+#define WN_EXEC_NO_FWD_GROUPS 4u   /* fp16x2 stack forward: every layer its own launch (no k_layer_fwd_h2_grp); same results,
+                                      bit for bit -- A/B timing and the parity tests of the per-layer kernel */
 typedef struct WnExec {
     int precision;
     unsigned flags;

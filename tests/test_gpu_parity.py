@@ -580,6 +580,71 @@ def test_fast_generation_vs_oracle_golden(act):
     np.testing.assert_array_equal(buf[iw:], z["tokens"][:12])
 
 
+@pytest.mark.parametrize("B,T", [(1, 40), (2, 333), (3, 1000), (2, 2048), (8, 16384)])
+def test_grouped_layer_forward_is_the_per_layer_forward_bit_for_bit(B, T):
+    """k_layer_fwd_h2_grp (the d = 1 .. 16 layers of a block in one launch: inputs of the inner layers stay on chip, one
+    halo tile per seven recomputed) against the per-layer kernel k_layer_fwd_h2_t1 (WN_EXEC_NO_FWD_GROUPS): every
+    layer's output, z and sigmoid and the skip sum are IDENTICAL bit for bit -- same MFMAs, same per-tile scales -- at
+    ragged lengths, below one tile group, and at the bench's full size; the per-layer path itself is held to the oracle
+    by the tests above (ResidualConvLayer.__call__, wavenet.py:358-368, chained by wavenet.py:572-582)."""
+    if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1":
+        pytest.skip("generic kernels only")
+    p, w, net = build(CFG2)
+    net.gemm_precision = "fp16x2"
+    net.fwd_t1_min_blocks = 1
+    idx = dev(np.random.RandomState(T).randint(0, 256, (B, T)).astype(np.int32))
+    got = {}
+    for flags in (0, _lib.WN_EXEC_NO_FWD_GROUPS):
+        net.exec_flags = flags
+        c = net.forward_causal_block(idx)
+        out, s = net.forward_residual_block(c, t_off=0)
+        fn = s.grad_fn
+        while fn is not None and not hasattr(fn, "saved"):
+            fn = fn.next_functions[0][0] if fn.next_functions else None
+        x, xs, z, f, g = fn.saved
+        torch.cuda.synchronize()
+        got[flags] = (xs.clone(), z.clone(), g.clone(), s.detach().clone())
+    for a, b, what in zip(got[0], got[_lib.WN_EXEC_NO_FWD_GROUPS], ("layer outputs", "z", "sigmoid", "skip sum")):
+        assert torch.equal(a, b), what
+    # inference form (no sigmoid saved) through the same kernels
+    with torch.no_grad():
+        outs = []
+        for flags in (0, _lib.WN_EXEC_NO_FWD_GROUPS):
+            net.exec_flags = flags
+            o, s = net.forward_residual_block(net.forward_causal_block(idx))
+            outs.append((o.clone(), s.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_fast_step_full_window_output_is_the_references_shape_and_values():
+    """faster_wavenet.py:105-113 returns the softmax of the WHOLE rolled window, (1, Q, 1, W), every cached column under
+    the ELU head; ``keep_window`` + ``full_window=True`` reproduces that from a device-side ring of logits: all W columns
+    of eight consecutive steps against the oracle's literal restatement, and the newest-column face is unchanged."""
+    over = dict(quantization_steps=256, causal_conv_channels=[16], residual_conv_channels=[16] * 4,
+                residual_num_blocks=2, softmax_conv_channels=[32, 256])
+    p, w, net = build(over, cls=FasterWaveNet)
+    ref = R.RefFasterWaveNet(p, w, "elu")
+    iw = net.input_width
+    rs = np.random.RandomState(11)
+    buf = rs.randint(0, 256, (iw,)).astype(np.int32)
+    with pytest.raises(Exception, match="keep_window"):
+        net._forward_one_step(data.onehot_pixel_image(buf.reshape(1, -1), 256), full_window=True)
+    net.keep_window = True
+    for step in range(9):
+        x = data.onehot_pixel_image(buf[-iw:].reshape(1, -1), 256)
+        want = ref._forward_one_step(x, apply_softmax=True)
+        got = net._forward_one_step(x, apply_softmax=True, as_numpy=True, full_window=step > 0 and step != 5)
+        if step > 0 and step != 5:
+            assert got.shape == want.shape == (1, 256, 1, iw)
+            np.testing.assert_allclose(got, want, atol=2e-5)
+        else:                                           # the prefill call / a newest-column call in between
+            np.testing.assert_allclose(got[0, :, 0, -1], want[0, :, 0, -1], atol=2e-5)
+        buf = np.append(buf, [int(rs.randint(0, 256))]).astype(np.int32)
+    lg = net._forward_one_step(int(buf[-1]), apply_softmax=False, as_numpy=True, full_window=True)
+    want = ref._forward_one_step(data.onehot_pixel_image(buf[-iw:].reshape(1, -1), 256), apply_softmax=False)
+    np.testing.assert_allclose(lg, want, atol=1e-4)
+
+
 def test_fast_equals_slow_cfg2_topology_with_extra_causal_layer_and_fw3():
     """KAT-6 on the GPU: incremental decode == full-window forward, same head activation."""
     over = dict(quantization_steps=32, causal_conv_channels=[12, 8], causal_conv_filter_width=3,
@@ -1288,6 +1353,50 @@ def test_fp16x2_split_follows_the_gradient_range(scale):
     assert abs(float(loss.detach()) - loss_ref) < 1e-4
     for ln, kind, off, n, shape in net._spans:
         want = g["%s/%s" % (ln.name, kind)] * scale
+        got = to_np(net._grad_arena[off:off + n].view(shape))
+        assert np.isfinite(got).all()
+        assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-30), (ln.name, kind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wscale", [2.0 ** 10, 2.0 ** -9])
+def test_fp16x2_skip_contractions_follow_the_weight_range(wscale):
+    """the fp16 split of the skip-path GEMMs scaled weights by a fixed 2^8 and clamped at 65,000, so a weight
+    above ~254 was silently saturated.  The scale now comes from the weights' measured maximum: skip projections a
+    thousand times larger (or 500 times smaller) than usual -- skip sum, dz and dWs all see them -- still meet the
+    oracle (skip sum within 1e-5 of its largest entry, every gradient within 2e-4 of its tensor's largest)."""
+    if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1":
+        pytest.skip("generic kernels only")
+    over = dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 5, residual_num_blocks=2,
+                softmax_conv_channels=[256, 256])
+    p = R.make_params(**over)
+    w = R.init_weights(p, 1234)
+    for k in w:
+        if "projection_softmax" in k:
+            w[k] = (w[k] * wscale).astype(np.float32)
+        if k == "softmax_0/W":
+            w[k] = (w[k] / wscale).astype(np.float32)              # keep the logits in a sane range
+    assert max(np.abs(v).max() for k, v in w.items() if "projection_softmax" in k) > 300 or wscale < 1
+    net = WaveNet(Params(p), seed=0)
+    net.load_state_dict(w)
+    net.to_gpu()
+    net.gemm_precision = "fp16x2"
+    B, T, tw = 2, 400, 300
+    idx = np.random.RandomState(5).randint(0, 256, (B, T)).astype(np.int32)
+    tgt = np.random.RandomState(6).randint(0, 256, (B, tw)).astype(np.int32)
+    c = net.forward_causal_block(idx)
+    _, s = net.forward_residual_block(c, t_off=T - tw)
+    mask = (to_np(s) > 0).astype(np.float32)
+    keep = {}
+    loss_ref, _, g = R.train_step_grads(p, w, idx, tgt, first_relu_mask=mask, keep=keep)
+    assert np.abs(to_np(s) - keep["skip"]).max() <= 1e-5 * np.abs(keep["skip"]).max()
+    loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt)
+    net.zero_grads()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - loss_ref) < 1e-4
+    for ln, kind, off, n, shape in net._spans:
+        want = g["%s/%s" % (ln.name, kind)]
         got = to_np(net._grad_arena[off:off + n].view(shape))
         assert np.isfinite(got).all()
         assert np.abs(got - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-30), (ln.name, kind)

@@ -193,7 +193,7 @@ def stream_ptr() -> Optional[int]:
 
 
 GEMM_PRECISIONS = ("fp32", "bf16x3", "bf16", "fp16x2")
-WN_EXEC_FORCE_GENERIC, WN_EXEC_NO_FUSED_WIDE = 1, 2
+WN_EXEC_FORCE_GENERIC, WN_EXEC_NO_FUSED_WIDE, WN_EXEC_NO_FWD_GROUPS = 1, 2, 4
 
 
 def default_exec_flags() -> int:
@@ -205,6 +205,8 @@ def default_exec_flags() -> int:
         f |= WN_EXEC_FORCE_GENERIC
     if os.environ.get("WAVENET_HIP_NO_FUSED_WIDE"):
         f |= WN_EXEC_NO_FUSED_WIDE
+    if os.environ.get("WAVENET_HIP_NO_FWD_GROUPS") == "1":
+        f |= WN_EXEC_NO_FWD_GROUPS
     return f
 
 

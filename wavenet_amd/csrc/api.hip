@@ -41,6 +41,21 @@ const unsigned* exec_absmax(const float* x, long long n, hipStream_t s) {
     g_absmax_key[g_absmax_n] = x;
     return slots + g_absmax_n++;
 }
+unsigned* exec_word(const void* key, bool* fresh, hipStream_t s) {
+    *fresh = false;
+    if (!g_exec || !g_exec->ws || g_exec->ws_bytes < kExecTail) {
+        set_error("this call needs WnExec scratch (the fp16 split scales its operands by their measured range)");
+        return nullptr;
+    }
+    unsigned* slots = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(g_exec->ws) + g_exec->ws_bytes - kExecTail);
+    for (int i = 0; i < g_absmax_n; ++i)
+        if (g_absmax_key[i] == key) return slots + i;
+    if (g_absmax_n >= 16) { set_error("exec_word: more than 16 range words in one call"); return nullptr; }
+    if (hipMemsetAsync(slots + g_absmax_n, 0, sizeof(unsigned), s) != hipSuccess) { set_error("exec_word: memset failed"); return nullptr; }
+    g_absmax_key[g_absmax_n] = key;
+    *fresh = true;
+    return slots + g_absmax_n++;
+}
 bool exec_has_scratch(size_t bytes) { return g_exec && g_exec->ws && g_exec->ws_bytes >= bytes + kExecTail; }
 void* exec_scratch(size_t bytes, const char* what) {
     bytes += kExecTail;

@@ -51,4 +51,15 @@ __device__ __forceinline__ void lb_split16(const float (&v)[16], float s, H2Op& 
         }
 }
 
+// LDS-DMA of one 1 KB piece (global_load_lds_dwordx4: lane L's 16 bytes at `src` land at lds_dst + 16 L; lds_dst is
+// wave-uniform) as inline asm.  With the builtin, hipcc knows that LDS is written asynchronously and puts `s_waitcnt
+// vmcnt(0)` in front of every later LDS read that may alias it -- which also waits for every store issued since.  The asm
+// form is opaque to that pass: the kernel's own counted `s_waitcnt vmcnt(N)` (vector-memory operations retire in issue
+// order) is then the only wait, so every read of the destination must sit behind one, and a barrier that is meant to
+// publish the data needs an explicit wait in front of it (the compiler no longer drains vmcnt there by itself).
+__device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory");
+}
+
 }  // namespace wn

@@ -39,6 +39,7 @@ struct CGArgs {
     // stride ldo = 128) = Wp z + proj_bias + residual, Wp's image is the kernel's second image argument
     int h2_ok;                       // X is provably within the fp16 split's static range (z = tanh * sigmoid)
     const unsigned* xmax_dev;        // else: device word with the bits of max |X| (exec_absmax) -> dynamic power-of-two scale
+    const unsigned* wmax_dev;        // fp16 split: bits of max |W| over the launch's weight tiles (launch_colgemm_b3 fills it)
     const float* proj_W;             // Wp[128][128], row-major
     const float* proj_bias;
 };

@@ -35,7 +35,7 @@ static bool half2_mode() { return gemm_mode() == 3; }
 // gradients, whose magnitude follows the batch size and any loss scaling -- those keep the bf16 split.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-static constexpr float kH2ScaleW = 256.f;        // weights: |w| < 255
+static constexpr float kH2ScaleW = 256.f;        // weights without a measured range (never used by the launchers below)
 static constexpr float kH2ScaleX = 16384.f;      // z = tanh * sigmoid in [-1, 1] (the only operand with a static range): 2^14,
                                                  // so that values down to ~1e-8 keep their two parts (with 2^4 a residual
                                                  // stream 4,096 times smaller than usual lost them: 1e-3 relative in the skip sum)
@@ -66,8 +66,11 @@ __device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
 // mode 0: chunk c = (source, 32-wide k slice), m-tile t = rows 32t.. of that source's W[m][k]
 // mode 2: m-tile t = problem t (32 rows), chunk c = k slice of W[t]
 // one != 0 (one-term products): only the h parts are stored, 2 KB per tile instead of 6
+// WMAX: only the largest |w| of the launch's weight tiles, into *a.wmax_dev (atomicMax of the bits: a positive float orders
+// like an unsigned) -- the fp16 split scales the weights by the power of two that brings that maximum just below 2^14
+template <bool WMAX>
 __global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __bf16* __restrict__ img, int one) {
-    // one: 1 = h parts only (one-term bf16), 3 = fp16 two-way split of W * kH2ScaleW, 0 = bf16 three-way split
+    // one: 1 = h parts only (one-term bf16), 3 = fp16 two-way split of W * h2_scale(max |W|), 0 = bf16 three-way split
     const int tile = blockIdx.x;
     const int c = tile / mtiles, t = tile - c * mtiles;
     const int i = threadIdx.x & 31, c4 = threadIdx.x >> 5;           // row, group of 4 consecutive k
@@ -92,6 +95,16 @@ __global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __
     float w[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) w[e] = wp[(long long)e * a.wsk];
+    if (WMAX) {
+        float mw = fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fmaxf(fabsf(w[2]), fabsf(w[3])));
+        for (int o = 32; o >= 1; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o));
+        __shared__ float red[4];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mw;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            atomicMax(const_cast<unsigned*>(a.wmax_dev), __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+        return;
+    }
     bf16x4 h, m, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -101,11 +114,12 @@ __global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __
     }
     const int ks = c4 >> 2, hh = (c4 >> 1) & 1, jo = 4 * (c4 & 1);
     if (one == 3) {
+        const float h2sw = h2_scale(a.wmax_dev, kH2ScaleW);
         f16x4 fh, fm;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             _Float16 a0, a1;
-            split2h(w[e] * kH2ScaleW, a0, a1);
+            split2h(w[e] * h2sw, a0, a1);
             fh[e] = a0; fm[e] = a1;
         }
         __bf16* d = img + (long long)tile * (kTileElems * 2 / 3) + (i + 32 * hh) * 8 + jo;
@@ -198,6 +212,7 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
     constexpr bool ONE = TM == 1;
     constexpr bool H2 = TM == 3;
     const float h2sx = H2 ? h2_scale(a.xmax_dev, kH2ScaleX) : 1.f;
+    const float h2sw = H2 ? h2_scale(a.wmax_dev, kH2ScaleW) : 1.f;
     static_assert(MT == 4 || (MT == 8 && (ONE || H2)), "8 m-tiles per workgroup: one-term or fp16-split products");
     static_assert(!H2 || MODE == 0 || MODE == 2, "the fp16 split serves the plain contractions only");
     constexpr int TB = ONE ? kTileBytes / 3 : (H2 ? kTileBytes * 2 / 3 : kTileBytes);   // bytes of one tile image
@@ -262,7 +277,7 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
                     if (t0 + mt < mtiles) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            acc[mt][r] += a.bias[src][(t0 + mt) * 32 + b3_ch(r, h)] * (H2 ? kH2ScaleW * h2sx : 1.f);
+                            acc[mt][r] += a.bias[src][(t0 + mt) * 32 + b3_ch(r, h)] * (H2 ? h2sw * h2sx : 1.f);
                     }
             }
     }
@@ -481,7 +496,7 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] *= 1.f / (kH2ScaleW * h2sx);            // exact: a power of two
+            for (int r = 0; r < 16; ++r) acc[mt][r] *= 1.f / (h2sw * h2sx);                 // exact: a power of two
     }
     __syncthreads();                                               // the image buffers become the waves' 4 KB row patches
     float* patch = reinterpret_cast<float*>(lds) + wave * 1024;
@@ -600,7 +615,16 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     const size_t bytes2 = mode == 5 ? (size_t)16 * (kTileBytes / 3) : 0;        // Wp's image behind the gate image
     __bf16* img = reinterpret_cast<__bf16*>(exec_scratch(bytes + bytes2, "the split weight image"));
     if (!img) return WN_EARG;
-    hipLaunchKernelGGL(k_split_w, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img, one ? 1 : (h2 ? 3 : 0));
+    if (h2) {
+        // the weights' own range: |w| <= 2^7 was an assumption (a weight above ~254 saturated the fp16 parts silently); one
+        // pass of the same grid over the weight tiles measures it, per entry-point call and weight set
+        bool fresh = false;
+        unsigned* wm = exec_word(a.W[0], &fresh, s);
+        if (!wm) return WN_EARG;
+        a.wmax_dev = wm;
+        if (fresh) hipLaunchKernelGGL(k_split_w<true>, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img, 3);
+    }
+    hipLaunchKernelGGL(k_split_w<false>, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img, one ? 1 : (h2 ? 3 : 0));
     if (mode == 5) {
         if (!a.proj_W || !a.residual || !a.gate_z || a.act != WN_ACT_NONE || mtiles != 8) {
             wn::set_error("colgemm_b3: fused-layer mode needs Wp, the residual input, z and 128 gate channels");
@@ -609,7 +633,7 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
         CGArgs b{};
         b.nsrc = 1; b.W[0] = a.proj_W; b.wsm[0] = 128; b.wsk = 1; b.K[0] = 128; b.M = 128;
         __bf16* img2 = reinterpret_cast<__bf16*>(reinterpret_cast<char*>(img) + bytes);
-        hipLaunchKernelGGL(k_split_w, dim3(16), dim3(256), 0, s, b, 0, 4, 4, img2, 1);
+        hipLaunchKernelGGL(k_split_w<false>, dim3(16), dim3(256), 0, s, b, 0, 4, 4, img2, 1);
         hipLaunchKernelGGL((k_colgemm_b3<5, WN_ACT_NONE, 1, 8>), dim3(cdiv(a.N, 128)), dim3(256), 0, s, a,
                            (const __bf16*)img, mtiles, nchunks, cps, (const __bf16*)img2);
         WN_LAUNCH_CHECK();

@@ -484,6 +484,222 @@ __global__ __launch_bounds__(256, 4) void k_layer_fwd_h2_t1(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// A GROUP of consecutive small-dilation layers in one launch (fp16 x 2 form).  With per-layer launches every layer reads
+// its input back from HBM (128 of the 512 bytes a column costs in training form) and pays a launch's ramp: every wave
+// of the grid loads, computes and stores at the same time, so loads and stores never overlap.  Layers whose dilations add
+// up to at most 32 (d = 1, 2, 4, 8, 16 of every block) can be chained inside a workgroup instead: a workgroup owns 8
+// consecutive tiles plus the tile to their left (the halo, recomputed: 12.5 % more arithmetic, no extra HBM reads beyond
+// the first layer's), one tile per wave, 9 waves.  (Eight main tiles, not seven: config 2's 4,096 tiles are then 512
+// workgroups = exactly the two per CU that fit -- with seven, 592 workgroups ran as one full round plus a round of 80,
+// and the launch took as long as the five it replaced.)  Per layer a wave
+//   1. puts its tile of the layer's input (registers: the previous layer's output, or the group's input from memory)
+//      into the workgroup's slab in LDS (time-major rows, 16-byte chunk c of row r at position c ^ (r & 7)),
+//   2. after a barrier takes x[t - d] from the slab (its own rows and the left neighbour's), second barrier,
+//   3. runs the layer exactly as k_layer_fwd_h2_t1 does (same MFMAs, same scales, same stores of z / sigmoid / out) and
+//      keeps out in registers as the next layer's x[t].
+// The halo tile's results are wrong to the left of column t0 - 32 + (sum of the dilations so far) and are read only to
+// the right of it; it stores nothing.  The layer's weight image comes from the stack's packed images by LDS-DMA, one
+// layer ahead, into the other of two buffers (counted waits: the pieces are issued BEFORE the layer's stores).
+// LDS: slab 36 KB + 2 x 20 KB of images = 76 KB, two workgroups per CU (18 waves: at most 96 registers each).
+// ---------------------------------------------------------------------------------------------
+static constexpr int kGrpTiles = 8;                      // main tiles per workgroup (+ 1 halo tile)
+static constexpr int kGrpWaves = kGrpTiles + 1;
+static constexpr int kGrpMaxLayers = 8;
+struct GrpArgs {
+    const float* x;                                       // input of the group's first layer
+    float* out[kGrpMaxLayers]; float* z[kGrpMaxLayers]; float* f[kGrpMaxLayers]; float* g[kGrpMaxLayers];
+    int d[kGrpMaxLayers], Z[kGrpMaxLayers];
+    const char* img;                                      // first layer's image; consecutive layers kH2ImgStride apart
+    int nl, B, T, tiles_per_b, wgs_per_b;
+};
+
+template <int SAVE>
+__global__ __launch_bounds__(64 * kGrpWaves, 5) void k_layer_fwd_h2_grp(GrpArgs a) {
+    __shared__ __attribute__((aligned(16))) char imgs[2][kH2ImgBytes];
+    __shared__ __attribute__((aligned(16))) float slab[kGrpWaves * 1024];
+    const int lane = threadIdx.x & 63;
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // XCD k = blockIdx % 8 gets the k-th contiguous eighth of the workgroups (neighbouring slabs share an L2)
+    int wg = blockIdx.x;
+    if ((gridDim.x & 7) == 0) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int b = wg / a.wgs_per_b;
+    const int ti = (wg - b * a.wgs_per_b) * kGrpTiles - 1 + wv;          // this wave's tile of clip b (-1: left of the clip)
+    const int T = a.T;
+    const int t = ti * 32 + j;
+    const bool tile_ok = ti >= 0 && ti < a.tiles_per_b;                  // wave-uniform: the tile exists
+    const bool valid = tile_ok && t < T;
+    const bool writer = wv > 0 && tile_ok;                               // the halo tile stores nothing
+    const int tc = t < 0 ? 0 : (t < T ? t : T - 1);
+    const long long row = ((long long)b * T + tc) * 32 + 4 * h;
+
+    // weight image of the first layer (all waves: 20 pieces of 1 KB), and this tile of the group's input
+    auto dma_image = [&](int l, int buf) {
+        const char* src = a.img + (size_t)l * kH2ImgStride + lane * 16;
+        for (int piece = wv; piece < kH2ImgBytes / 1024; piece += kGrpWaves)
+            lds_dma16(src + piece * 1024, imgs[buf] + piece * 1024);
+    };
+    dma_image(0, 0);
+    float xc[16];
+    {
+        const float mc = valid ? 1.f : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(a.x + row + 8 * q);
+            xc[4 * q + 0] = v.x * mc; xc[4 * q + 1] = v.y * mc; xc[4 * q + 2] = v.z * mc; xc[4 * q + 3] = v.w * mc;
+        }
+    }
+    float* const my_rows = slab + wv * 1024 + j * 32;
+    for (int l = 0; l < a.nl; ++l) {
+        const int d = a.d[l];
+        // 1. this tile of the layer's input -> slab
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(my_rows + (((2 * q + h) ^ (j & 7)) << 2)) =
+                make_float4(xc[4 * q], xc[4 * q + 1], xc[4 * q + 2], xc[4 * q + 3]);
+        // the image of this layer (requested a layer ago, before that layer's stores: everything but the youngest
+        // `nstores` operations has retired) and the slab rows are published by the barrier
+        if (l == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (writer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (2 + (SAVE >= 1 ? 1 : 0) + (SAVE == 1 ? 1 : 0))) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // 2. x[t - d]: slab row (32 wv + j - d); rows left of the slab (halo tile only) and columns before the clip are 0
+        float xo[16];
+        {
+            const int r = wv * 32 + j - d;
+            const bool in = r >= 0 && t - d >= 0 && valid;
+            const int rr = r < 0 ? 0 : r;
+            const float* src = slab + rr * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 o = *reinterpret_cast<const float4*>(src + (((2 * q + h) ^ (rr & 7)) << 2));
+                xo[4 * q + 0] = in ? o.x : 0.f; xo[4 * q + 1] = in ? o.y : 0.f;
+                xo[4 * q + 2] = in ? o.z : 0.f; xo[4 * q + 3] = in ? o.w : 0.f;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                                 // every wave has its x[t - d]: the slab may be rewritten
+        // the next layer's image goes out now, ahead of this layer's stores
+        if (l + 1 < a.nl) dma_image(l + 1, (l + 1) & 1);
+        // 3. the layer (k_layer_fwd_h2_t1's arithmetic)
+        const char* img = imgs[l & 1];
+        const float w_inv = *reinterpret_cast<const float*>(a.img + (size_t)l * kH2ImgStride + kH2ImgBytes);
+        float mx = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) mx = fmaxf(mx, fmaxf(fabsf(xc[s]), fabsf(xo[s])));
+        mx = lb_wave_max(mx);
+        float sx, ix;
+        lb_pow2_scale(mx, sx, ix);
+        H2Op oc, oo;
+        lb_split16(xc, sx, oc);
+        lb_split16(xo, sx, oo);
+        f32x16 aa, ag;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { aa[r] = 0.f; ag[r] = 0.f; }
+        const char* ib = img + lane * 16;
+        auto frag = [&](int mt, int ks, int part) {
+            return *reinterpret_cast<const h16x8*>(ib + ((mt * 2 + ks) * 2 + part) * 1024);
+        };
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int tap = 0; tap < 2; ++tap) {
+                const H2Op& ob = tap == 0 ? oo : oc;                     // tap 0 multiplies x[t - d]
+                const h16x8 fh = frag(tap, ks, 0), fm = frag(tap, ks, 1);
+                const h16x8 gh = frag(2 + tap, ks, 0), gm = frag(2 + tap, ks, 1);
+                aa = __builtin_amdgcn_mfma_f32_32x32x16_f16(fm, ob.h[ks], aa, 0, 0, 0);
+                ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(gm, ob.h[ks], ag, 0, 0, 0);
+                aa = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, ob.m[ks], aa, 0, 0, 0);
+                ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, ob.m[ks], ag, 0, 0, 0);
+                aa = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, ob.h[ks], aa, 0, 0, 0);
+                ag = __builtin_amdgcn_mfma_f32_32x32x16_f16(gh, ob.h[ks], ag, 0, 0, 0);
+            }
+        }
+        const float uc = ix * w_inv;
+        const bool live = t >= a.Z[l];
+        const bool st = writer && valid;
+        float zz[16];
+        float* const zout = a.z[l];
+        float* const gout = a.g[l];
+        float* const fout = a.f[l];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float f4[4], g4[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int r = 4 * q + m;
+                f4[m] = fast_tanh(live ? aa[r] * uc : 0.f);
+                g4[m] = fast_sigmoid(live ? ag[r] * uc : 0.f);
+                zz[r] = f4[m] * g4[m];
+            }
+            if (writer) {                                                // (wave-uniform; the lanes beyond T are masked)
+                if (st) {
+                    if (SAVE == 1) *reinterpret_cast<float4*>(fout + row + 8 * q) = make_float4(f4[0], f4[1], f4[2], f4[3]);
+                    if (SAVE >= 1) *reinterpret_cast<float4*>(gout + row + 8 * q) = make_float4(g4[0], g4[1], g4[2], g4[3]);
+                    *reinterpret_cast<float4*>(zout + row + 8 * q) = make_float4(zz[4 * q], zz[4 * q + 1], zz[4 * q + 2], zz[4 * q + 3]);
+                }
+            }
+        }
+        H2Op oz;
+        lb_split16(zz, 16384.f, oz);
+        f32x16 ao;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ao[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const h16x8 ph = frag(4, ks, 0), pm = frag(4, ks, 1);
+            ao = __builtin_amdgcn_mfma_f32_32x32x16_f16(pm, oz.h[ks], ao, 0, 0, 0);
+            ao = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, oz.m[ks], ao, 0, 0, 0);
+            ao = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, oz.h[ks], ao, 0, 0, 0);
+        }
+        const float up = w_inv * (1.f / 16384.f);
+        const float mv = valid ? 1.f : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xc[r] = fmaf(ao[r], up, xc[r]) * mv;     // the layer's output = the next layer's x[t]
+        if (writer) {
+            float* const oout = a.out[l];
+            if (st) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(oout + row + 8 * q) = make_float4(xc[4 * q], xc[4 * q + 1], xc[4 * q + 2], xc[4 * q + 3]);
+            }
+        }
+    }
+}
+
+// how many of the layers l0, l0 + 1, ... (dilations dil[]) one group launch can take: their dilations add up to <= 32
+int mfma_layer_fwd_group_len(const int* dil, int l0, int L) {
+    int n = 0, sum = 0;
+    while (l0 + n < L && n < kGrpMaxLayers && sum + dil[l0 + n] <= 32) { sum += dil[l0 + n]; ++n; }
+    return n;
+}
+// layers l0 .. l0 + nl - 1 of a packed stack in one launch (see k_layer_fwd_h2_grp); outs / zs / fs / gs are per layer
+int mfma_layer_fwd_h2_group(const float* x, const void* img, int l0, int nl, float* const* outs, float* const* zs,
+                            float* const* fs, float* const* gs, const int* dil, const int* Zs, int B, int T,
+                            hipStream_t s) {
+    WN_CHECK_ARG(nl >= 1 && nl <= kGrpMaxLayers, "mfma_layer_fwd_h2_group: 1..%d layers", kGrpMaxLayers);
+    GrpArgs a{};
+    a.x = x;
+    a.img = reinterpret_cast<const char*>(img) + (size_t)l0 * kH2ImgStride;
+    a.nl = nl; a.B = B; a.T = T;
+    a.tiles_per_b = (T + 31) / 32;
+    a.wgs_per_b = (a.tiles_per_b + kGrpTiles - 1) / kGrpTiles;
+    for (int l = 0; l < nl; ++l) {
+        a.out[l] = outs[l]; a.z[l] = zs[l]; a.f[l] = fs ? fs[l] : nullptr; a.g[l] = gs ? gs[l] : nullptr;
+        a.d[l] = dil[l]; a.Z[l] = Zs[l];
+    }
+    const long long blocks = (long long)B * a.wgs_per_b;
+    WN_CHECK_SHAPE(blocks < (1ll << 31), "mfma_layer_fwd_h2_group: too many workgroups");
+    const dim3 grid((unsigned)blocks), block(64 * kGrpWaves);
+    if (fs && fs[0]) hipLaunchKernelGGL(k_layer_fwd_h2_grp<1>, grid, block, 0, s, a);
+    else if (gs && gs[0]) hipLaunchKernelGGL(k_layer_fwd_h2_grp<2>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(k_layer_fwd_h2_grp<0>, grid, block, 0, s, a);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
 size_t mfma_layer_h2_image_bytes(int L) { return (size_t)L * kH2ImgStride; }
 
 // images of L layers (Cr = Cd = 32, fw = 2) into img: one launch

@@ -114,6 +114,33 @@ int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, floa
         for (int l = 0; l < L; ++l) {
             float* out = xs + (size_t)l * n * d->Cr;
             int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
+            // consecutive layers whose dilations add up to <= 32 (d = 1 .. 16 of every block): ONE launch, the inner layers'
+            // inputs never leave the chip (k_layer_fwd_h2_grp)
+            int ng = (h2img && !exec_flag(WN_EXEC_NO_FWD_GROUPS) && mfma_layer_fwd_h2_ok(B, T, 0))
+                         ? mfma_layer_fwd_group_len(d->dilation, l, L) : 0;
+            for (int k = 0; k < ng; ++k)
+                if (live[l + k] > 0) ng = 0;
+            if (ng >= 2) {
+                float* outs[8]; float* zs[8]; float* fsv[8]; float* gsv[8]; int Zs[8];
+                size_t zo = zoff;
+                for (int k = 0; k < ng; ++k) {
+                    outs[k] = xs + (size_t)(l + k) * n * d->Cr;
+                    zs[k] = z + zo; fsv[k] = f ? f + zo : nullptr; gsv[k] = g ? g + zo : nullptr;
+                    Zs[k] = compat_zero_prefix ? zero_prefix(T, d->dilation[l + k], d->fw) : 0;
+                    zp[l + k] = z + zo;
+                    zo += n * d->cd[l + k];
+                }
+                {
+                    wn::ProfScope prof__("wn_layer_fwd", stream);
+                    rc = mfma_layer_fwd_h2_group(in, h2img, l, ng, outs, zs, f ? fsv : nullptr, g ? gsv : nullptr,
+                                                 d->dilation + l, Zs, B, T, as_stream(stream));
+                }
+                if (rc) return rc;
+                zoff = zo;
+                in = outs[ng - 1];
+                l += ng - 1;
+                continue;
+            }
             if (h2img && mfma_layer_fwd_h2_ok(B, T, live[l])) {
                 wn::ProfScope prof__("wn_layer_fwd", stream);
                 rc = mfma_layer_fwd_h2(in, h2img, l, out, z + zoff, f ? f + zoff : nullptr, g ? g + zoff : nullptr, B, T,

@@ -54,6 +54,10 @@ bool exec_has_scratch(size_t bytes);                    // whether the current c
 // call, shared by the launchers below it (the word lives in the last 256 bytes of the caller's scratch); NULL + error text
 // when there is no scratch.  Used by the fp16 split (WN_GEMM_FP16X2) to scale operands whose range is not known in advance.
 const unsigned* exec_absmax(const float* x, long long n, hipStream_t s);
+// a zeroed word of the same kind for a maximum the caller accumulates itself (atomicMax over several arrays); *fresh says
+// whether the word is new in this entry-point call (then it has been zeroed on the stream and must be filled) or was
+// handed out for the same key before
+unsigned* exec_word(const void* key, bool* fresh, hipStream_t s);
 int generic_absmax(const float* x, long long n, unsigned* slot, hipStream_t s);
 int generic_scale_by_dev(float* x, const float* sdev, long long n, hipStream_t s);
 int generic_rule(int rule, float* p, const float* g, float* s1, float* s2, long long n, float lr, float hy, float eps,
@@ -70,6 +74,9 @@ int mfma_layer_pack_h2(int L, const float* const* Wf, const float* const* Wg, co
 bool mfma_layer_fwd_h2_ok(int B, int T, int t_live);
 int mfma_layer_fwd_h2(const float* x, const void* img, int l, float* out, float* z, float* fs, float* gs, int B, int T,
                       int d, int Z, int t_live, hipStream_t s);
+int mfma_layer_fwd_group_len(const int* dil, int l0, int L);   // layers from l0 on that one group launch can chain
+int mfma_layer_fwd_h2_group(const float* x, const void* img, int l0, int nl, float* const* outs, float* const* zs,
+                            float* const* fs, float* const* gs, const int* dil, const int* Zs, int B, int T, hipStream_t s);
 int mfma_layer_fwd(const float* x, const float* Wf, const float* bf, const float* Wg, const float* bg,
                    const float* Wp, const float* bp, float* out, float* z, float* fs, float* gs, int B, int T,
                    int d, int Z, int t_live, hipStream_t s);

@@ -7,7 +7,8 @@ last (fw-1)*d input columns in HBM, advanced by one persistent kernel (csrc/deco
 Differences a caller can observe, both deliberate:
 * ``_forward_one_step`` returns ``(1, Q, 1, 1)`` -- the newest column -- not the full ``(1, Q, 1, W)``
   window; the reference's caller reads ``[0, :, 0, -1]`` only (train_audio/generate.py:38), which
-  indexes the same values.
+  indexes the same values.  ``keep_window = True`` + ``_forward_one_step(..., full_window=True)`` gives the
+  reference's shape and values (faster_wavenet.py:105-113) from a device-side ring of the window's logits.
 * only the newest token of ``x_batch_data`` is read (the reference also reads nothing else of it:
   wavenet.py:286), and an integer token may be passed instead of the one-hot window.
 """
@@ -43,6 +44,9 @@ class FasterWaveNet(WaveNet):
         self._dec_stale = True
         self.prev_causal_outputs = None
         self.prev_residual_outputs = None
+        self.keep_window = False           # keep the logits of the whole window on the device (full_window=True needs it)
+        self._hist = None                  # (W, Q) ring of ELU-head logits, oldest column at _hist_pos
+        self._hist_pos = 0
         super().__init__(params, compat_zero_prefix=compat_zero_prefix, seed=seed, storage=storage)
 
     def __del__(self):
@@ -119,13 +123,24 @@ class FasterWaveNet(WaveNet):
             check(_lib.lib().wn_decoder_load_state(
                 dec, ptr(tokens), W, ptr_array([t.contiguous() for t in self._last_causal_outputs]),
                 ptr_array(self._last_layer_inputs), stream_ptr()), "wn_decoder_load_state")
+            self._hist = None
+            if self.keep_window:
+                # the reference's next step re-evaluates EVERY cached column with the fast path's ELU head
+                # (faster_wavenet.py:100-112): the window's logits under that head, once, from the skip sum just computed
+                lg = self.forward_softmax_block(sum_skip, apply_softmax=False, activation=self.fast_head_activation)
+                self._hist = lg[0, :, 0, :].t().contiguous()                     # (W, Q), column 0 = oldest
+                self._hist_pos = 0
         self.prev_causal_outputs = _RingState("causal")
         self.prev_residual_outputs = _RingState("residual")
         return self.to_numpy(out) if as_numpy else out
 
-    def _forward_one_step(self, x_batch_data, apply_softmax=True, as_numpy=False):
+    def _forward_one_step(self, x_batch_data, apply_softmax=True, as_numpy=False, full_window=False):
         """One incremental step (faster_wavenet.py:50-63); falls back to the full forward when the
-        state was reset by ``prev_causal_outputs = None``."""
+        state was reset by ``prev_causal_outputs = None``.  ``full_window=True`` (needs ``keep_window = True`` set before
+        the prefill) returns the reference's ``(1, Q, 1, W)``: every column of the rolled window under the ELU head, the
+        newest last -- a compatibility face (one concatenation + one softmax over W rows per call), not the fast path."""
+        if full_window and not self.keep_window:
+            raise Exception("full_window=True needs keep_window = True before the first (prefill) call")
         if getattr(self, "prev_causal_outputs", None) is None:
             return self.forward_one_step(x_batch_data, apply_softmax=apply_softmax, as_numpy=as_numpy)
         if isinstance(x_batch_data, (int, np.integer)):
@@ -137,10 +152,31 @@ class FasterWaveNet(WaveNet):
             else:
                 token = int(x[0, -1]) if x.dim() == 2 else int(x[0, :, 0, -1].argmax())
         Q = self.params.quantization_steps
+        lib = _lib.lib()
         prob = torch.empty((1, 1, Q), device=self.device, dtype=torch.float32)
-        check(_lib.lib().wn_decoder_step(self._decoder(), token, ptr(prob), 1 if apply_softmax else 0, stream_ptr()),
-              "wn_decoder_step")
-        out = _as_view(prob)
+        if self._hist is None:
+            check(lib.wn_decoder_step(self._decoder(), token, ptr(prob), 1 if apply_softmax else 0, stream_ptr()),
+                  "wn_decoder_step")
+            out = _as_view(prob)
+            return self.to_numpy(out) if as_numpy else out
+        # window history: the step leaves its logits in the ring slot of the column that drops out of the window
+        W = self._hist.shape[0]
+        slot = self._hist[self._hist_pos]
+        check(lib.wn_decoder_step(self._decoder(), token, ptr(slot), 0, stream_ptr()), "wn_decoder_step")
+        self._hist_pos = (self._hist_pos + 1) % W
+        if not full_window:
+            if apply_softmax:
+                check(lib.wn_softmax_fwd(ptr(slot), ptr(prob), 1, Q, stream_ptr()), "wn_softmax_fwd")
+            else:
+                prob.view(-1).copy_(slot)
+            out = _as_view(prob)
+            return self.to_numpy(out) if as_numpy else out
+        win = torch.cat((self._hist[self._hist_pos:], self._hist[:self._hist_pos]), dim=0)      # oldest ... newest
+        if apply_softmax:
+            res = torch.empty_like(win)
+            check(lib.wn_softmax_fwd(ptr(win), ptr(res), W, Q, stream_ptr()), "wn_softmax_fwd")
+            win = res
+        out = _as_view(win.view(1, W, Q))
         return self.to_numpy(out) if as_numpy else out
 
     # -- the whole generate loop on the device (train_audio/generate.py:9-60 with --fast) --------
