@@ -352,9 +352,12 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
 int wn16_pack_pointwise(const float* W, uint16_t* Wb, uint16_t* WbT, int Cout, int Cin, void* stream);
 int wn16_pointwise_fwd(const uint16_t* x, const uint16_t* Wb, const float* bias, void* out, int out_f32, int64_t N,
                        int Cin, int Cout, int act, void* stream);
+/* ws (ABI 3; wn16_pointwise_bwd_workspace_bytes, may be NULL): with it the weight and bias gradients are sums of
+ * per-workgroup partials added in a fixed order -- bit-reproducible; without it they accumulate through float atomics */
+size_t wn16_pointwise_bwd_workspace_bytes(int64_t N, int Cout);
 int wn16_pointwise_bwd(const uint16_t* x, const uint16_t* WbT, const uint16_t* dout, const float* dout_f32,
                        uint16_t* dout_scratch, uint16_t* dx, float* dW, float* dbias, int64_t N, int Cin, int Cout,
-                       int act, void* stream);
+                       int act, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- measurement aid (bench.py): per-entry-point HIP-event timing on the caller's stream ------- */
 int wn_prof_enable(int on);                    /* 1: clear + start recording, 0: stop               */

@@ -107,7 +107,8 @@ _SIGS = {
     "wn16_stack_bwd": (_i, [C.POINTER(WnStackDesc)] + [_p] * 7 + [_pp] * 4 + [_p, C.c_size_t, _i, _i, _i, _i, _p]),
     "wn16_pack_pointwise": (_i, [_p, _p, _p, _i, _i, _p]),
     "wn16_pointwise_fwd": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _i, _p]),
-    "wn16_pointwise_bwd": (_i, [_p] * 8 + [_i64, _i, _i, _i, _p]),
+    "wn16_pointwise_bwd_workspace_bytes": (C.c_size_t, [_i64, _i]),
+    "wn16_pointwise_bwd": (_i, [_p] * 8 + [_i64, _i, _i, _i, _p, C.c_size_t, _p]),
     "wn_prof_enable": (_i, [_i]),
     "wn_prof_report": (_i, [C.c_char_p, _i]),
 }

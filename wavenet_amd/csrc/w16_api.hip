@@ -38,7 +38,7 @@ size_t pack_elems(const WnStackDesc* d) {
     return L * kLayerImg + 2 * (size_t)d->Cs * L * 128;     // layer images, skip matrix [Cs][128 L], dz matrix [128 L][Cs]
 }
 
-struct BwdWs { bf16* dzs; bf16* dadg; bf16* dxb[2]; float* parts; size_t bytes; };
+struct BwdWs { bf16* dzs; bf16* dadg; bf16* dxb[2]; float* parts; float* wgparts; size_t bytes; };
 BwdWs carve(const WnStackDesc* d, int B, int T, int t_off, char* ws) {
     const size_t L = d->n_layers, n = (size_t)B * T, nw = (size_t)B * (T - t_off);
     BwdWs r{};
@@ -49,6 +49,7 @@ BwdWs carve(const WnStackDesc* d, int B, int T, int t_off, char* ws) {
     r.dxb[0] = reinterpret_cast<bf16*>(take(n * 128 * 2));
     r.dxb[1] = reinterpret_cast<bf16*>(take(n * 128 * 2));
     r.parts = reinterpret_cast<float*>(take(L * (size_t)dx_grid(B, T) * 128 * 128 * 4));
+    r.wgparts = reinterpret_cast<float*>(take(kWgPartBytes));        // per-workgroup blocks of the time contractions
     r.bytes = o;
     return r;
 }
@@ -177,7 +178,7 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
             wn::ProfScope prof__("wn16_skip_sum_bwd_dw", stream);
             WG16 a{};
             a.lda = Cs; a.ldb = 128; a.nB = B; a.R = Tw; a.a_rpb = Tw; a.a_r0 = 0; a.b_rpb = T; a.b_r0 = t_off;
-            a.os_m = 128; a.os_n = 1; a.relu_b = 0;
+            a.os_m = 128; a.os_n = 1; a.relu_b = 0; a.part = w.wgparts;
             int np = 0;
             for (int mb = 0; mb < Cs / 256; ++mb)
                 for (int q = 0; q < L / 2; ++q) {
@@ -229,7 +230,7 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
         wn::ProfScope prof__("wn16_conv_wgrad", stream);
         WG16 a{};
         a.lda = 256; a.ldb = 128; a.nB = B; a.R = T; a.a_rpb = T; a.a_r0 = 0; a.b_rpb = T; a.b_r0 = 0;
-        a.os_m = 256; a.os_n = 2; a.relu_b = 0;
+        a.os_m = 256; a.os_n = 2; a.relu_b = 0; a.part = w.wgparts;
         for (int l = 0; l < L; ++l) {
             WG16Prob& p = a.prob[l];
             const bf16* in = l == 0 ? xb : xsb + (size_t)(l - 1) * n * 128;
@@ -273,10 +274,16 @@ int wn16_pointwise_fwd(const uint16_t* x, const uint16_t* Wb, const float* bias,
 
 // dx = act'(x) (W^T dout) (bf16, may be NULL), dW += dout^T act(x), dbias += sum dout.  dout arrives either as bf16
 // (dout) or as fp32 (dout_f32, e.g. d loss / d logits): the latter is rounded into dout_scratch (N x Cout bf16) first.
+size_t wn16_pointwise_bwd_workspace_bytes(int64_t N, int Cout) {
+    // the weight-gradient contraction's per-workgroup blocks + the bias gradient's per-chunk column sums (2,048 chunks at most)
+    return kWgPartBytes + (size_t)2048 * (Cout > 512 ? Cout : 512) * sizeof(float) + 4096 + 256;
+}
+
 int wn16_pointwise_bwd(const uint16_t* x, const uint16_t* WbT, const uint16_t* dout, const float* dout_f32,
                        uint16_t* dout_scratch, uint16_t* dx, float* dW, float* dbias, int64_t N, int Cin, int Cout,
-                       int act, void* stream) {
+                       int act, void* ws, size_t ws_bytes, void* stream) {
     wn::ProfScope prof__("wn16_pointwise_bwd", stream);
+    WN_CHECK_ARG(!ws || ws_bytes >= wn16_pointwise_bwd_workspace_bytes(N, Cout), "wn16_pointwise_bwd: workspace too small");
     WN_CHECK_ARG(x && WbT && (dout || (dout_f32 && dout_scratch)) && N > 0, "wn16_pointwise_bwd: bad argument");
     WN_CHECK_SHAPE(Cin % 256 == 0 && Cout % 256 == 0 && Cout / 128 <= kMaxSrc16, "wn16_pointwise_bwd: channels must be multiples of 256");
     WN_CHECK_SHAPE(act == WN_ACT_NONE || act == WN_ACT_RELU, "wn16_pointwise_bwd: relu or none");
@@ -301,6 +308,7 @@ int wn16_pointwise_bwd(const uint16_t* x, const uint16_t* WbT, const uint16_t* d
         WG16 a{};
         a.lda = Cout; a.ldb = Cin; a.nB = 1; a.R = (int)N; a.a_rpb = (int)N; a.a_r0 = 0; a.b_rpb = (int)N; a.b_r0 = 0;
         a.os_m = Cin; a.os_n = 1; a.relu_b = act == WN_ACT_RELU ? 1 : 0;
+        a.part = reinterpret_cast<float*>(ws);              // NULL: float atomics (the order of the slabs is then not defined)
         int np = 0;
         for (int mb = 0; mb < Cout / 256; ++mb)
             for (int nb = 0; nb < Cin / 256; ++nb) {
@@ -316,6 +324,10 @@ int wn16_pointwise_bwd(const uint16_t* x, const uint16_t* WbT, const uint16_t* d
     }
     if (dbias) {
         if (!dout_f32) { wn::set_error("wn16_pointwise_bwd: the bias gradient is summed from the fp32 gradient"); return WN_EARG; }
+        // with a workspace the column sums leave per-chunk partials that one kernel adds in a fixed order (no atomics)
+        WnExec ex{WN_GEMM_BF16, 0u, ws ? reinterpret_cast<char*>(ws) + kWgPartBytes : nullptr,
+                  ws ? ws_bytes - kWgPartBytes : (size_t)0, 0, 0};
+        wn::ExecScope scope__(ws ? &ex : nullptr);
         if ((rc = wn::generic_colsum(dout_f32, 1, (int)N, 0, Cout, Cout, dbias, s))) return rc;
     }
     return WN_OK;

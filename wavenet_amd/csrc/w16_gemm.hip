@@ -494,6 +494,17 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         mm(1);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (a.part) {
+        // this workgroup's block as it sits in the accumulators: [wave][mi][ni][r][lane], 256-byte rows, coalesced
+        float* pp = a.part + ((size_t)blockIdx.x * gridDim.y + p) * 65536 + (size_t)w * 8192 + lane;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pp[((mi * 4 + ni) * 16 + r) * 64] = acc[mi][ni][r];
+        return;
+    }
     float* ob = pr.out[wm >> 1][wn];
     if (!ob) return;
 #pragma unroll
@@ -506,6 +517,27 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 const int n = 32 * ni + j;
                 atomicAdd(ob + (long long)m * a.os_m + (long long)n * a.os_n, acc[mi][ni][r]);
             }
+}
+
+// dW += the slabs' blocks of a problem, slab 0 first: one thread per element of the 256 x 256 block, no atomics.  A slab
+// whose chunk range is empty has left its block unwritten: the ranges are recomputed here.
+__global__ void k16_wgrad_reduce(WG16 a, int slabs) {
+    const int p = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;            // [wave][mi][ni][r][lane]
+    const int lane = e & 63, r = (e >> 6) & 15, ni = (e >> 10) & 3, mi = (e >> 12) & 1, w = e >> 13;
+    const int wm = w & 3, wn = w >> 2, j = lane & 31, h = lane >> 5;
+    float* ob = a.prob[p].out[wm >> 1][wn];
+    if (!ob) return;
+    const int cpb = (a.R + kWT - 1) / kWT;
+    const int nch = a.nB * cpb;
+    float sum = 0.f;
+    for (int sl = 0; sl < slabs; ++sl) {
+        const int c_begin = (int)((long long)nch * sl / slabs), c_end = (int)((long long)nch * (sl + 1) / slabs);
+        if (c_begin < c_end) sum += a.part[((size_t)sl * gridDim.y + p) * 65536 + e];
+    }
+    const int m = 64 * (wm & 1) + 32 * mi + acc_row(r, h);
+    const int n = 32 * ni + j;
+    ob[(long long)m * a.os_m + (long long)n * a.os_n] += sum;
 }
 
 int launch_wgrad16(const WG16& a, int nprob, hipStream_t s) {
@@ -528,6 +560,10 @@ int launch_wgrad16(const WG16& a, int nprob, hipStream_t s) {
     if (a.relu_b) WGL(true); else WGL(false);
 #undef WGL
     WN_LAUNCH_CHECK();
+    if (a.part) {
+        hipLaunchKernelGGL(k16_wgrad_reduce, dim3(256, nprob), dim3(256), 0, s, a, slabs);
+        WN_LAUNCH_CHECK();
+    }
     return WN_OK;
 }
 

@@ -42,7 +42,11 @@ struct WG16 {
     int nB, R, a_rpb, a_r0, b_rpb, b_r0;
     int os_m, os_n;
     int relu_b;
+    float* part;                     // kWgPartBytes of scratch: every workgroup leaves its 256 x 256 block there and a second
+                                     // kernel adds the slabs of a problem in a fixed order (bit-reproducible); NULL: each
+                                     // workgroup adds its block to dW with float atomics (order of the slabs not defined)
 };
+static constexpr size_t kWgPartBytes = (size_t)256 * 256 * 256 * sizeof(float);   // at most 256 workgroups per launch
 int launch_wgrad16(const WG16& a, int nprob, hipStream_t s);
 
 int pack_layers(int L, const float* const* Wf, const float* const* Wg, const float* const* Wp, bf16* img, hipStream_t s);

@@ -409,8 +409,10 @@ class _Pointwise16Fn(_Fn):
                 d32 = torch.empty((N, Cout), device=d2.device, dtype=torch.float32)
                 check(lib.wn16_cvt_to_f32(ptr(d16), ptr(d32), d16.numel(), stream_ptr()), "wn16_cvt_to_f32")
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        nws = lib.wn16_pointwise_bwd_workspace_bytes(N, Cout)      # per-workgroup partials: gradients without float atomics
+        ws = torch.empty((nws,), device=d2.device, dtype=torch.uint8)
         check(lib.wn16_pointwise_bwd(ptr(x2), ptr(ctx.WbT), ptr(d16), ptr(d32), ptr(scratch), ptr(dx), ptr(W.grad),
-                                     ptr(None if b is None else b.grad), N, Cin, Cout, ctx.act, stream_ptr()),
+                                     ptr(None if b is None else b.grad), N, Cin, Cout, ctx.act, ptr(ws), nws, stream_ptr()),
               "wn16_pointwise_bwd")
         return (None if dx is None else dx.view(*ctx.lead, Cin)), None, None, None, None, None, None, None
 
