@@ -373,7 +373,8 @@ def main():
         # collected from inside the bench); `traffic_source` says which file, and the file says which commit it measured
         import glob
         import re
-        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_hbm_traffic.json")),
+        tfiles = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json"))
+                         if re.match(r"r\d+_hbm_traffic\.json$", os.path.basename(f))),
                         key=lambda f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)))
         tfile = tfiles[-1] if tfiles else None
         tdoc = json.load(open(tfile)) if tfile else {}
