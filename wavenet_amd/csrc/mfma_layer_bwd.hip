@@ -853,37 +853,26 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
         }
     }
 #endif
-    // ---- sum the five accumulators over the waves (tree through the slot groups) -----
-    __syncthreads();
-    for (int half = NW / 2; half >= 1; half >>= 1) {
-        if (wv >= half && wv < 2 * half) {
-            float* red = wbase + (wv - half) * kPartFloats;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                red[(0 * 16 + r) * 64 + lane] = aWf0[r]; red[(1 * 16 + r) * 64 + lane] = aWf1[r];
-                red[(2 * 16 + r) * 64 + lane] = aWg0[r]; red[(3 * 16 + r) * 64 + lane] = aWg1[r];
-                red[(4 * 16 + r) * 64 + lane] = aWp[r];
-            }
-        }
-        __syncthreads();
-        if (wv < half) {
-            const float* red = wbase + wv * kPartFloats;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                aWf0[r] += red[(0 * 16 + r) * 64 + lane]; aWf1[r] += red[(1 * 16 + r) * 64 + lane];
-                aWg0[r] += red[(2 * 16 + r) * 64 + lane]; aWg1[r] += red[(3 * 16 + r) * 64 + lane];
-                aWp[r] += red[(4 * 16 + r) * 64 + lane];
-            }
-        }
-        __syncthreads();
-    }
-    if (wv == 0) {
-        float* __restrict__ o = part + (long long)blockIdx.x * kPartFloats + lane;
+    // ---- the four waves' accumulators -> LDS (the slot groups are dead), ONE barrier, then every thread adds them in a fixed
+    // order for its 20 elements and writes the workgroup's partial tile with coalesced stores.  (The two-level tree it
+    // replaces cost four barriers and left the 80 stores of the tile to one wave.)
+    __syncthreads();                                   // every wave is done with its slot groups
+    {
+        float* red = wbase + wv * kPartFloats;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            o[(0 * 16 + r) * 64] = aWf0[r]; o[(1 * 16 + r) * 64] = aWf1[r];
-            o[(2 * 16 + r) * 64] = aWg0[r]; o[(3 * 16 + r) * 64] = aWg1[r];
-            o[(4 * 16 + r) * 64] = aWp[r];
+            red[(0 * 16 + r) * 64 + lane] = aWf0[r]; red[(1 * 16 + r) * 64 + lane] = aWf1[r];
+            red[(2 * 16 + r) * 64 + lane] = aWg0[r]; red[(3 * 16 + r) * 64 + lane] = aWg1[r];
+            red[(4 * 16 + r) * 64 + lane] = aWp[r];
+        }
+    }
+    __syncthreads();
+    {
+        float* __restrict__ o = part + (long long)blockIdx.x * kPartFloats;
+#pragma unroll
+        for (int i = 0; i < kPartFloats / (64 * NW); ++i) {
+            const int e = threadIdx.x + i * 64 * NW;
+            o[e] = (wbase[e] + wbase[kPartFloats + e]) + (wbase[2 * kPartFloats + e] + wbase[3 * kPartFloats + e]);
         }
     }
 }
