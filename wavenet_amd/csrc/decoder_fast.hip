@@ -199,8 +199,20 @@ __device__ __forceinline__ void old_layer(const FastLds& S, const OldW& w, int l
 }
 // The chain wave: one residual layer of one step.  xc = x_l[n] (channel lane % 32, valid in every lane); a_old = the
 // x[n-d] half of this lane's gate row (from wave 1).  Returns x_{l+1}[n]; a_old is replaced by the next layer's.
+// The next layer's a_old is requested at the TOP of this layer together with wave 1's counter (counter read first, data read
+// second: the LDS pipeline serves them in that order, so a counter value >= l + 2 proves the data read saw wave 1's
+// write) and looked at only at the bottom: two LDS round trips (the spin's read, then the data's) left the 40-layer
+// critical path.  Wave 1 is normally many layers ahead; when it is not, the bounded spin and a second read follow.
 __device__ __forceinline__ float chain_layer(const FastLds& S, const ChainW& w, float& a_old, int l, int nlayers, int lane,
                                              float xc) {
+    int c_next = 0;
+    float a_next = 0.f;
+    const bool more = l + 1 < nlayers;
+    if (more) {
+        c_next = __hip_atomic_load(S.ready_old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        a_next = S.aold[(l + 1) * 64 + lane];
+    }
     // gate row `lane`: 32 scalar broadcasts of x[n], all read before the first use (a v_readlane result needs wait
     // states before a VALU may consume it: batched, the FMAs need no s_nop); packed FMAs (v_pk_fma_f32: two MACs per
     // instruction, the scalar pair as an SGPR operand), two accumulator pairs
@@ -220,7 +232,7 @@ __device__ __forceinline__ float chain_layer(const FastLds& S, const ChainW& w, 
     const float act = lo ? 1.0f - 2.0f * r : r;
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(act), __float_as_uint(act), false, false);
     const float z = __uint_as_float(sw[0]) * __uint_as_float(sw[1]);          // z[lane % 32] in every lane
-    if (lo) S.zall[l * 32 + lane] = z;
+    S.zall[l * 32 + (lane & 31)] = z;                  // both half waves hold the same value: no exec-mask branch
     // residual projection row lane % 32
     float sz[32];
 #pragma unroll
@@ -232,14 +244,17 @@ __device__ __forceinline__ float chain_layer(const FastLds& S, const ChainW& w, 
         P1 = __builtin_elementwise_fma(f2{sz[4 * j + 2], sz[4 * j + 3]}, f2{w.p[j].z, w.p[j].w}, P1);
     }
     const float xn = ((P0.x + P0.y) + (P1.x + P1.y)) + xc;
-    if (lo) S.xcur[(l + 1) * 32 + lane] = xn;
+    S.xcur[(l + 1) * 32 + (lane & 31)] = xn;
     // publish: LDS operations of a wave retire in order, so the counter store only has to FOLLOW the z store in the
     // instruction stream (a compiler-level fence; no s_waitcnt on the chain's critical path)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (lane == 0) __hip_atomic_store(S.ready, l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (l + 1 < nlayers) {                             // wave 1 is normally many layers ahead
-        wait_count(S.ready_old, l + 2);
-        a_old = S.aold[(l + 1) * 64 + lane];
+    if (more) {
+        if (__builtin_amdgcn_readfirstlane(c_next) < l + 2) {       // rare: wave 1 has not been here yet
+            wait_count(S.ready_old, l + 2);
+            a_next = S.aold[(l + 1) * 64 + lane];
+        }
+        a_old = a_next;
     }
     return xn;
 }
@@ -326,6 +341,11 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
                 for (int u = 0; u < kUnroll; ++u) {
                     const int l = l0 + u;
                     if (l < nlayers) {
+                        // Layer l's weights were requested a whole layer ago.  Waiting for them HERE, in front of the next
+                        // request, costs nothing and leaves hipcc's counter bookkeeping exact: without it the first use of
+                        // w[u & 1] carried `s_waitcnt vmcnt(15)` behind the 16 fresh loads, i.e. it also waited for the
+                        // first load of layer l + 1 -- one exposed L2 round trip per layer on the chain.
+                        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
                         if (l + 1 < nlayers) load_chain(w[(u + 1) & 1], P, l + 1, 4u * lane);   // in flight during layer l
                         xc = chain_layer(S, w[u & 1], a_old, l, nlayers, lane, xc);
                     }
@@ -340,6 +360,7 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
                 for (int u = 0; u < kUnroll; ++u) {
                     const int l = l0 + u;
                     if (l < nlayers) {
+                        __builtin_amdgcn_s_waitcnt(0x0F70);          // as in the chain wave: exact counters
                         if (l + 1 < nlayers) load_old(wo[(u + 1) & 1], P, l + 1, 4u * lane);
                         old_layer(S, wo[u & 1], l, lane);
                     }
@@ -356,6 +377,7 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
                     const int l = l0 + u;
                     if (l < nlayers && l > 0) {
                         // behind the chain: fetch layer l's rows, use layer l-1's (loaded a trip ago) once its z is there
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
                         load_skip(w[u & 1], P, l, t4);
                         wait_layer(S, l);
                         skip_layer(S, w[(u + 1) & 1], l - 1, skip0, skip1);

@@ -180,8 +180,8 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
             a.lda = Cs; a.ldb = 128; a.nB = B; a.R = Tw; a.a_rpb = Tw; a.a_r0 = 0; a.b_rpb = T; a.b_r0 = t_off;
             a.os_m = 128; a.os_n = 1; a.relu_b = 0; a.part = w.wgparts;
             int np = 0;
-            for (int mb = 0; mb < Cs / 256; ++mb)
-                for (int q = 0; q < L / 2; ++q) {
+            for (int q = 0; q < L / 2; ++q)                   // the problems that share a layer pair's z are neighbours
+                for (int mb = 0; mb < Cs / 256; ++mb) {
                     WG16Prob& p = a.prob[np++];
                     p.A = dsk + 256 * mb;
                     for (int nh = 0; nh < 2; ++nh) {

@@ -230,9 +230,19 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     {
         const int id = blockIdx.x;
         if ((a.n_blocks & 7) == 0) {
+            // An XCD (linear ids = xcd mod 8, dispatched in id order) takes its column blocks in panels of 8 and, inside a
+            // panel, the channel blocks one after the other: the ~64 workgroups in flight on its 32 CUs are then 8 channel
+            // blocks x the panel's 8 column blocks, so a W slice is fetched once per panel and the panel's X tiles (2 MB) stay
+            // in that XCD's L2 until all channel blocks have passed.  (With the channel block as the fast index the XCD cycled
+            // through ALL of W -- 5.2 MB for config 5's dz, above its 4 MB of L2 -- once per 3 column blocks: 2.1 GB fetched
+            // for a 0.1 GB X.)
             const int xcd = id & 7, slot = id >> 3;
-            mblk = slot % nmb;
-            nblk = (slot / nmb) * 8 + xcd;
+            const int nbx = a.n_blocks >> 3;
+            const int panel = slot / (8 * nmb);
+            const int pw = nbx - 8 * panel < 8 ? nbx - 8 * panel : 8;
+            const int rem = slot - panel * (8 * nmb);
+            mblk = rem / pw;
+            nblk = (8 * panel + (rem - mblk * pw)) * 8 + xcd;
         } else {
             mblk = id % nmb;
             nblk = id / nmb;
@@ -384,13 +394,27 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int wm = w & 3, wn = w >> 2;
-    const int p = blockIdx.y;
+    // (slab, problem) of this workgroup.  Linear ids go round the 8 XCDs, so XCD c is given the c-th eighth of the
+    // (slab-major, problem-minor) list: its workgroups stream the SAME rows of neighbouring problems, and operands that
+    // neighbouring problems share (dWs: the two dskip halves of a layer pair, one dskip half for all layer pairs) come from
+    // HBM once per XCD and from its L2 for the rest.  (In grid order an XCD held every slab of every fifth problem or so:
+    // 42 distinct operand slabs per XCD for 30 workgroups, 2.86 GB fetched for 1.1 GB of operands.)
+    int slab = blockIdx.x, p = blockIdx.y;
+    {
+        const int total = gridDim.x * gridDim.y;
+        if ((total & 7) == 0) {
+            const int id = blockIdx.x + gridDim.x * blockIdx.y;
+            const int item = (id & 7) * (total >> 3) + (id >> 3);
+            slab = item / (int)gridDim.y;
+            p = item - slab * (int)gridDim.y;
+        }
+    }
     const WG16Prob& pr = a.prob[p];
     // this workgroup's slab of 64-row chunks
     const int cpb = (a.R + kWT - 1) / kWT;
     const int nch = a.nB * cpb;
-    const int c_begin = (int)((long long)nch * blockIdx.x / gridDim.x);
-    const int c_end = (int)((long long)nch * (blockIdx.x + 1) / gridDim.x);
+    const int c_begin = (int)((long long)nch * slab / gridDim.x);
+    const int c_end = (int)((long long)nch * (slab + 1) / gridDim.x);
     auto tile = [&](int buf, int which) { return lds + (buf * 4 + which) * kWTileB; };   // which: A0 A1 B0 B1
 
     auto issue = [&](int c, int buf) {
@@ -496,7 +520,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     if (a.part) {
         // this workgroup's block as it sits in the accumulators: [wave][mi][ni][r][lane], 256-byte rows, coalesced
-        float* pp = a.part + ((size_t)blockIdx.x * gridDim.y + p) * 65536 + (size_t)w * 8192 + lane;
+        float* pp = a.part + ((size_t)slab * gridDim.y + p) * 65536 + (size_t)w * 8192 + lane;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
