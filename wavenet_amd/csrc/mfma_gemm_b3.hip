@@ -321,13 +321,6 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
             const float v[8] = {xr[2 * ks].x, xr[2 * ks].y, xr[2 * ks].z, xr[2 * ks].w,
                                 xr[2 * ks + 1].x, xr[2 * ks + 1].y, xr[2 * ks + 1].z, xr[2 * ks + 1].w};
             if (H2) {
-#ifdef WN_DIAG_NOSPLIT
-                typedef unsigned u4 __attribute__((ext_vector_type(4)));
-                u4 q0, q1;
-                for (int e = 0; e < 4; ++e) { q0[e] = __float_as_uint(v[e]) & 0x33ff33ffu; q1[e] = __float_as_uint(v[4 + e]) & 0x33ff33ffu; }
-                xh[ks] = __builtin_bit_cast(bf16x8, q0);
-                xm[ks] = __builtin_bit_cast(bf16x8, q1);
-#else
                 f16x8 fh, fm;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -337,7 +330,6 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
                 }
                 xh[ks] = __builtin_bit_cast(bf16x8, fh);
                 xm[ks] = __builtin_bit_cast(bf16x8, fm);
-#endif
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -349,15 +341,8 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
         }
         __syncthreads();                 // vmcnt(0): chunk c's image has landed; every wave is done with chunk c-1
         if (c + 1 < nchunks) {           // next chunk: image into the other buffer, X into registers
-#ifdef WN_DIAG_NODMA
-            if (c < 1)
-#endif
             dma_chunk(c + 1, (c + 1) & 1);
-#ifdef WN_DIAG_NOX
-            load_x(0);
-#else
             load_x(c + 1);
-#endif
         }
         const char* Ab = lds + ((c & 1) * MT) * TB + lane * 16;
         // The A fragments of m-tile mt + 1 are requested while the MFMAs of m-tile mt run.  (Left to itself hipcc sinks every
@@ -369,19 +354,12 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
         bf16x8 fr[PIPE ? 2 : 1][2][3];
         auto ldA = [&](int mt, bf16x8 (&f)[2][3]) {
 #pragma unroll
-#ifdef WN_DIAG_HALF_A
-            for (int ks = 0; ks < 1; ++ks) {
-#else
             for (int ks = 0; ks < 2; ++ks) {
-#endif
                 const char* p = Ab + mt * TB + ks * (TB / 2);
                 f[ks][0] = *reinterpret_cast<const bf16x8*>(p);
                 if (!ONE) f[ks][1] = *reinterpret_cast<const bf16x8*>(p + 1024);
                 if (!ONE && !H2) f[ks][2] = *reinterpret_cast<const bf16x8*>(p + 2048);
             }
-#ifdef WN_DIAG_HALF_A
-            f[1][0] = f[0][0]; f[1][1] = f[0][1]; f[1][2] = f[0][2];
-#endif
         };
         if (PIPE) ldA(0, fr[0]);
 #pragma unroll
@@ -965,13 +943,6 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
                     av *= ra < r_end ? 1.f : 0.f;
                     bv *= (rb < r_end && rb + off >= 0 && rb + off < a.rows_B_per_b) ? 1.f : 0.f;
                 }
-#ifdef WN_DIAG_NOSPLIT
-                if (H2) {
-                    const unsigned ua = __float_as_uint(av) & 0x33ff33ffu, ub = __float_as_uint(bv) & 0x33ff33ffu;
-                    ah[e] = __builtin_bit_cast(__bf16, (unsigned short)ua); am[e] = __builtin_bit_cast(__bf16, (unsigned short)(ua >> 16));
-                    bh[ks][e] = __builtin_bit_cast(__bf16, (unsigned short)ub); bm[ks][e] = __builtin_bit_cast(__bf16, (unsigned short)(ub >> 16));
-                } else
-#endif
                 if (H2) {                                // fp16 two-way split of the scaled operands (bit patterns travel as bf16x8)
                     _Float16 y0, y1;
                     split2h(av * h2sa, y0, y1);
