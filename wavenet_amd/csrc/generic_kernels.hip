@@ -560,40 +560,57 @@ __global__ void k_softmax(const float* __restrict__ logits, float* __restrict__ 
 }
 
 // loss[0] = (sum of the per-block sums, in block order) / n_norm: no float atomics, the loss is bit-reproducible
-static constexpr int kXentPart = 8, kXentBlocks = 2048;
-// n_norm < 0: the number of rows that count was left in loss[1] by k_xent_count (labels in [0, Q))
+static constexpr int kXentPart = 8, kXentCnt = 64, kXentBlocks = 2048 - kXentCnt;
+// n_norm < 0: the number of rows that count (labels in [0, Q)) is taken on the device: k_xent_count leaves one INTEGER per
+// workgroup in the last kXentCnt words of the loss buffer and every reader adds them (one load per lane and a wave
+// reduction; integer sums do not depend on the order).  No memset, no atomics: with one zeroed word + an integer atomic
+// per wave, the FIRST replay of a captured bf16x3 training step read a garbage count (the loss buffer is allocated from
+// the graph's pool during capture; eager calls and later replays were right).  The single block of 1,024 threads this
+// replaces took 45 us at config 2 (98,320 labels) -- 1.4 % of the training step for a count.
 __global__ void k_xent_count(const int32_t* __restrict__ target, long long N, int Q, float* __restrict__ loss) {
     __shared__ int red[16];
     int c = 0;
-    for (long long i = threadIdx.x; i < N; i += blockDim.x) c += (target[i] >= 0 && target[i] < Q) ? 1 : 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long long)gridDim.x * blockDim.x) {
+        const int t = target[i];
+        c += (t >= 0 && t < Q) ? 1 : 0;
+    }
     for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
-        int s = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
-        loss[1] = (float)(s > 0 ? s : 1);
+        int sum = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += red[w];
+        reinterpret_cast<int*>(loss + kXentPart + kXentBlocks)[blockIdx.x] = sum;
     }
 }
-__global__ void k_xent_final(float* __restrict__ loss, int nb, long long n_norm) {      // 256 threads, fixed tree
+// every lane of the calling wave gets the count (at least 1); ncnt = workgroups of k_xent_count (<= kXentCnt = 64)
+__device__ __forceinline__ float xent_count(const float* loss, int ncnt) {
+    const int lane = threadIdx.x & 63;
+    int c = lane < ncnt ? reinterpret_cast<const int*>(loss + kXentPart + kXentBlocks)[lane] : 0;
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    return (float)(c > 0 ? c : 1);
+}
+__global__ void k_xent_final(float* __restrict__ loss, int nb, long long n_norm, int ncnt) {      // 256 threads, fixed tree
     __shared__ float red[4];
+    const float nrm = n_norm < 0 ? xent_count(loss, ncnt) : (float)n_norm;
     float acc = 0.f;
     for (int i = threadIdx.x; i < nb; i += 256) acc += loss[kXentPart + i];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (n_norm < 0 ? loss[1] : (float)n_norm);
+    if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) / nrm;
 }
 
 __global__ void k_softmax_xent(const float* __restrict__ logits, const int32_t* __restrict__ target,
-                               float* __restrict__ loss, float* __restrict__ dlogits, long long N, int Q, long long n_norm) {
+                               float* __restrict__ loss, float* __restrict__ dlogits, long long N, int Q, long long n_norm,
+                               int ncnt) {
     // one wave per row; rows of up to 256 logits live in registers (one float4 per lane).  Waves stride
     // over rows so that the loss leaves with ONE atomic per block: thousands of adds to one address
     // would serialise at ~13 ns each.
     int lane = threadIdx.x & 63;
     __shared__ float part[16];
     float rl_acc = 0.f;
-    const float invN = 1.f / (n_norm < 0 ? loss[1] : (float)n_norm);
+    const float invN = 1.f / (n_norm < 0 ? xent_count(loss, ncnt) : (float)n_norm);
     for (long long row = (long long)blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64; row < N;
          row += (long long)gridDim.x * (blockDim.x / 64)) {
         float rl = 0.f;
@@ -1106,9 +1123,14 @@ int generic_softmax_xent(const float* logits, const int32_t* target, float* loss
     if (blocks > kXentBlocks) blocks = kXentBlocks;
     // n_norm > 0: that many rows count; 0: all N; < 0: counted on the device (labels in [0, Q)), one small launch
     const long long nn = n_norm > 0 ? n_norm : (n_norm == 0 ? N : -1);
-    if (nn < 0) hipLaunchKernelGGL(k_xent_count, dim3(1), dim3(1024), 0, s, target, N, Q, loss);
-    hipLaunchKernelGGL(k_softmax_xent, dim3(blocks), dim3(256), 0, s, logits, target, loss, dlogits, N, Q, nn);
-    hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(256), 0, s, loss, blocks, nn);
+    int ncnt = 0;
+    if (nn < 0) {
+        ncnt = cdiv(N, 2048);
+        ncnt = ncnt > kXentCnt ? kXentCnt : (ncnt < 1 ? 1 : ncnt);
+        hipLaunchKernelGGL(k_xent_count, dim3(ncnt), dim3(1024), 0, s, target, N, Q, loss);
+    }
+    hipLaunchKernelGGL(k_softmax_xent, dim3(blocks), dim3(256), 0, s, logits, target, loss, dlogits, N, Q, nn, ncnt);
+    hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(256), 0, s, loss, blocks, nn, ncnt);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }
