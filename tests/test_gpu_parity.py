@@ -1352,6 +1352,48 @@ def test_cross_entropy_ignores_label_minus_one_like_chainer_and_rejects_other_ba
 
 
 @pytest.mark.gpu
+def test_cross_entropy_counts_device_labels_over_many_workgroups_and_in_the_first_graph_replay():
+    """The device-side count of the rows that enter the mean (n_norm < 0) at a size that takes every partial-count word
+    (150,000 labels, a third of them ignored), eager and as the FIRST replay of a captured graph whose loss buffer comes
+    from the graph's pool (an earlier form -- one zeroed word + integer atomics -- read garbage exactly there)."""
+    from wavenet_amd import _lib
+    from wavenet_amd._lib import ptr, stream_ptr
+    N, Q = 150_000, 256
+    rs = np.random.RandomState(8)
+    logits = torch.tensor(rs.standard_normal((N, Q)).astype(np.float32), device="cuda")
+    tg = rs.randint(0, Q, N).astype(np.int32)
+    tg[rs.rand(N) < 0.33] = -1
+    tgt = torch.tensor(tg, device="cuda")
+    ref = torch.nn.functional.cross_entropy(logits.double().cpu(), torch.tensor(tg.astype(np.int64)), ignore_index=-1)
+    lib = _lib.lib()
+
+    def run(buf, dlog):
+        assert lib.wn_softmax_xent(ptr(logits), ptr(tgt), ptr(buf), ptr(dlog), N, Q, -1, stream_ptr()) == 0
+
+    buf = torch.full((_lib.XENT_LOSS_WORDS,), float("nan"), device="cuda")
+    dlog = torch.empty_like(logits)
+    run(buf, dlog)
+    torch.cuda.synchronize()
+    assert abs(float(buf[0]) - float(ref)) < 2e-5
+    inv = 1.0 / int((tg >= 0).sum())
+    np.testing.assert_allclose(float(dlog[tg >= 0][:, :].sum(1).abs().max()), 0.0, atol=1e-6)     # rows of softmax - onehot
+    assert float(dlog[int(np.argmax(tg >= 0)), int(tg[np.argmax(tg >= 0)])]) < 0 and float(dlog.abs().max()) <= inv * 1.0001
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        run(buf, dlog)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            buf2 = torch.empty((_lib.XENT_LOSS_WORDS,), device="cuda")
+            dlog2 = torch.empty_like(logits)
+            run(buf2, dlog2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(buf2[0]) == float(buf[0])
+    assert torch.equal(dlog2, dlog)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("scale", [2.0 ** 20, 1.0, 2.0 ** -30])
 def test_fp16x2_split_follows_the_gradient_range(scale):
     """WN_GEMM_FP16X2 scales the operands of the skip-path contractions by a power of two taken from their MEASURED range
