@@ -554,10 +554,14 @@ __global__ void k16_wgrad_reduce(WG16 a, int slabs) {
     if (!ob) return;
     const int cpb = (a.R + kWT - 1) / kWT;
     const int nch = a.nB * cpb;
+    // (the slab ranges in 32-bit arithmetic: launch_wgrad16 guarantees nch * (slabs + 1) < 2^31 -- the 64-bit divisions this
+    // loop used to do per thread and slab were most of its 41 us)
     float sum = 0.f;
+    unsigned cb = 0;
     for (int sl = 0; sl < slabs; ++sl) {
-        const int c_begin = (int)((long long)nch * sl / slabs), c_end = (int)((long long)nch * (sl + 1) / slabs);
-        if (c_begin < c_end) sum += a.part[((size_t)sl * gridDim.y + p) * 65536 + e];
+        const unsigned ce = (unsigned)nch * (unsigned)(sl + 1) / (unsigned)slabs;
+        if (cb < ce) sum += a.part[((size_t)sl * gridDim.y + p) * 65536 + e];
+        cb = ce;
     }
     const int m = 64 * (wm & 1) + 32 * mi + acc_row(r, h);
     const int n = 32 * ni + j;
@@ -571,6 +575,7 @@ int launch_wgrad16(const WG16& a, int nprob, hipStream_t s) {
     int slabs = 256 / nprob;                             // every workgroup resident at once: slabs stream in step
     if (slabs < 1) slabs = 1;
     if (slabs > nch) slabs = nch;
+    if ((long long)nch * (slabs + 1) >= (1ll << 31)) { wn::set_error("w16 wgrad: %d chunks x %d slabs overflows", nch, slabs); return WN_ESHAPE; }
 #define WGL(RB)                                                                                                   \
     do {                                                                                                          \
         static bool attr = false;                                                                                 \
