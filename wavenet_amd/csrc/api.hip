@@ -205,9 +205,11 @@ int wn_pointwise_bwd(const float* x, const float* W, const float* dout, float* d
         dx = nullptr;
     }
     if (dW && !force_generic() && mfma_pointwise_supported(Cin, Cout)) {
-        int rc = mfma_pointwise_bwd_dw(x, dout, dW, N, Cin, Cout, act, as_stream(stream));
+        bool bias_done = false;
+        int rc = mfma_pointwise_bwd_dw(x, dout, dW, N, Cin, Cout, act, dbias, &bias_done, as_stream(stream));
         if (rc) return rc;
         dW = nullptr;
+        if (bias_done) dbias = nullptr;
     }
     return generic_pointwise_bwd(x, W, dout, dx, dW, dbias, N, Cin, Cout, act, as_stream(stream));
 }

@@ -416,8 +416,15 @@ int launch_wgrad(WGArgs& a, int M, hipStream_t s) {
             WGArgs h = a;
             h.A = a.A + m0;
             for (int q = 0; q < a.nprob; ++q) h.out[q] = a.out[q] + (long long)m0 * a.ldo;
+            h.colsum = a.colsum ? a.colsum + m0 : nullptr;
+            h.colsum_done = 0;
             int rc = launch_wgrad_b3w(h, s);
             if (rc) return rc;
+            if (a.colsum && !h.colsum_done) {
+                wn::set_error("wgrad: the column sums were taken for a part of the rows only");
+                return WN_EARG;
+            }
+            a.colsum_done = h.colsum_done;
         }
         return WN_OK;
     }
@@ -479,11 +486,13 @@ int mfma_skip_bwd_dw(int L, const float* const* z, const int* cd, const float* d
 
 // dW[o][c] += sum_n dout[n][o] act(x[n][c])
 int mfma_pointwise_bwd_dw(const float* x, const float* dout, float* dW, long long N, int Cin, int Cout, int act,
-                          hipStream_t s) {
+                          float* dbias, bool* dbias_done, hipStream_t s) {
     if (N >= (1ll << 30)) { wn::set_error("pointwise dW: N too large"); return WN_ESHAPE; }
+    if (dbias_done) *dbias_done = false;
     for (int c0 = 0; c0 < Cin; c0 += 32 * WN_MAX_SRC) {
         WGArgs a{};
         a.A = dout; a.lda = Cout;
+        a.colsum = (c0 == 0 && dbias_done) ? dbias : nullptr;     // the column sums of dout: once, with the first group
         a.nprob = 0;
         for (int c = c0; c < Cin && a.nprob < WN_MAX_SRC; c += 32) {
             a.Bp[a.nprob] = x + c; a.out[a.nprob] = dW + c; ++a.nprob;
@@ -492,6 +501,7 @@ int mfma_pointwise_bwd_dw(const float* x, const float* dout, float* dW, long lon
         a.nB = 1; a.rows_A_per_b = (int)N; a.rows_B_per_b = (int)N; a.off = 0; a.act = act;
         int rc = launch_wgrad_mfma(a, Cout, s);
         if (rc) return rc;
+        if (a.colsum_done && dbias_done) *dbias_done = true;
     }
     return WN_OK;
 }

@@ -64,6 +64,10 @@ struct WGArgs {
     // fp16 split (WN_GEMM_FP16X2): amax_dev = bits of max |A| (required); bmax_dev = bits of max |B| or NULL when B is
     // provably in [-1, 1] (z)
     const unsigned* amax_dev; const unsigned* bmax_dev; int h2;
+    // wide block, six-term products only: colsum != NULL asks for colsum[m] += sum over rows of A[.][m] (the bias gradient of a
+    // 1x1 convolution whose weight gradient this launch is) from the A values the kernel loads anyway; launch_wgrad_b3w sets
+    // colsum_done when it took the request (other kernels ignore it), colsum_part is its scratch
+    float* colsum; float* colsum_part; int colsum_done;
 };
 
 // 1 unless WAVENET_HIP_GEMM=fp32: contractions use three-way bf16 splits (6 bf16 MFMAs per product term)
@@ -75,7 +79,7 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s);
 // dW_p[m*ldo + k*osk] += sum_n A[n][m] * act(B_p[row(n)][k]) (* B2_p);  M rows; picks bf16x3 or exact fp32
 int launch_wgrad(WGArgs& a, int M, hipStream_t s);
 // wide bf16x3 block (M == 256, nprob >= 8)
-int launch_wgrad_b3w(WGArgs a, hipStream_t s);
+int launch_wgrad_b3w(WGArgs& a, hipStream_t s);
 // one channel GEMM launch (multi-source form); picks bf16x3 or exact fp32
 int launch_colgemm_multi(CGArgs& a, hipStream_t s);
 // bf16x3 form of k_wgrad_mfma (same grid / arguments)

@@ -923,6 +923,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
             }
     };
     const float amask = active ? 1.f : 0.f;
+    float csum = 0.f;                    // six-term form: sum over this slab's rows of A[.][fm] (rows 8 fhh .. of every 16)
     if (r_begin < r_end) issue(r_begin);
     int c = 0;
     for (int r0 = r_begin; r0 < r_end; r0 += 32, ++c) {
@@ -943,6 +944,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
                     av *= ra < r_end ? 1.f : 0.f;
                     bv *= (rb < r_end && rb + off >= 0 && rb + off < a.rows_B_per_b) ? 1.f : 0.f;
                 }
+                if (TM == 6 && !HAS_B2) csum += av;
                 if (H2) {                                // fp16 two-way split of the scaled operands (bit patterns travel as bf16x8)
                     _Float16 y0, y1;
                     split2h(av * h2sa, y0, y1);
@@ -993,6 +995,10 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
             }
         }
     }
+    if (TM == 6 && !HAS_B2) {
+        // [slab][row half][channel]: k_colsum_reduce adds the 2 x slabs rows in index order
+        if (a.colsum_part && blockIdx.y == 0) a.colsum_part[((long long)blockIdx.x * 2 + fhh) * 256 + fm] = csum;
+    }
     if (!active) return;
     if (H2) {
         const float inv = 1.f / (h2sa * h2sb);               // exact: powers of two
@@ -1034,7 +1040,8 @@ __global__ void k_wgrad_b3w_reduce(WGArgs a, int nwg_x) {
 }
 
 // M == 256 and at least 8 problems: the wide block.  Picks its own row slabs (one workgroup per CU).
-int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
+int launch_wgrad_b3w(WGArgs& a_io, hipStream_t s) {
+    WGArgs a = a_io;
     static bool attr_set = false;
     if (!attr_set) {
 #define W_ATTR(B2_, ACT_)                                                                               \
@@ -1068,10 +1075,14 @@ int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
     // atomics per workgroup into the same addresses -- cost more than the contraction; with long slabs (config 2's dWs: 85
     // chunks) the two cost the same (the partial tiles are ~60 MB of extra traffic) and this form is deterministic.
     const size_t part_bytes = (size_t)grid.x * grid.y * 8 * (8 * 16 * 64) * sizeof(float);
-    a.part = reinterpret_cast<float*>(exec_scratch(part_bytes, "the weight-gradient partial tiles"));
-    if (!a.part) return WN_EARG;
     const bool one = one_term();
     const bool h2 = half2_mode() && a.h2 && a.amax_dev && !any_b2;
+    // the bias gradient rides along in the six-term form (the head convolutions): 2 x slabs rows of 256 column sums
+    const bool cs = a.colsum && !one && !h2 && !any_b2;
+    const size_t cs_bytes = cs ? (size_t)grid.x * 2 * 256 * sizeof(float) : 0;
+    a.part = reinterpret_cast<float*>(exec_scratch(part_bytes + cs_bytes, "the weight-gradient partial tiles"));
+    if (!a.part) return WN_EARG;
+    a.colsum_part = cs ? a.part + part_bytes / sizeof(float) : nullptr;
 #define W_LAUNCH(B2_, ACT_)                                                                                     \
     do {                                                                                                        \
         if (one) hipLaunchKernelGGL((k_wgrad_b3w<B2_, ACT_, 1>), grid, dim3(512), 2 * 8 * kTileBytes, s, a);     \
@@ -1091,6 +1102,11 @@ int launch_wgrad_b3w(WGArgs a, hipStream_t s) {
     WN_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_wgrad_b3w_reduce, dim3(128 / 4, a.nprob), dim3(256), 0, s, a, (int)grid.x);
     WN_LAUNCH_CHECK();
+    if (cs) {
+        const int rc = colsum_reduce_launch(a.colsum_part, 2 * (int)grid.x, 256, a.colsum, s);
+        if (rc) return rc;
+        a_io.colsum_done = 1;
+    }
     return WN_OK;
 }
 
