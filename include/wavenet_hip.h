@@ -71,7 +71,7 @@ const char* wn_last_error(void);
  * WAVENET_HIP_FORCE_GENERIC / _NO_FUSED_WIDE / _FWD_T1_MIN_BLOCKS inside the .so are per-call fields here):
  *   WN_EXEC_FORCE_GENERIC   every kernel of the call from the any-shape correctness path (generic_kernels.hip), fp32
  *   WN_EXEC_NO_FUSED_WIDE   the 128/128-channel bf16-operand layer forward as two launches instead of one (diagnostic)
- *   WN_EXEC_NO_FWD_GROUPS   see the define
+ *   WN_EXEC_NO_FWD_GROUPS, WN_EXEC_NO_PIPELINED_GEMM   see the defines
  * fwd_t1_min_blocks: launch size (workgroups of four 32-column tiles) from which the fused 32-channel layer forward takes its
  * one-tile-per-wave form; 0 = the library's default (512: every CU gets two to four workgroups), n > 0 = n (1 = always:
  * parity tests of that kernel at small sizes), < 0 = never.
@@ -82,6 +82,8 @@ enum { WN_GEMM_FP32 = 0, WN_GEMM_BF16X3 = 1, WN_GEMM_BF16 = 2, WN_GEMM_FP16X2 = 
 #define WN_EXEC_NO_FUSED_WIDE 2u
 #define WN_EXEC_NO_FWD_GROUPS 4u   /* fp16x2 stack forward: every layer its own launch (no k_layer_fwd_h2_grp); same results,
                                       bit for bit -- A/B timing and the parity tests of the per-layer kernel */
+#define WN_EXEC_NO_PIPELINED_GEMM 8u /* fp16x2 skip contractions: the one-chunk-ahead kernel (k_colgemm_b3) instead of
+                                        k_colgemm_h2q; same results, bit for bit -- A/B timing and parity of the older kernel */
 typedef struct WnExec {
     int precision;
     unsigned flags;

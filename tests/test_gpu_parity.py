@@ -616,6 +616,41 @@ def test_grouped_layer_forward_is_the_per_layer_forward_bit_for_bit(B, T):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("B,T,tw,bias", [(1, 300, 300, False), (2, 1000, 777, True), (3, 4099, 2050, False),
+                                          (8, 16384, 12290, False)])
+def test_pipelined_skip_sum_is_the_older_kernel_bit_for_bit(B, T, tw, bias):
+    """k_colgemm_h2q (fetches three half-chunks ahead, scalar-base addressing, inline-asm requests with counted waits) against
+    k_colgemm_b3<0, ., 3, 8> (WN_EXEC_NO_PIPELINED_GEMM) through wn_skip_sum_fwd: the 40-layer skip sum of config 2's
+    topology on the loss window, ragged sizes (a last block of one column, windows that start inside a clip), with and
+    without biases, and the bench's own shape: IDENTICAL bit for bit -- same products, same order.  The older kernel is
+    held to the oracle by the skip-sum tests above (wavenet.py:363-364, 579).  Sources that are NOT equally spaced
+    arrays take the older kernel by themselves (the launcher's check): same result again."""
+    if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1":
+        pytest.skip("generic kernels only")
+    from wavenet_amd._lib import ptr, ptr_array, int_array, stream_ptr
+    lib = _lib.lib()
+    L, Cd, Cs = 40, 32, 256
+    g = torch.Generator(device="cuda").manual_seed(T + tw)
+    zall = torch.rand(L, B, T, Cd, device="cuda", generator=g) * 2 - 1
+    Ws = [torch.randn(Cs, Cd, device="cuda", generator=g) * 0.2 for _ in range(L)]
+    bs = [torch.randn(Cs, device="cuda", generator=g) * 0.1 for _ in range(L)] if bias else None
+    t_off = T - tw
+    outs = []
+    for flags, zs in ((0, [zall[l] for l in range(L)]), (_lib.WN_EXEC_NO_PIPELINED_GEMM, [zall[l] for l in range(L)]),
+                      (0, [zall[l].clone() if l == 7 else zall[l] for l in range(L)])):
+        skip = torch.full((B, tw, Cs), float("nan"), device="cuda")
+        rc = lib.wn_skip_sum_fwd(L, ptr_array(zs), ptr_array(Ws), ptr_array(bs) if bs else None, int_array([Cd] * L), ptr(skip),
+                                 B, T, t_off, tw, Cs, 0, EX("fp16x2", flags=flags), stream_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append(skip)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[2])
+    ref = sum(torch.einsum("btc,sc->bts", zall[l][:, t_off:].double(), Ws[l].double()) + (bs[l].double() if bs else 0) for l in range(L))
+    np.testing.assert_allclose(to_np(outs[0]), ref.cpu().numpy(), atol=2e-5, rtol=4e-6)
+
+
 def test_fast_step_full_window_output_is_the_references_shape_and_values():
     """faster_wavenet.py:105-113 returns the softmax of the WHOLE rolled window, (1, Q, 1, W), every cached column under
     the ELU head; ``keep_window`` + ``full_window=True`` reproduces that from a device-side ring of logits: all W columns

@@ -13,6 +13,8 @@
 // (global_load_lds, no staging registers) into a double buffer: the copy of chunk c+1 lands while chunk c
 // computes.  X columns are split in registers right after their (prefetched) float4 loads.
 #include "mfma_gemm.hpp"
+#include "h2_ops.hpp"
+#include <type_traits>
 
 namespace wn {
 
@@ -590,6 +592,238 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
     }
 }
 
+// =============================================================================================
+// k_colgemm_h2q: the fp16-split multi-source contraction (mode 0, eight m-tiles per workgroup: the skip sum) with every
+// fetch three HALF-chunks ahead.  DESIGN.md ("what bounds the skip contractions") has the measurements behind each choice:
+//   * the loop of k_colgemm_b3 waits ~2 us per chunk for requests issued one chunk ago (and its __syncthreads() drains
+//     vmcnt, so the prefetch cannot be deepened there);
+//   * one eight-wave workgroup per CU with a deeper prefetch runs all its waves in lock step behind one barrier: here a
+//     workgroup is four waves (one per SIMD, 128 columns) and a CU holds two, so that one group's barrier / request phase
+//     runs under the other's MFMAs;
+//   * a step is HALF a chunk (one 16-deep k-step: 24 MFMAs per wave, 16 KB of image); the image sits in a ring of four such
+//     buffers (64 KB per workgroup), X in a ring of four register pairs:
+//       step s:  wait (image(s), X(s+1) landed) -> barrier -> request image(s+3) -> 24 MFMAs of half-chunk s on operand
+//                set s & 1, the split of X(s+1) into set (s+1) & 1 spread over them -> request X(s+4) into X(s)'s registers
+//   * requests are inline asm (invisible to hipcc's counter pass) and retire in issue order; between X(s+1) and the wait of
+//     step s lie image(s+1), X(s+2), image(s+2), X(s+3) = 12 requests: `s_waitcnt vmcnt(12)`.  Requests past the end re-fetch
+//     the last half-chunk (uniform counts).  nchunks must be even (the loop is unrolled by four: static register indices);
+//   * every request is `scalar base + 32-bit lane offset`: with 64-bit vector address arithmetic, a v_readfirstlane + M0
+//     write per request and the per-source pointer / shift / stride fetched from the kernel arguments behind
+//     `s_waitcnt lgkmcnt(0)`, stamps showed 350-1,100 cycles for issuing the four image requests and 600-1,300 for the two X
+//     requests of a 770-cycle half-chunk.  The lane offsets are fixed for the launch, the bases advance by a uniform stride
+//     per chunk (the launcher checks that the sources are equally spaced arrays of one chunk each with one row shift -- the
+//     layers' z of a stack -- or one array), M0 comes from scalar arithmetic.
+// Same results as k_colgemm_b3<0, ., 3, 8>, bit for bit (same products in the same order); config 2's skip sum 0.255 ->
+// 0.242 ms.  `dz` (mode 2: 8 chunks per workgroup, prologue and epilogue dominate) measured equal and stays on the older kernel.
+// =============================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void asm_load16(f32x4& dst, const float* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+static constexpr int kH2qTB = kTileBytes * 2 / 3;            // 4 KB: one m-tile of an fp16-split chunk ([ks][plane][lane][8])
+static constexpr int kH2qHalf = kH2qTB / 2;                  // 2 KB: one k-step of it
+static constexpr int kH2qLds = 4 * 8 * kH2qHalf;             // ring of four half-chunk images
+
+__device__ __forceinline__ void asm_load16s(f32x4& dst, unsigned voff, const char* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+// two 1 KB pieces of one image tile half: lane offset voff, uniform base sbase, LDS destination m0v (+ 1 KB for the second)
+__device__ __forceinline__ void asm_dma2(unsigned voff, const char* sbase, unsigned m0v) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
+                 :: "v"(voff), "s"(sbase), "s"(m0v) : "memory");
+}
+
+// x_stride: bytes from chunk c's X to chunk c + 1's (the launcher's check: equally spaced sources of one chunk each, or
+// one source: 128)
+template <int MODE, int ACT>
+__global__ __launch_bounds__(256, 2) void k_colgemm_h2q(CGArgs a, const __bf16* __restrict__ img, int mtiles, int nchunks,
+                                                        long long x_stride) {
+    constexpr int MT = 8;
+    static_assert(MODE == 0 || MODE == 2, "plain contractions only");
+    extern __shared__ __attribute__((aligned(16))) char ldsq[];
+    const float h2sx = h2_scale(a.xmax_dev, kH2ScaleX);
+    const float h2sw = h2_scale(a.wmax_dev, kH2ScaleW);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    int bx, by;
+    {   // the m-tile groups of one column block on the same XCD at consecutive slots (as in k_colgemm_b3)
+        const int ny = (mtiles + MT - 1) / MT;
+        const int nx = gridDim.x / ny;
+        const int id = blockIdx.x;
+        const int full = nx & ~7;
+        if (id < full * ny) {
+            const int g = id / (8 * ny), rem = id - g * 8 * ny;
+            bx = g * 8 + (rem & 7);
+            by = rem >> 3;
+        } else {
+            const int t = id - full * ny;
+            by = t % ny;
+            bx = full + t / ny;
+        }
+    }
+    const int t0 = by * MT;
+    const long long n = ((long long)bx * 4 + wave) * 32 + j;
+    const bool nvalid = n < a.N;
+    long long rb0 = 0;
+    int rbase = -(1 << 30);
+    long long no = n;
+    if (nvalid) {
+        long long b = n / a.rows_out_per_b;
+        rbase = (int)(n - b * a.rows_out_per_b) + a.off;
+        rb0 = b * a.rows_src_per_b;
+        if (a.out_rows_per_b) no = b * a.out_rows_per_b + a.out_row0 + (n - b * a.rows_out_per_b);
+    }
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    if (MODE == 0) {
+        for (int src = 0; src < a.nsrc; ++src)
+            if (a.bias[src]) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    if (t0 + mt < mtiles) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mt][r] += a.bias[src][(t0 + mt) * 32 + b3_ch(r, h)] * (h2sw * h2sx);
+                    }
+            }
+    }
+    const int nhalf = 2 * nchunks;
+    // this wave copies the half-chunk pieces of m-tiles t0 + wave and t0 + wave + 4: four 1 KB requests
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ldsq;
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    unsigned tile_off[2];              // lane offsets into a chunk's image: this wave's two m-tiles
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+        tile_off[tt] = (unsigned)((t0 + swave + 4 * tt < mtiles) ? t0 + swave + 4 * tt : mtiles - 1) * kH2qTB + lane * 16;
+    const long long img_stride = (long long)mtiles * kH2qTB;          // bytes from chunk c's image to chunk c + 1's
+    auto dma_half = [&](int s) {
+        const int ss = s < nhalf ? s : nhalf - 1;
+        const char* base = reinterpret_cast<const char*>(img) + (long long)(ss >> 1) * img_stride + (ss & 1) * kH2qHalf;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+            asm_dma2(tile_off[tt], base, lds0 + ((s & 3) * MT + swave + 4 * tt) * kH2qHalf);
+    };
+    f32x4 xr[4][2];                    // X(s) in xr[s & 3]: 8 consecutive k of this lane's column
+    // one row shift for all sources: the lane's row, its validity and its byte offset are fixed for the launch
+    const int rs0 = rbase + a.soff[0];
+    const bool rv0 = rs0 >= 0 && rs0 < a.rows_src_per_b;
+    const float msk0 = rv0 ? 1.f : 0.f;
+    const unsigned x_off = (unsigned)(((rb0 + (rv0 ? rs0 : 0)) * (a.ldx ? a.ldx : a.K[0]) + 8 * h) * 4);
+    const char* x0 = reinterpret_cast<const char*>(a.X[0]);
+    auto load_x = [&](int s, auto slot_tag) {
+        constexpr int slot = decltype(slot_tag)::value;
+        const int ss = s < nhalf ? s : nhalf - 1;
+        const char* base = x0 + (long long)(ss >> 1) * x_stride + (ss & 1) * 64;
+        asm_load16s(xr[slot][0], x_off, base);
+        asm_load16s(xr[slot][1], x_off + 16, base);
+    };
+    f16x8 xh[2], xm[2];                // operand sets by half-chunk parity
+    auto split_one = [&](const f32x4 (&raw)[2], float ms, int e, f16x8& oh, f16x8& om) {
+        const float v = raw[e >> 2][e & 3];
+        _Float16 a0, a1;
+        split2h(act_apply_t<ACT>(v) * (ms * h2sx), a0, a1);
+        oh[e] = a0; om[e] = a1;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    load_x(0, I0{});
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0][0]), "+v"(xr[0][1]) : : "memory");
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split_one(xr[0], msk0, e, xh[0], xm[0]);
+    asm volatile("" : "+v"(xh[0]), "+v"(xm[0]));
+    dma_half(0); load_x(1, I1{});
+    dma_half(1); load_x(2, I2{});
+    dma_half(2); load_x(3, I3{});
+
+    auto step = [&](int s, auto p_tag) {
+        constexpr int p = decltype(p_tag)::value;          // s & 3
+        constexpr int set = p & 1, nxt = 1 - set;
+        constexpr int rn = (p + 1) & 3;                     // raw slot of X(s + 1)
+        asm volatile("s_waitcnt vmcnt(12)" : "+v"(xr[rn][0]), "+v"(xr[rn][1]) : : "memory");
+        const float ms = msk0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // image(s) complete; every wave is done with half-chunk s - 1
+        dma_half(s + 3);
+        const char* Ab = ldsq + (p * MT) * kH2qHalf + lane * 16;
+        f16x8 fr[2][2];
+        auto ldA = [&](int mt, f16x8 (&f)[2]) {
+            f[0] = *reinterpret_cast<const f16x8*>(Ab + mt * kH2qHalf);
+            f[1] = *reinterpret_cast<const f16x8*>(Ab + mt * kH2qHalf + 1024);
+        };
+        ldA(0, fr[0]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f16x8 (&f)[2] = fr[mt & 1];
+            asm volatile("" ::"v"(f[0]));
+            asm volatile("" ::"v"(f[1]));
+            if (mt + 1 < MT) ldA(mt + 1, fr[(mt + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            split_one(xr[rn], ms, mt, nxt ? xh[1] : xh[0], nxt ? xm[1] : xm[0]);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[1], xh[set], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], xm[set], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[0], xh[set], acc[mt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the split values are complete before the raw registers of X(s) (split a step ago) take the next request
+        asm volatile("" : "+v"(xh[nxt]), "+v"(xm[nxt]));
+        load_x(s + 4, p_tag);
+    };
+    for (int s = 0; s < nhalf; s += 4) {
+        step(s, I0{});
+        step(s + 1, I1{});
+        step(s + 2, I2{});
+        step(s + 3, I3{});
+    }
+    // the requests past the end are still in flight (into registers that stay allocated and into the ring)
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(xr[0][0]), "+v"(xr[0][1]), "+v"(xr[1][0]), "+v"(xr[1][1]), "+v"(xr[2][0]), "+v"(xr[2][1]),
+                   "+v"(xr[3][0]), "+v"(xr[3][1])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] *= 1.f / (h2sw * h2sx);                 // exact: a power of two
+    __syncthreads();                                               // the ring becomes the waves' 4 KB row patches
+    float* patch = reinterpret_cast<float*>(ldsq) + wave * 1024;
+    const RowMap rm = row_map(no, nvalid, lane);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        if (t0 + mt >= mtiles) break;
+        float* __restrict__ og = (MODE == 2) ? a.out[t0 + mt] : a.out[0];
+        const int col = (MODE == 2) ? 0 : (t0 + mt) * 32;
+        float4 t[4], v[4], u[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = make_float4(acc[mt][4 * q], acc[mt][4 * q + 1], acc[mt][4 * q + 2], acc[mt][4 * q + 3]);
+        if (MODE == 0 && a.gate_x) {
+            rows_load(a.gate_x, a.ldo, col, rm, lane, v);
+            rows_to_tile(patch, lane, v, u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                t[q].x *= act_grad(u[q].x, a.gate_act); t[q].y *= act_grad(u[q].y, a.gate_act);
+                t[q].z *= act_grad(u[q].z, a.gate_act); t[q].w *= act_grad(u[q].w, a.gate_act);
+            }
+        }
+        if (MODE == 0 && a.residual) {
+            rows_load(a.residual, a.ldo, col, rm, lane, v);
+            rows_to_tile(patch, lane, v, u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { t[q].x += u[q].x; t[q].y += u[q].y; t[q].z += u[q].z; t[q].w += u[q].w; }
+        }
+        if (a.accumulate) {
+            rows_load(og, a.ldo, col, rm, lane, v);
+            rows_to_tile(patch, lane, v, u);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { t[q].x += u[q].x; t[q].y += u[q].y; t[q].z += u[q].z; t[q].w += u[q].w; }
+        }
+        tile_store_rows(patch, lane, t, og, a.ldo, col, rm);
+    }
+}
+
 int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     if (mode != 0 && mode != 2 && mode != 3 && mode != 4 && mode != 5) return WN_ESHAPE;
     int mtiles, nchunks, cps;
@@ -657,6 +891,38 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
         else hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, 3, 4>), grid, dim3(256), 0, s, a, (const __bf16*)img,        \
                                 mtiles, nchunks, cps, (const __bf16*)nullptr);                                          \
     } while (0)
+    // the pipelined kernel takes sources that are equally spaced arrays of one chunk each with one row shift (the z of a
+    // stack's layers), or a single source
+    long long x_stride = 128;
+    bool lean = h2 && mt8 && mode == 0 && (nchunks & 1) == 0 && !exec_flag(WN_EXEC_NO_PIPELINED_GEMM) &&
+                (long long)a.N * (a.ldx ? a.ldx : a.K[0]) * 4 < (1ll << 32);
+    if (lean && mode == 0 && a.nsrc > 1) {
+        x_stride = (const char*)a.X[1] - (const char*)a.X[0];
+        lean = cps == 1;
+        for (int i = 1; i < a.nsrc && lean; ++i)
+            lean = a.soff[i] == a.soff[0] && a.K[i] == a.K[0] && (const char*)a.X[i] - (const char*)a.X[i - 1] == x_stride;
+    } else if (lean && mode == 0) {
+        lean = a.nsrc == 1;
+    }
+    if (lean) {
+        static bool attr = false;
+        if (!attr) {
+#define Q_ATTR(MODE_, ACT_)                                                                                   \
+    WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_colgemm_h2q<MODE_, ACT_>),                      \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kH2qLds))
+            Q_ATTR(0, WN_ACT_NONE); Q_ATTR(0, WN_ACT_RELU); Q_ATTR(0, WN_ACT_ELU);
+#undef Q_ATTR
+            attr = true;
+        }
+#define Q_LAUNCH(MODE_, ACT_)                                                                                 \
+    hipLaunchKernelGGL((k_colgemm_h2q<MODE_, ACT_>), grid, dim3(256), kH2qLds, s, a, (const __bf16*)img, mtiles, nchunks, x_stride)
+        if (a.act == WN_ACT_RELU) Q_LAUNCH(0, WN_ACT_RELU);
+        else if (a.act == WN_ACT_ELU) Q_LAUNCH(0, WN_ACT_ELU);
+        else Q_LAUNCH(0, WN_ACT_NONE);
+#undef Q_LAUNCH
+        WN_LAUNCH_CHECK();
+        return WN_OK;
+    }
     if (h2) {
         if (mode == 2) CG_LAUNCH_H2(2, WN_ACT_NONE);
         else if (a.act == WN_ACT_RELU) CG_LAUNCH_H2(0, WN_ACT_RELU);
