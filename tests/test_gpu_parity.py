@@ -647,8 +647,10 @@ def test_pipelined_skip_sum_is_the_older_kernel_bit_for_bit(B, T, tw, bias):
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[1])
     assert torch.equal(outs[0], outs[2])
-    ref = sum(torch.einsum("btc,sc->bts", zall[l][:, t_off:].double(), Ws[l].double()) + (bs[l].double() if bs else 0) for l in range(L))
-    np.testing.assert_allclose(to_np(outs[0]), ref.cpu().numpy(), atol=2e-5, rtol=4e-6)
+    if B * tw <= 10_000:               # the float64 reference on the small cases; the bench's shape is held by the equality above
+        ref = sum(torch.einsum("btc,sc->bts", zall[l][:, t_off:].double(), Ws[l].double()) + (bs[l].double() if bs else 0)
+                  for l in range(L))
+        np.testing.assert_allclose(to_np(outs[0]), ref.cpu().numpy(), atol=2e-5, rtol=4e-6)
 
 
 def test_fast_step_full_window_output_is_the_references_shape_and_values():
