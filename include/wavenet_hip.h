@@ -82,8 +82,8 @@ enum { WN_GEMM_FP32 = 0, WN_GEMM_BF16X3 = 1, WN_GEMM_BF16 = 2, WN_GEMM_FP16X2 = 
 #define WN_EXEC_NO_FUSED_WIDE 2u
 #define WN_EXEC_NO_FWD_GROUPS 4u   /* fp16x2 stack forward: every layer its own launch (no k_layer_fwd_h2_grp); same results,
                                       bit for bit -- A/B timing and the parity tests of the per-layer kernel */
-#define WN_EXEC_NO_PIPELINED_GEMM 8u /* fp16x2 skip contractions: the one-chunk-ahead kernel (k_colgemm_b3) instead of
-                                        k_colgemm_h2q; same results, bit for bit -- A/B timing and parity of the older kernel */
+#define WN_EXEC_NO_PIPELINED_GEMM 8u /* fp16x2 skip contractions: the older kernels (k_colgemm_b3, k_wgrad_b3w) instead of
+                                        k_colgemm_h2q / k_wgrad_h2p; same results, bit for bit -- A/B timing, parity tests */
 typedef struct WnExec {
     int precision;
     unsigned flags;

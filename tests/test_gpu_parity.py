@@ -653,6 +653,38 @@ def test_pipelined_skip_sum_is_the_older_kernel_bit_for_bit(B, T, tw, bias):
         np.testing.assert_allclose(to_np(outs[0]), ref.cpu().numpy(), atol=2e-5, rtol=4e-6)
 
 
+@pytest.mark.parametrize("B,T,tw", [(1, 300, 300), (2, 1000, 777), (3, 4099, 2050), (2, 16384, 12290), (8, 16384, 12290)])
+def test_pipelined_skip_weight_gradient_is_the_older_kernel_bit_for_bit(B, T, tw):
+    """k_wgrad_h2p (raw A by LDS-DMA into a staging ring, raw B two chunks ahead, the split of the next chunk inside the MFMA
+    stream) against k_wgrad_b3w<false, 0, 3> (WN_EXEC_NO_PIPELINED_GEMM) through wn_skip_sum_bwd_dw: dWs of 40 layers,
+    slabs with odd and even chunk counts, a ragged last chunk, a two-row last slab (B = 2 at the bench's length), the
+    bench's own shape -- IDENTICAL bit for bit, three times in a row (a first form of the kernel was intermittently wrong
+    at full size only: in-flight registers copied by the compiler), and equal to a float64 contraction to fp32 rounding
+    (chainer's Convolution2D backward for the 1x1 skip projection, wavenet.py:363-364)."""
+    if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1":
+        pytest.skip("generic kernels only")
+    from wavenet_amd._lib import ptr, ptr_array, int_array, stream_ptr
+    lib = _lib.lib()
+    L, Cd, Cs = 40, 32, 256
+    g = torch.Generator(device="cuda").manual_seed(T + tw)
+    zall = torch.rand(L, B, T, Cd, device="cuda", generator=g) * 2 - 1
+    dskip = torch.randn(B, tw, Cs, device="cuda", generator=g) * 1e-3
+
+    def run(flags):
+        dWs = [torch.zeros(Cs, Cd, device="cuda") for _ in range(L)]
+        rc = lib.wn_skip_sum_bwd_dw(L, ptr_array([zall[l] for l in range(L)]), int_array([Cd] * L), ptr(dskip), ptr_array(dWs), None,
+                                    B, T, T - tw, tw, Cs, EX("fp16x2", flags=flags), stream_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        return torch.stack(dWs)
+
+    old = run(_lib.WN_EXEC_NO_PIPELINED_GEMM)
+    for _ in range(3):
+        assert torch.equal(run(0), old)
+    ref = torch.einsum("btc,lbtd->lcd", dskip.double(), zall[:, :, T - tw:].double())
+    assert float((old.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-9
+
+
 def test_fast_step_full_window_output_is_the_references_shape_and_values():
     """faster_wavenet.py:105-113 returns the softmax of the WHOLE rolled window, (1, Q, 1, W), every cached column under
     the ELU head; ``keep_window`` + ``full_window=True`` reproduces that from a device-side ring of logits: all W columns

@@ -1283,6 +1283,190 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_b3w(WGArgs a) {
         for (int r = 0; r < 16; ++r) o[(mt * 16 + r) * 64] = acc[mt][r];
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_wgrad_h2p: the wide weight-gradient block for the fp16-split dWs launch (M == 256 rows of A = dskip, B = z of one
+// layer per wave), restructured after its in-kernel stamps: a 32-row chunk of k_wgrad_b3w<., ., 3> cost a wave 8,000
+// cycles -- split + image stores 1,600, barrier 1,100-2,000, issuing the 32 dword loads (64-bit address arithmetic each)
+// 1,250-2,350, the 48 MFMAs 3,050 (two waves share a SIMD's pipe) -- with all eight waves in lock step behind the one
+// barrier, i.e. the matrix pipe idle through 62 % of the chunk.  Here
+//   * the raw A chunk (32 rows x 256 floats = 32 KB) arrives by LDS-DMA into a two-deep staging ring and the raw B rows
+//     (16 dwords per lane) into two register sets, both requested TWO chunks ahead (right after the barrier that frees
+//     their buffers): scalar bases + fixed lane offsets for the DMA, scalar row offsets + one select per B load;
+//   * the split of chunk c + 1 (A: staging -> fp16 planes of the next image buffer; B: registers -> the other operand
+//     set) rides in the MFMA stream of chunk c, four values per m-tile;
+//   * one LDS-only barrier per chunk; the requests of chunk c + 1 are a whole chunk old when they are waited for
+//     (`s_waitcnt vmcnt(0)` in front of the barrier: chunk c + 2 is requested behind it).
+// Same products in the same order as k_wgrad_b3w<false, ACT, 3>: bit-identical partial tiles.  Requirements (the
+// launcher checks): fp16 split with a measured A range, no B2 factor, lda == 256, 32-bit byte offsets into a B clip.
+// LDS: two 32 KB images ([tile][ks][plane][lane][8] fp16) + two 32 KB staging buffers = 128 KB, one workgroup per CU.
+// ---------------------------------------------------------------------------------------------
+static constexpr int kWpTile = 4096, kWpImg = 8 * kWpTile, kWpStage = 32 * 1024, kWpLds = 2 * kWpImg + 2 * kWpStage;
+
+template <int ACT>
+__global__ __launch_bounds__(512, 1) void k_wgrad_h2p(WGArgs a) {
+    constexpr int MT = 8;
+    const float h2sa = h2_scale(a.amax_dev, 1.f);
+    const float h2sb = h2_scale(a.bmax_dev, kH2ScaleX);
+    extern __shared__ __attribute__((aligned(16))) char ldsp2[];
+    char* const img0 = ldsp2;                                  // image buffers: img0 + (c & 1) * kWpImg
+    char* const stg0 = ldsp2 + 2 * kWpImg;                     // staging:       stg0 + (c & 1) * kWpStage
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int p = blockIdx.y * 8 + wv;
+    const bool active = p < a.nprob;
+    const int off = a.off + a.offp[active ? p : 0];
+    const int b = blockIdx.x / a.wgs_per_b;
+    const int r_begin = (blockIdx.x - b * a.wgs_per_b) * a.rows_per_wg;
+    const int r_end = min(a.rows_A_per_b, r_begin + a.rows_per_wg);
+    const int nch = (r_end - r_begin + 31) / 32;
+    const char* Abase = reinterpret_cast<const char*>(a.A + ((long long)b * a.rows_A_per_b) * 256);          // uniform
+    const char* Bbase = reinterpret_cast<const char*>(a.Bp[active ? p : 0] + ((long long)b * a.rows_B_per_b + off) * a.ldb);
+    const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)ldsp2;
+    const unsigned a_voff = lane * 16;                          // a staging row: lane L moves channels 4 L .. 4 L + 3
+    const int ldb4 = a.ldb * 4;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    const int fm = tid & 255, fhh = tid >> 8;
+    const float amask = active ? 1.f : 0.f;
+    float brr[2][2][8];                 // raw B of chunks c + 1 / c + 2 (set = chunk parity): [ks][jj] = row 16 ks + 8 h + jj
+    f16x8 bh[2][2], bm[2][2];           // B operands by chunk parity
+
+    // requests of chunk cc (clamped to the slab's last chunk): 4 LDS-DMA rows of A (inline asm: scalar base, fixed lane
+    // offset, M0 from scalar arithmetic) + 16 dwords of B as ORDINARY loads -- the compiler must know that brr is in flight:
+    // as asm outputs it copied them to other registers at the loop header, before they had landed (intermittently wrong
+    // sums at full size).  Rows past the slab's end are clamped in scalar arithmetic (two candidates per load, the lane's
+    // row half selects) and masked at split time.
+    auto issue = [&](int cc, auto set_tag) {
+        constexpr int set = decltype(set_tag)::value;
+        const int c = cc < nch ? cc : nch - 1;
+        const int r0 = r_begin + 32 * c;
+        const int rlast = r_end - 1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                           // this wave's four rows of the chunk (clamped at the slab's end)
+            const int row = min(r0 + 4 * wv + k, rlast);
+            const char* sb = Abase + (long long)row * 1024;
+            const unsigned m0v = lds_base + 2 * kWpImg + set * kWpStage + (4 * wv + k) * 1024;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(a_voff), "s"(sb), "s"(m0v) : "memory");
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int row = r0 + 16 * ks + jj;
+                const unsigned o0 = (unsigned)(min(row, rlast) * ldb4), o1 = (unsigned)(min(row + 8, rlast) * ldb4);   // scalar
+                const unsigned vo = (h ? o1 : o0) + (unsigned)(j * 4);
+                brr[set][ks][jj] = *reinterpret_cast<const float*>(Bbase + vo);
+            }
+    };
+    // split of two A values and two B values of chunk cc (e0, e0 + 1 of k-step ks) into A fragments fa / B operand set
+    auto split4 = [&](int cc, auto set_tag, int ks, int e0, f16x8 (&fah)[2], f16x8 (&fam)[2]) {
+        constexpr int set = decltype(set_tag)::value;
+        const int r0 = r_begin + 32 * cc;                       // NOT clamped: a chunk past the slab's end is all zeros
+        const char* st = stg0 + set * kWpStage;
+#pragma unroll
+        for (int e = e0; e < e0 + 2; ++e) {
+            const int ra = r0 + 16 * ks + 8 * fhh + e, rb = r0 + 16 * ks + 8 * h + e;
+            float av = *reinterpret_cast<const float*>(st + (16 * ks + 8 * fhh + e) * 1024 + fm * 4);
+            float bv = act_apply_t<ACT>(brr[set][ks][e]) * amask;
+            av = ra < r_end ? av : 0.f;
+            bv = rb < r_end ? bv : 0.f;
+            _Float16 y0, y1;
+            split2h(av * h2sa, y0, y1);
+            fah[ks][e] = y0; fam[ks][e] = y1;
+            split2h(bv * h2sb, y0, y1);
+            bh[set][ks][e] = y0; bm[set][ks][e] = y1;
+        }
+    };
+    auto store_frag = [&](int set, int ks, const f16x8& fah, const f16x8& fam) {
+        char* d = img0 + set * kWpImg + (fm >> 5) * kWpTile + ks * 2048 + ((fm & 31) + 32 * fhh) * 16;
+        *reinterpret_cast<f16x8*>(d) = fah;
+        *reinterpret_cast<f16x8*>(d + 1024) = fam;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    if (nch > 0) {
+        // chunk 0: requested, landed, published, split outside the MFMA stream; chunk 1 is requested in between
+        issue(0, I0{});
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0) (a builtin: the compiler's load bookkeeping follows it)
+        __builtin_amdgcn_s_barrier();
+        issue(1, I1{});
+        {
+            f16x8 fah[2], fam[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int e0 = 0; e0 < 8; e0 += 2) split4(0, I0{}, ks, e0, fah, fam);
+                store_frag(0, ks, fah[ks], fam[ks]);
+            }
+        }
+    }
+    auto step = [&](int c, auto set_tag) {
+        constexpr int set = decltype(set_tag)::value;          // c & 1
+        constexpr int nxt = 1 - set;
+        using NXT = std::integral_constant<int, nxt>;
+        // chunk c + 1's requests are a chunk old; image(c) and (for the others) this wave's rows of staging(c + 1) are complete
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): the loads the compiler tracks AND the LDS-DMA it cannot see
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(c + 2, set_tag);                                  // staging / raw set of chunk c: split a chunk ago by everyone
+        const char* Al = img0 + set * kWpImg + lane * 16;
+        f16x8 fr[2][2][2];
+        auto ldA = [&](int mt, f16x8 (&f)[2][2]) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f[ks][0] = *reinterpret_cast<const f16x8*>(Al + mt * kWpTile + ks * 2048);
+                f[ks][1] = *reinterpret_cast<const f16x8*>(Al + mt * kWpTile + ks * 2048 + 1024);
+            }
+        };
+        f16x8 fah[2], fam[2];
+        ldA(0, fr[0]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f16x8 (&f)[2][2] = fr[mt & 1];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                asm volatile("" ::"v"(f[ks][0]));
+                asm volatile("" ::"v"(f[ks][1]));
+            }
+            if (mt + 1 < MT) ldA(mt + 1, fr[(mt + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            split4(c + 1, NXT{}, mt >> 2, (mt & 3) * 2, fah, fam);
+            if ((mt & 3) == 3) store_frag(nxt, mt >> 2, fah[mt >> 2], fam[mt >> 2]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks][1], bh[set][ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks][0], bm[set][ks], acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[ks][0], bh[set][ks], acc[mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // Two steps per trip, no branch between them: the raw B registers are written by requests the compiler cannot see, and a
+    // control-flow merge inside the ring would let it copy them while they are in flight (seen: wrong sums at odd chunk
+    // counts).  An odd slab runs one chunk past its end, whose rows are masked to zero by the split.
+    for (int c = 0; c < nch; c += 2) {
+        step(c, I0{});
+        step(c + 1, I1{});
+    }
+    // requests past the slab's end are still in flight (staging that nobody reads any more)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (!active) return;
+    const float inv = 1.f / (h2sa * h2sb);                       // exact: powers of two
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] *= inv;
+    float* __restrict__ o = a.part + (((long long)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv) * (MT * 16 * 64) + lane;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[(mt * 16 + r) * 64] = acc[mt][r];
+}
+
 // Sum of the partial tiles of k_wgrad_b3w: one thread per output element, the workgroups' tiles of one (problem, mt, r)
 // are 256-byte rows `stride` floats apart.  dW += sum (sole writer of its element).
 __global__ void k_wgrad_b3w_reduce(WGArgs a, int nwg_x) {
@@ -1349,6 +1533,22 @@ int launch_wgrad_b3w(WGArgs& a_io, hipStream_t s) {
     a.part = reinterpret_cast<float*>(exec_scratch(part_bytes + cs_bytes, "the weight-gradient partial tiles"));
     if (!a.part) return WN_EARG;
     a.colsum_part = cs ? a.part + part_bytes / sizeof(float) : nullptr;
+    if (h2 && a.lda == 256 && (long long)a.rows_B_per_b * a.ldb * 4 < (1ll << 31) && !exec_flag(WN_EXEC_NO_PIPELINED_GEMM)) {
+        static bool attr_p = false;
+        if (!attr_p) {
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h2p<WN_ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, kWpLds));
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h2p<WN_ACT_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, kWpLds));
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h2p<WN_ACT_ELU>), hipFuncAttributeMaxDynamicSharedMemorySize, kWpLds));
+            attr_p = true;
+        }
+        if (a.act == WN_ACT_RELU) hipLaunchKernelGGL((k_wgrad_h2p<WN_ACT_RELU>), grid, dim3(512), kWpLds, s, a);
+        else if (a.act == WN_ACT_ELU) hipLaunchKernelGGL((k_wgrad_h2p<WN_ACT_ELU>), grid, dim3(512), kWpLds, s, a);
+        else hipLaunchKernelGGL((k_wgrad_h2p<WN_ACT_NONE>), grid, dim3(512), kWpLds, s, a);
+        WN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_wgrad_b3w_reduce, dim3(128 / 4, a.nprob), dim3(256), 0, s, a, (int)grid.x);
+        WN_LAUNCH_CHECK();
+        return WN_OK;
+    }
 #define W_LAUNCH(B2_, ACT_)                                                                                     \
     do {                                                                                                        \
         if (one) hipLaunchKernelGGL((k_wgrad_b3w<B2_, ACT_, 1>), grid, dim3(512), 2 * 8 * kTileBytes, s, a);     \
