@@ -256,13 +256,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int nst = a.nsrc * spk;
     const int lr = lane >> 3, lp = lane & 7;
 
-    auto issue = [&](int st, int buf) {
-        const int src = st / spk;
-        const int k0 = (st - src * spk) * 64;
-        const bf16* xb = a.X[0] + src * a.x_src_stride + ((long long)b * a.x_rows_per_b) * a.ldx + k0;
+    // Requests as `scalar base + fixed 32-bit lane offset`: the rows and chunk positions a lane copies do not change from
+    // stage to stage, only the uniform k offset (and source) does.  (With a 64-bit pointer per piece computed in vector
+    // registers -- row clamp, multiply, add -- and the builtin's v_readfirstlane + M0 write, issuing the eight requests of a
+    // stage cost a wave several hundred cycles of its 1,024-cycle MFMA budget: the same finding as in k_colgemm_h2q.)
+    unsigned xo[4], wo[4];
+    {
         const int sh = a.x_row0 + r0;
         const int hi = a.x_rows_per_b - 1;
-        const bf16* wb = a.W + (long long)m0 * a.K + st * 64;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int p = w + 8 * i;
@@ -270,8 +271,23 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const int c = lp ^ ((r >> 1) & 7);
             int t = sh + r;
             t = t > hi ? hi : t;
-            W16_DMA16(xb + (long long)t * a.ldx + c * 8, xt(buf) + p * 1024);
-            W16_DMA16(wb + (long long)r * a.K + c * 8, wt(buf) + p * 1024);
+            xo[i] = (unsigned)(((long long)t * a.ldx + c * 8) * 2);
+            wo[i] = (unsigned)(((long long)r * a.K + c * 8) * 2);
+        }
+    }
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds;
+    const char* xbase0 = reinterpret_cast<const char*>(a.X[0] + ((long long)b * a.x_rows_per_b) * a.ldx);
+    const char* wbase0 = reinterpret_cast<const char*>(a.W + (long long)m0 * a.K);
+    auto issue = [&](int st, int buf) {
+        const int src = st / spk;
+        const int k0 = (st - src * spk) * 64;
+        const char* xb = xbase0 + ((long long)src * a.x_src_stride + k0) * 2;
+        const char* wb = wbase0 + (long long)st * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned mx = lds0 + buf * kBTileB + (w + 8 * i) * 1024, mw = mx + 2 * kBTileB;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(xo[i]), "s"(xb), "s"(mx) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(wo[i]), "s"(wb), "s"(mw) : "memory");
         }
     };
 
