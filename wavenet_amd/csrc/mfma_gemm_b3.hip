@@ -895,7 +895,7 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     // stack's layers), or a single source
     long long x_stride = 128;
     bool lean = h2 && mt8 && mode == 0 && (nchunks & 1) == 0 && !exec_flag(WN_EXEC_NO_PIPELINED_GEMM) &&
-                (long long)a.N * (a.ldx ? a.ldx : a.K[0]) * 4 < (1ll << 32);
+                (a.N / a.rows_out_per_b + 1) * (long long)a.rows_src_per_b * (a.ldx ? a.ldx : a.K[0]) * 4 < (1ll << 32);   // 32-bit lane offsets
     if (lean && mode == 0 && a.nsrc > 1) {
         x_stride = (const char*)a.X[1] - (const char*)a.X[0];
         lean = cps == 1;

@@ -382,6 +382,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 }
 
 static int launch_cgemm256(CG16& a, hipStream_t s) {
+    // the kernel's requests carry 32-bit byte offsets from per-stage scalar bases
+    if ((long long)a.x_rows_per_b * a.ldx * 2 >= (1ll << 32) || 256ll * a.K * 2 >= (1ll << 32)) {
+        wn::set_error("w16 cgemm256: a clip of %d rows x %d channels exceeds the 32-bit offsets of its requests", a.x_rows_per_b, a.ldx);
+        return WN_ESHAPE;
+    }
     a.blocks_per_b = (a.rows_per_b + 255) / 256;
     a.n_blocks = a.B * a.blocks_per_b;
     const int grid = a.n_blocks * (a.M / 256);
