@@ -236,7 +236,15 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     barrier = None
-    if world > 1:
+    # WAVENET_BENCH_FORCE_DIST=1 (test hook): run the data-parallel branch -- process group on the real backend, two-graph step
+    # with the all-reduce between the graphs, MAX over ranks, the `dist` record -- in a group of ONE rank, which is how a
+    # one-GPU box executes RCCL itself (tests/test_gpu_dp.py::test_rccl_world_size_one...)
+    force_dist = world == 1 and os.environ.get("WAVENET_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ.get("WAVENET_BENCH_SHARE_GPU") == "1":
@@ -252,8 +260,8 @@ def main():
     net = FasterWaveNet(p, seed=1234)
     net.to_gpu()
     net.update_laerning_rate(0.001)                                     # train_audio/args.py --lr default
-    if world > 1:
-        net.enable_data_parallel()
+    if world > 1 or force_dist:
+        net.enable_data_parallel(always_reduce=force_dist)
     iw = net.input_width
     x, tgt = make_batch(rank, world, iw)
     assert _lib.lib().wn_layer_fast_path(32, 32, 2) == 1
@@ -293,7 +301,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     local_dt = dt
-    if world > 1:
+    if world > 1 or force_dist:
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -320,16 +328,16 @@ def main():
                       "fp32-input MFMA (v_mfma_f32_32x32x2_f32)",
         "config": {"workload": "cfg2 train step: 4 blocks x 10 dilations (1..512), 32 residual / 256 skip ch, "
                                "16 kHz, %d clips x 16384 samples per GPU, loss over last 12290 columns, "
-                               "fwd + bwd + clip + Adam%s" % (B_PER_GPU, " + RCCL all-reduce" if world > 1 else ""),
+                               "fwd + bwd + clip + Adam%s" % (B_PER_GPU, " + RCCL all-reduce" if world > 1 or force_dist else ""),
                    "global_batch": world * B_PER_GPU, "seq_len": T, "parallelism": "dp%d" % world},
         "loss": float(loss.detach()),
         "launch": ("hipGraph replay, one graph launch per step" + (" (fwd+bwd graph, RCCL all-reduce, optimiser graph)"
-                   if world > 1 else "")) if graph is not None else "op-by-op launches from Python",
+                   if world > 1 or force_dist else "")) if graph is not None else "op-by-op launches from Python",
         "eager_ms_per_step": eager_dt * 1e3,
         "entry_point_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
     }
 
-    if rank == 0 and world == 1 and not args.no_exact_fp32 and _lib.get_gemm_precision() != "fp32":
+    if rank == 0 and world == 1 and not force_dist and not args.no_exact_fp32 and _lib.get_gemm_precision() != "fp32":
         # ---- the same step with every contraction on fp32-input MFMA (the reference's own arithmetic): 10 graph replays
         try:
             net.gemm_precision = "fp32"
@@ -344,7 +352,7 @@ def main():
         finally:
             net.gemm_precision = None
             torch.cuda.empty_cache()
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not force_dist:
         # ---- fused residual-stack forward (the north star's roofline target) -------------------
         with torch.no_grad():
             c = net.forward_causal_block(x)
@@ -483,7 +491,7 @@ def main():
             if "ar_generate" in out:
                 out["ar_generate"]["vs_cpu_baseline"] = out["ar_generate"]["samples_per_s"] / \
                     out["cpu_baseline"]["decode_value"]
-    if world > 1:
+    if world > 1 or force_dist:
         # what every rank actually ran, so that a scaling record can be trusted at first sight
         forms = [None] * world
         dist.all_gather_object(forms, {"rank": rank, "device": torch.cuda.current_device(), "launch": out["launch"],
@@ -493,7 +501,7 @@ def main():
                                      % net._grad_arena.numel()}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

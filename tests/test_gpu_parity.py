@@ -816,6 +816,32 @@ def test_pointwise_mfma_fwd_bwd(N, Cin, Cout, act, bias):
         np.testing.assert_allclose(to_np(dbias), g.astype(np.float64).sum(0), atol=1e-3)
 
 
+@pytest.mark.parametrize("prec,tol", [("bf16", 3e-2), ("fp16x2", 1e-4), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("N,Cin,Cout", [(3000, 256, 512), (2100, 512, 768), (2500, 256, 256)])
+def test_head_weight_gradient_with_more_than_256_output_channels_in_every_mode(N, Cin, Cout, prec, tol):
+    """the head's dW with Cout a multiple of 256 ABOVE 256 and Cin >= 256 runs one wide launch per 256
+    output rows; in the one-term modes none of those launches takes the bias column sums, and the call must then leave
+    the bias gradient to the generic sum instead of failing (config 5's [512, 256, ...] head on fp32 storage with
+    gemm precision 'bf16').  Every mode: dW, dbias and dx against float64."""
+    rs = np.random.RandomState(N + Cout)
+    x = rs.standard_normal((N, Cin)).astype(np.float32)
+    W = (rs.standard_normal((Cout, Cin)) / np.sqrt(Cin)).astype(np.float32)
+    g = rs.standard_normal((N, Cout)).astype(np.float32)
+    a64 = np.maximum(x.astype(np.float64), 0)
+    want_dW = g.astype(np.float64).T @ a64
+    want_dx = (g.astype(np.float64) @ W.astype(np.float64)) * (x > 0)
+    lib = _lib.lib()
+    x_, W_, g_ = dev(x), dev(W), dev(g)
+    dx = torch.empty((N, Cin), device="cuda")
+    dW = torch.zeros((Cout, Cin), device="cuda")
+    db = torch.zeros((Cout,), device="cuda")
+    check(lib.wn_pointwise_bwd(ptr(x_), ptr(W_), ptr(g_), ptr(dx), ptr(dW), ptr(db), N, Cin, Cout, _lib.ACT["relu"],
+                               EX(prec), None))
+    np.testing.assert_allclose(to_np(db), g.astype(np.float64).sum(0), atol=1e-3)
+    np.testing.assert_allclose(to_np(dW), want_dW, atol=tol * float(np.abs(want_dW).max()))
+    np.testing.assert_allclose(to_np(dx), want_dx, atol=tol * float(np.abs(want_dx).max()))
+
+
 def _layer_bwd_ref(x, Wf, Wg, Wp, b, Z, d, fw, dout, dzs):
     """float64 autograd through the closed form of one residual layer (+ an explicit dz_skip term)."""
     xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)

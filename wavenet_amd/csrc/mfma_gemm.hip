@@ -420,7 +420,10 @@ int launch_wgrad(WGArgs& a, int M, hipStream_t s) {
             h.colsum_done = 0;
             int rc = launch_wgrad_b3w(h, s);
             if (rc) return rc;
-            if (a.colsum && !h.colsum_done) {
+            // Whether the wide kernel takes the column sums depends on the arithmetic mode only (six-term form: yes; one-term
+            // bf16 / fp16x2: no), so every 256-row slice must answer alike.  "None did" is fine: colsum_done stays 0 and the
+            // caller sums the bias gradient itself.  A mix would leave dbias half written.
+            if (a.colsum && m0 > 0 && h.colsum_done != a.colsum_done) {
                 wn::set_error("wgrad: the column sums were taken for a part of the rows only");
                 return WN_EARG;
             }

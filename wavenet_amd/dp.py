@@ -12,10 +12,13 @@ import torch.distributed as dist
 
 
 class DataParallel(object):
-    def __init__(self, net, group=None):
+    def __init__(self, net, group=None, always_reduce: bool = False):
+        """``always_reduce``: issue the collective even in a group of one rank (a no-op arithmetically: x -> x).  It is how
+        the one GPU of a test box runs the REAL backend -- communicator creation outside graph capture, stream ordering
+        between the two replayed graphs and the collective, tear-down -- when no second GPU exists."""
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
-        self.net, self.group = net, group
+        self.net, self.group, self.always_reduce = net, group, always_reduce
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.broadcast_weights()
@@ -49,7 +52,7 @@ class DataParallel(object):
     def all_reduce_grads(self, flat_grad: torch.Tensor) -> float:
         """Sum the flat gradient buffer over ranks in place; returns the multiplier (1/world) that
         the optimiser kernel applies."""
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=self.group)
         return 1.0 / self.world
 

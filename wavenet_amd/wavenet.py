@@ -999,9 +999,9 @@ class WaveNet(object):
                 self.optimizer.load_state_dict({k: z[k] for k in z.files})
 
     # -- data parallel (new capability) -----------------------------------
-    def enable_data_parallel(self, group=None):
+    def enable_data_parallel(self, group=None, always_reduce: bool = False):
         from .dp import DataParallel
-        self._dp_group = DataParallel(self, group)
+        self._dp_group = DataParallel(self, group, always_reduce=always_reduce)
         return self._dp_group
 
 
