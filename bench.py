@@ -48,6 +48,49 @@ GEMM_MODE_TEXT = {
 }
 
 
+ARITH_SHORT = {
+    "fp32": "f32 x f32 products on v_mfma_f32_32x32x2_f32, f32 accumulate (the reference's arithmetic)",
+    "bf16x3": "f32 operands split into 3 bf16 parts, 6 v_mfma_f32_32x32x16_bf16 per product (<= 3*2^-27 per product: "
+              "fp32-accurate), f32 accumulate; fused layer kernels on f32 MFMA",
+    "fp16x2": "f32 operands scaled by a power of two and split into 2 fp16 parts, 3 v_mfma_f32_32x32x16_f16 per product "
+              "(<= 2^-21 per product), f32 accumulate; head convolutions on bf16x3",
+    "bf16": "operands rounded to bf16 once, f32 accumulate",
+}
+
+
+def newest_profile(pattern):
+    """Newest committed profiles/r<N>_<pattern> file (highest round number), or None."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_" + pattern)):
+        m = re.match(r"r(\d+)_" + re.escape(pattern) + "$", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
+def arith_record(mode):
+    """What multiplies in the timed step, and how far that arithmetic is from the float64 truth next to the exact-fp32
+    mode (measured by tests/test_gpu_arith_error.py on the GPU; its committed output is quoted, not recomputed: the oracle
+    may not run inside the bench's timed legs)."""
+    rec = {"mode": mode, "storage": "f32", "accumulate": "f32", "multiply": ARITH_SHORT[mode],
+           "like_for_like_with_reference": mode == "fp32",
+           "note": "value / ms_per_step are measured in `mode`; ms_per_step_by_mode holds the same captured step in every "
+                   "shipped mode (fp32 = exact fp32 products, the reference's arithmetic)"}
+    f = newest_profile("arith_error_vs_fp64.json")
+    if f:
+        doc = json.load(open(f))
+        m = doc.get("modes", {}).get(mode)
+        if m:
+            rec["error_vs_float64_truth"] = {
+                "source": os.path.relpath(f, ROOT), "workload": doc.get("workload"),
+                "logits_max_abs_err": m["logits_max_abs_err"], "grad_err_largest_over_tensors": m["grad_err_largest_over_tensors"],
+                "ratio_to_exact_fp32_mode": m["vs_fp32_mode"],
+                "exact_fp32_mode": {k: doc["modes"]["fp32"][k] for k in ("logits_max_abs_err", "grad_err_largest_over_tensors")}}
+    return rec
+
+
 def make_batch(rank, world, iw):
     """Synthetic 16 kHz clips -> mu-law tokens; targets are the next sample (train.py:14-22)."""
     wav = data.synthetic_waveform(B_PER_GPU, T + 1, 16000, b0=rank * B_PER_GPU, Btot=world * B_PER_GPU)
@@ -108,7 +151,7 @@ def wide_channel_step(rank, world, steps=10, warmup=3):
            "mfma": {"flop_per_step": flop, "achieved": flop / dt / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                     "frac": flop / dt / 1e12 / 2500.0,
                     "note": "algorithmic flops / step time / dense bf16 peak; the rocprofv3 MFMA-busy counters of the same "
-                            "step are in profiles/ (r2_cfg5_mfma_busy.json)"}}
+                            "step are in %s" % (os.path.relpath(newest_profile("cfg5_mfma_busy.json") or "profiles/", ROOT))}}
     del graph, net
     torch.cuda.empty_cache()
     return res
@@ -322,6 +365,7 @@ def main():
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": spinup,
         "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "arith": arith_record(_lib.get_gemm_precision()),
         "gemm_mode": GEMM_MODE_TEXT[_lib.get_gemm_precision()],
         "dtype_note": "dtype names STORAGE and ACCUMULATION (fp32 tensors in HBM, fp32 MFMA accumulators); what the matrix "
                       "cores multiply is in gemm_mode; exact_fp32_ms_per_step is the same step with every contraction on "
@@ -337,21 +381,31 @@ def main():
         "entry_point_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
     }
 
-    if rank == 0 and world == 1 and not force_dist and not args.no_exact_fp32 and _lib.get_gemm_precision() != "fp32":
-        # ---- the same step with every contraction on fp32-input MFMA (the reference's own arithmetic): 10 graph replays
-        try:
-            net.gemm_precision = "fp32"
-            g32 = TrainStepGraph(net, x, tgt)
-            dt32 = timed(lambda: g32.step(), 10, 3)
-            out["exact_fp32_ms_per_step"] = dt32 * 1e3
-            out["exact_fp32_samples_per_s"] = samples / dt32
-            del g32
-        except Exception as e:
-            out["exact_fp32_ms_per_step"] = None
-            sys.stderr.write("exact-fp32 step failed (%s: %s)\n" % (type(e).__name__, e))
-        finally:
-            net.gemm_precision = None
-            torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not force_dist and not args.no_exact_fp32:
+        # ---- the SAME captured step in every shipped arithmetic mode: 10 graph replays each after 3 warm-up replays.
+        # fp32 = the reference's own arithmetic (exact fp32 products); bf16x3 = fp32-accurate split products on the skip path
+        # and the head, exact fp32 MFMA in the layer kernels; fp16x2 = the default (see `arith`).
+        by_mode = {}
+        default_mode = _lib.get_gemm_precision()
+        for mode in ("fp32", "bf16x3", "fp16x2"):
+            if mode == default_mode and graph is not None:
+                by_mode[mode] = dt * 1e3                                # the timed region above
+                continue
+            try:
+                net.gemm_precision = mode
+                gm = TrainStepGraph(net, x, tgt)
+                by_mode[mode] = timed(lambda: gm.step(), 10, 3) * 1e3
+                del gm
+            except Exception as e:
+                by_mode[mode] = None
+                sys.stderr.write("%s step failed (%s: %s)\n" % (mode, type(e).__name__, e))
+            finally:
+                net.gemm_precision = None
+                torch.cuda.empty_cache()
+        out["ms_per_step_by_mode"] = by_mode
+        out["samples_per_s_by_mode"] = {k: (samples / (v * 1e-3) if v else None) for k, v in by_mode.items()}
+        out["exact_fp32_ms_per_step"] = by_mode.get("fp32")
+        out["exact_fp32_samples_per_s"] = out["samples_per_s_by_mode"].get("fp32")
     if rank == 0 and world == 1 and not force_dist:
         # ---- fused residual-stack forward (the north star's roofline target) -------------------
         with torch.no_grad():
@@ -375,16 +429,14 @@ def main():
             "TFLOPs": nl * alg_flops_layer / (stack_ms * 1e-3) / 1e12,
             "note": "algorithmic bytes = SURVEY 8(d)'s 2,304 B per sample-layer, which include the per-layer skip "
                     "read-modify-write; the deferred skip sum does not move those bytes, so frac_of_hbm_8TBps can exceed 1: "
-                    "layer_traffic_frac is the layer kernel's measured HBM bytes / its time / 8 TB/s",
+                    "layer_traffic_frac = MEASURED HBM bytes of all the stack's layer launches (the launch plan x the PMC bytes "
+                    "per launch of each kernel, layer_traffic_launches) / the time of the bracket around them / 8 TB/s; "
+                    "traffic_frac adds the skip contraction's bytes and time",
         }
         # measured HBM bytes per launch: the newest rocprofv3 PMC summary committed under profiles/ (PMC counters cannot be
         # collected from inside the bench); `traffic_source` says which file, and the file says which commit it measured
-        import glob
         import re
-        tfiles = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json"))
-                         if re.match(r"r\d+_hbm_traffic\.json$", os.path.basename(f))),
-                        key=lambda f: int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)))
-        tfile = tfiles[-1] if tfiles else None
+        tfile = newest_profile("hbm_traffic.json")
         tdoc = json.load(open(tfile)) if tfile else {}
         pmc = tdoc.get("kernels", {})
         traffic_source = {"file": os.path.relpath(tfile, ROOT), "measured_at_commit": tdoc.get("commit"),
@@ -400,11 +452,41 @@ def main():
                     k = max(hits)[1]
                     return k, float(pmc[k]["hbm_bytes_per_launch"])
             return None, None
-        fk, fb = pmc_find([r"wn::k_layer_fwd_h2\w*<0\b", r"wn::k_layer_fwd_mfma32_t1<0\b"])
+
+        def layer_fwd_traffic(save):
+            """Measured HBM bytes of the stack's layer launches (inference form save=0, training form save=2): the launch
+            plan of wn_stack_fwd (consecutive layers whose dilations add up to <= 32 share ONE grouped launch, at most 8
+            layers: mfma_layer_fwd_group_len; every other layer is one launch) x the PMC bytes per launch of the kernel
+            each launch runs.  Returns (bytes, [(kernel, launches, bytes per launch)]) or (None, None)."""
+            dil = [lay.dilation for lay in net._flat_layers]
+            plan, l = [], 0
+            while l < len(dil):
+                n, tot = 0, 0
+                while l + n < len(dil) and n < 8 and tot + dil[l + n] <= 32:
+                    tot += dil[l + n]
+                    n += 1
+                plan.append(n if n >= 2 else 1)
+                l += plan[-1]
+            parts, total = [], 0.0
+            for kind, pat in (("grp", r"wn::k_layer_fwd_h2_grp<%d\b" % save), ("one", r"wn::k_layer_fwd_h2_t1<%d\b" % save)):
+                cnt = sum(1 for n in plan if (n >= 2) == (kind == "grp"))
+                if not cnt:
+                    continue
+                k, b = pmc_find([pat])
+                if b is None:
+                    return None, None
+                parts.append({"kernel": k, "launches": cnt, "bytes_per_launch": b})
+                total += cnt * b
+            return total, parts
+        fb, fparts = layer_fwd_traffic(0)
         if fb:
-            out["stack_forward"]["layer_traffic_kernel"] = fk
             out["stack_forward"]["layer_traffic_bytes"] = fb
-            out["stack_forward"]["layer_traffic_frac"] = fb / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["stack_forward"]["layer_traffic_launches"] = fparts
+            out["stack_forward"]["layer_traffic_frac"] = fb / (layer_ms * nl * 1e-3) / 1e9 / HBM_PEAK_GBS
+            sk, sb = pmc_find([r"wn::k_colgemm_h2q<0, 0", r"wn::k_colgemm_b3<0, 0,"])
+            if sb:
+                out["stack_forward"]["traffic_bytes"] = fb + sb
+                out["stack_forward"]["traffic_frac"] = (fb + sb) / (stack_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         # ---- roofline of the dominant unit of the TIMED REGION (the training step) -------------------
         # Units = the library's per-op entry points; times are HIP-event means over the timed steps.
         # Algorithmic bytes / flops are SURVEY.md section 8(d)'s per-sample-layer figures x the
@@ -431,19 +513,25 @@ def main():
         # matrix peak of the fused layer kernels: fp32 MFMA, or three f16 MFMAs per product under fp16x2
         layer_peak = 2500.0 / 3.0 if _lib.get_gemm_precision() == "fp16x2" else F32_MFMA_PEAK_TF
         if bound == "hbm":
-            ach = amount / (launch_ms * 1e-3) / 1e9
+            alg = amount / (launch_ms * 1e-3) / 1e9
+            # primary figure: MEASURED HBM bytes per launch (the PMC passes committed under profiles/) / launch time; the
+            # SURVEY 8(d) algorithmic figure is kept beside it (it charges a per-layer dskip read this design never does)
+            ach = (traffic / (launch_ms * 1e-3) / 1e9) if traffic else alg
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_kernel": traffic_kernel,
+                               "frac": ach / HBM_PEAK_GBS, "basis": "measured HBM bytes (PMC)" if traffic else "SURVEY 8(d) algorithmic bytes",
+                               "traffic": traffic, "traffic_kernel": traffic_kernel,
                                "traffic_source": traffic_source, "launch_ms": launch_ms,
-                               "algorithmic_bytes_per_launch": amount,
                                "traffic_frac": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                               "survey_8d": {"algorithmic_bytes_per_launch": amount, "achieved": alg, "frac": alg / HBM_PEAK_GBS},
+                               "algorithmic_bytes_per_launch": amount,
                                "mfma_frac": layer_flops.get(dom, 0) / (launch_ms * 1e-3) / 1e12 / layer_peak,
                                "mfma_peak_TFLOPs": layer_peak,
-                               "note": "frac: SURVEY 8(d)'s algorithmic bytes (1,664 B per sample-layer for the backward, "
-                                       "1,024 B of them the per-layer dskip read that the deferred skip sum never "
-                                       "performs) / launch time / 8 TB/s; traffic_frac: HBM bytes MEASURED by the PMC "
-                                       "passes in profiles/ / launch time / 8 TB/s; mfma_frac: fp32-equivalent flops of the "
-                                       "launch / time / mfma_peak_TFLOPs (157.3 fp32 MFMA; 833 = 2.5 PF / 3 with fp16x2 split products)"}
+                               "note": "frac = achieved / peak with achieved = HBM bytes MEASURED by the PMC passes in profiles/ "
+                                       "(FETCH_SIZE x 2 + WRITE_SIZE, per launch) / launch time; survey_8d: SURVEY 8(d)'s "
+                                       "algorithmic bytes (1,664 B per sample-layer for the backward, 1,024 B of them the "
+                                       "per-layer dskip read that the deferred skip sum never performs) / launch time; "
+                                       "mfma_frac: fp32-equivalent flops of the launch / time / mfma_peak_TFLOPs (157.3 fp32 "
+                                       "MFMA; 833 = 2.5 PF / 3 with fp16x2 split products)"}
         else:
             ach = amount / (launch_ms * 1e-3) / 1e12
             peak = {"fp32": F32_MFMA_PEAK_TF, "fp16x2": 2500.0 / 3.0}.get(_lib.get_gemm_precision(), BF16X3_PEAK_TF)

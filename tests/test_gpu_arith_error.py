@@ -1,0 +1,129 @@
+"""How far is each shipped arithmetic mode from the TRUTH?  
+
+The reference multiplies in float32 (wavenet.py:212,225,358-368).  The default mode of this build (`fp16x2`) multiplies on
+the f16 matrix cores with two-part split operands; `bf16x3` uses three bf16 parts (product error 3 * 2^-27: below fp32's own
+rounding); `fp32` is v_mfma_f32_32x32x2_f32.  This test measures all three against the oracle evaluated in FLOAT64 on
+the 4 x 10 stack bench.py times (B = 2, T = input_width + 200; several seeds), for the logits, the loss and EVERY gradient
+tensor (max-norm error relative to the tensor's largest entry), and requires that fp16x2 is as close to the truth as the
+exact-fp32 mode is: the distance of all three modes from the truth is set by what they share -- fp32 storage of every
+activation, fp32 accumulation, the device's exp / rcp -- not by the 2^-21 of a split product.
+
+The per-tensor maximum is a noisy statistic (a maximum over a few thousand rounding errors); `bf16x3`, whose products are
+more accurate than fp32's own rounding, is measured beside fp16x2 as the yardstick for that noise: its per-tensor ratios to
+the fp32 mode spread as far as fp16x2's do.  Bars: logits and loss <= 1.25 x the fp32 mode's error; over all gradient
+tensors the median ratio <= 1.05, the 90th percentile <= 1.25, the POOLED error (largest relative error of any tensor)
+<= 1.25 x, the RMS error of every tensor <= 1.25 x, and no single tensor's maximum beyond 1.25 x the larger of the two
+fp32-accurate modes' (fp32, bf16x3) + 10 % of the median error.  The numbers are written to gpurun_out/ and committed
+as profiles/r4_arith_error_vs_fp64.json, which bench.py quotes in its line."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wavenet_ref as R
+
+from gpu_util import CFG2, build, dev, to_np
+
+pytestmark = pytest.mark.gpu
+MODES = ("fp32", "bf16x3", "fp16x2")
+
+
+def measure(seeds=(17, 18, 19), B=2, extra=200):
+    p, w, net = build(CFG2)
+    iw = R.input_width(p)
+    T = iw + extra
+    per_seed = []
+    for seed in seeds:
+        rs = np.random.RandomState(seed)
+        idx = rs.randint(0, 256, (B, T)).astype(np.int32)
+        tgt = rs.randint(0, 256, (B, extra)).astype(np.int32)
+        keep = {}
+        loss64, logits64, g64 = R.train_step_grads(p, w, idx, tgt, dtype=torch.float64, keep=keep)
+        mask64 = keep["skip"] > 0
+        x, t = dev(idx), dev(tgt)
+        res = {}
+        for prec in MODES:
+            net.gemm_precision = prec
+            c = net.forward_causal_block(x)
+            _, s = net.forward_residual_block(c, t_off=T - extra)
+            # same ReLU mask as the truth, or the comparison measures a discontinuity (tests/test_gpu_baseline_configs.py)
+            flips = int(((to_np(s) > 0) != mask64).sum())
+            logits = net.forward_softmax_block(s, apply_softmax=False)
+            loss = net.cross_entropy(logits, t)
+            net.zero_grads()
+            loss.backward()
+            torch.cuda.synchronize()
+            gmax, grms = {}, {}
+            for ln, kind, off, n, shape in net._spans:
+                k = "%s/%s" % (ln.name, kind)
+                want = g64[k].astype(np.float64)
+                if not np.abs(want).max() > 0:
+                    continue                                         # the last layer's projection: exactly 0
+                d = to_np(net._grad_arena[off:off + n].view(shape)).astype(np.float64) - want
+                gmax[k] = float(np.abs(d).max() / np.abs(want).max())
+                grms[k] = float(np.sqrt((d * d).mean()) / np.abs(want).max())
+            res[prec] = {"mask_flips": flips, "skip": float(np.abs(to_np(s) - keep["skip"]).max()),
+                         "logits": float(np.abs(to_np(logits).astype(np.float64) - logits64).max()),
+                         "logits_rms": float(np.sqrt(((to_np(logits).astype(np.float64) - logits64) ** 2).mean())),
+                         "loss": abs(float(loss) - float(loss64)), "grad_max": gmax, "grad_rms": grms}
+        per_seed.append(res)
+    net.gemm_precision = None
+    # pool the seeds: a tensor's error = its largest error over the seeds (RMS: root of the mean square)
+    pooled = {}
+    for prec in MODES:
+        keys = per_seed[0][prec]["grad_max"].keys()
+        pooled[prec] = {
+            "mask_flips": max(r[prec]["mask_flips"] for r in per_seed),
+            "skip": max(r[prec]["skip"] for r in per_seed), "logits": max(r[prec]["logits"] for r in per_seed),
+            "logits_rms": float(np.sqrt(np.mean([r[prec]["logits_rms"] ** 2 for r in per_seed]))),
+            "loss": max(r[prec]["loss"] for r in per_seed),
+            "grad_max": {k: max(r[prec]["grad_max"][k] for r in per_seed) for k in keys},
+            "grad_rms": {k: float(np.sqrt(np.mean([r[prec]["grad_rms"][k] ** 2 for r in per_seed]))) for k in keys}}
+    return pooled, dict(B=B, T=T, extra=extra, seeds=list(seeds))
+
+
+def summarize(pooled, shape):
+    out = {"workload": "cfg2 topology (4 x 10 layers, 32 / 256 channels), B = %(B)d, T = %(T)d, loss over the last %(extra)d "
+                       "columns, seeds %(seeds)s pooled; truth = oracle/wavenet_ref.py in float64" % shape,
+           "error_definition": "max-norm error of a tensor / largest entry of the true tensor; logits and loss absolute",
+           "modes": {}}
+    f32 = pooled["fp32"]
+    for prec in MODES:
+        m = pooled[prec]
+        gm = np.array(list(m["grad_max"].values()))
+        rat = np.array([m["grad_max"][k] / f32["grad_max"][k] for k in f32["grad_max"]])
+        rrat = np.array([m["grad_rms"][k] / f32["grad_rms"][k] for k in f32["grad_rms"]])
+        out["modes"][prec] = {
+            "logits_max_abs_err": m["logits"], "logits_rms_err": m["logits_rms"], "loss_abs_err": m["loss"],
+            "skip_sum_max_abs_err": m["skip"], "relu_mask_flips": m["mask_flips"],
+            "grad_err_largest_over_tensors": float(gm.max()), "grad_err_median_over_tensors": float(np.median(gm)),
+            "vs_fp32_mode": {"logits": m["logits"] / f32["logits"], "logits_rms": m["logits_rms"] / f32["logits_rms"],
+                             "pooled_grad": float(gm.max() / max(f32["grad_max"].values())),
+                             "grad_ratio_median": float(np.median(rat)), "grad_ratio_p90": float(np.percentile(rat, 90)),
+                             "grad_ratio_max": float(rat.max()), "grad_rms_ratio_max": float(rrat.max()),
+                             "grad_rms_ratio_median": float(np.median(rrat))}}
+    return out
+
+
+def test_fp16x2_is_as_close_to_the_float64_truth_as_the_exact_fp32_mode():
+    pooled, shape = measure()
+    out = summarize(pooled, shape)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "arith_error_vs_fp64.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    f32, b3, h2 = pooled["fp32"], pooled["bf16x3"], pooled["fp16x2"]
+    for prec in MODES:
+        assert pooled[prec]["mask_flips"] == 0, (prec, "a skip value changed sign: pick other seeds")
+        assert pooled[prec]["logits"] < 1e-4 and max(pooled[prec]["grad_max"].values()) < 1e-4      # the north-star bars
+    for prec in ("bf16x3", "fp16x2"):
+        v = out["modes"][prec]["vs_fp32_mode"]
+        assert v["logits"] <= 1.25 and v["logits_rms"] <= 1.25, (prec, v)
+        assert pooled[prec]["loss"] <= 1.25 * f32["loss"] + 1e-7, (prec, pooled[prec]["loss"], f32["loss"])
+        assert v["pooled_grad"] <= 1.25 and v["grad_ratio_median"] <= 1.05 and v["grad_ratio_p90"] <= 1.25, (prec, v)
+        assert v["grad_rms_ratio_max"] <= 1.25, (prec, v)
+    med = float(np.median(list(f32["grad_max"].values())))
+    for k, e in h2["grad_max"].items():
+        assert e <= 1.25 * max(f32["grad_max"][k], b3["grad_max"][k]) + 0.1 * med, (k, e, f32["grad_max"][k], b3["grad_max"][k])
