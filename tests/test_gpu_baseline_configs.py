@@ -178,39 +178,3 @@ def test_bench_two_ranks_on_one_gpu_runs_the_n_gt_1_branch():
         assert "fwd+bwd graph" in rk["launch"], rk
     assert np.isfinite(out["loss"]) and out["value"] > 0
     assert out["config"]["global_batch"] == 16 and out["scaling"] == "weak"
-
-
-@pytest.mark.parametrize("B,extra,window_only", [(2, 200, False), (1, 333, True), (2, 12290, False), (8, 12290, False)])
-def test_multi_layer_backward_launch_equals_the_per_layer_launches_bit_for_bit(B, extra, window_only):
-    """k_layer_bwd_chain_multi: every layer below the top one of the 4 x 10 stack in ONE launch of co-resident workgroups
-    with a grid barrier between layers (the next layer's weights, z, sigmoid, dz_skip and x requested before the barrier).
-    Same tile code, same per-layer partial tiles, same fixed-order sums: every gradient must equal the per-layer launches'
-    (WN_EXEC_NO_MULTI_LAYER_BWD) BIT FOR BIT -- small and ragged windows (idle waves, live ranges that differ per layer),
-    the bench's window at B = 2, and the bench's full batch (256 workgroups, one per CU).  Three repetitions: a missed
-    dependency between layers would show as a difference that comes and goes."""
-    from wavenet_amd import _lib
-    net = WaveNet(Params(R.make_params(**CFG2)), seed=1234)
-    net.to_gpu()
-    iw = net.input_width
-    T = iw + extra
-    rs = np.random.RandomState(B * 1000 + extra)
-    x = dev(rs.randint(0, 256, (B, T)).astype(np.int32))
-    tgt = dev(rs.randint(0, 256, (B, extra)).astype(np.int32))
-    base = _lib.default_exec_flags() & ~_lib.WN_EXEC_NO_MULTI_LAYER_BWD
-    got = {}
-    for name, flags, reps in (("per-layer", base | _lib.WN_EXEC_NO_MULTI_LAYER_BWD, 1), ("multi", base, 3)):
-        net.exec_flags = flags
-        for rep in range(reps):
-            c = net.forward_causal_block(x)
-            _, s = net.forward_residual_block(c, t_off=iw, window_only=window_only)
-            loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt)
-            net.zero_grads()
-            loss.backward()
-            torch.cuda.synchronize()
-            got[(name, rep)] = to_np(net._grad_arena).copy()
-            del c, s, loss
-    ref = got[("per-layer", 0)]
-    assert np.isfinite(ref).all() and np.abs(ref).max() > 0
-    for rep in range(3):
-        bad = np.flatnonzero(ref != got[("multi", rep)])
-        assert bad.size == 0, (rep, bad.size, bad[:8], ref[bad[:8]], got[("multi", rep)][bad[:8]])

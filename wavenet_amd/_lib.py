@@ -195,7 +195,6 @@ def stream_ptr() -> Optional[int]:
 
 GEMM_PRECISIONS = ("fp32", "bf16x3", "bf16", "fp16x2")
 WN_EXEC_FORCE_GENERIC, WN_EXEC_NO_FUSED_WIDE, WN_EXEC_NO_FWD_GROUPS, WN_EXEC_NO_PIPELINED_GEMM = 1, 2, 4, 8
-WN_EXEC_NO_MULTI_LAYER_BWD = 16
 
 
 def default_exec_flags() -> int:
@@ -211,8 +210,6 @@ def default_exec_flags() -> int:
         f |= WN_EXEC_NO_FWD_GROUPS
     if os.environ.get("WAVENET_HIP_NO_PIPELINED_GEMM") == "1":
         f |= WN_EXEC_NO_PIPELINED_GEMM
-    if os.environ.get("WAVENET_HIP_NO_MULTI_LAYER_BWD") == "1":
-        f |= WN_EXEC_NO_MULTI_LAYER_BWD
     return f
 
 
