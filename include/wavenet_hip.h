@@ -71,7 +71,7 @@ const char* wn_last_error(void);
  * WAVENET_HIP_FORCE_GENERIC / _NO_FUSED_WIDE / _FWD_T1_MIN_BLOCKS inside the .so are per-call fields here):
  *   WN_EXEC_FORCE_GENERIC   every kernel of the call from the any-shape correctness path (generic_kernels.hip), fp32
  *   WN_EXEC_NO_FUSED_WIDE   the 128/128-channel bf16-operand layer forward as two launches instead of one (diagnostic)
- *   WN_EXEC_NO_FWD_GROUPS, WN_EXEC_NO_PIPELINED_GEMM   see the defines
+ *   WN_EXEC_NO_FWD_GROUPS, WN_EXEC_NO_PIPELINED_GEMM, WN_EXEC_NO_MULTI_LAYER_BWD   see the defines
  * fwd_t1_min_blocks: launch size (workgroups of four 32-column tiles) from which the fused 32-channel layer forward takes its
  * one-tile-per-wave form; 0 = the library's default (512: every CU gets two to four workgroups), n > 0 = n (1 = always:
  * parity tests of that kernel at small sizes), < 0 = never.
@@ -84,6 +84,8 @@ enum { WN_GEMM_FP32 = 0, WN_GEMM_BF16X3 = 1, WN_GEMM_BF16 = 2, WN_GEMM_FP16X2 = 
                                       bit for bit -- A/B timing and the parity tests of the per-layer kernel */
 #define WN_EXEC_NO_PIPELINED_GEMM 8u /* fp16x2 skip contractions: the older kernels (k_colgemm_b3, k_wgrad_b3w) instead of
                                         k_colgemm_h2q / k_wgrad_h2p; same results, bit for bit -- A/B timing, parity tests */
+#define WN_EXEC_NO_MULTI_LAYER_BWD 16u /* fp16x2 chained stack backward: one launch per layer instead of the multi-layer launch
+                                          with grid barriers (k_layer_bwd_chain_multi); same results, bit for bit */
 typedef struct WnExec {
     int precision;
     unsigned flags;

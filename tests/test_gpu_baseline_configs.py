@@ -178,3 +178,46 @@ def test_bench_two_ranks_on_one_gpu_runs_the_n_gt_1_branch():
         assert "fwd+bwd graph" in rk["launch"], rk
     assert np.isfinite(out["loss"]) and out["value"] > 0
     assert out["config"]["global_batch"] == 16 and out["scaling"] == "weak"
+
+
+@pytest.mark.parametrize("B,extra,window_only", [(2, 200, False), (1, 333, True), (3, 1333, False), (2, 12290, False), (8, 12290, False)])
+def test_multi_layer_backward_launch_equals_the_per_layer_launches(B, extra, window_only):
+    """k_layer_bwd_chain_multi: every layer below the top one of the 4 x 10 stack in ONE launch of co-resident workgroups,
+    synchronised per tile through dataflow words (no grid barrier), the deal of tiles to waves rotated from layer to layer.
+    Same tile code and the same per-tile arithmetic as the per-layer launches (WN_EXEC_NO_MULTI_LAYER_BWD); what differs is
+    which wave sums which tiles' weight-gradient contributions, i.e. fp32 summation order: every gradient tensor within 1e-6
+    of its largest entry (measured 1-2e-7) -- a missed dependency between layers reads a stale or half-written (V, U) tile
+    and is O(1e-2) -- and the multi-layer launch is BIT-reproducible: three repetitions agree exactly (its schedule is
+    static; only the waiting is dynamic).  Small and ragged windows (idle waves, live ranges that differ per layer, a
+    batch that is no multiple of 8: the non-XCD deal), the bench's window at B = 2, and the bench's full batch (256
+    workgroups, one per CU)."""
+    from wavenet_amd import _lib
+    net = WaveNet(Params(R.make_params(**CFG2)), seed=1234)
+    net.to_gpu()
+    iw = net.input_width
+    T = iw + extra
+    rs = np.random.RandomState(B * 1000 + extra)
+    x = dev(rs.randint(0, 256, (B, T)).astype(np.int32))
+    tgt = dev(rs.randint(0, 256, (B, extra)).astype(np.int32))
+    base = _lib.default_exec_flags() & ~_lib.WN_EXEC_NO_MULTI_LAYER_BWD
+    got = {}
+    for name, flags, reps in (("per-layer", base | _lib.WN_EXEC_NO_MULTI_LAYER_BWD, 1), ("multi", base, 3)):
+        net.exec_flags = flags
+        for rep in range(reps):
+            c = net.forward_causal_block(x)
+            _, s = net.forward_residual_block(c, t_off=iw, window_only=window_only)
+            loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt)
+            net.zero_grads()
+            loss.backward()
+            torch.cuda.synchronize()
+            got[(name, rep)] = to_np(net._grad_arena).copy()
+            del c, s, loss
+    ref = got[("per-layer", 0)]
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 0
+    for rep in (1, 2):
+        np.testing.assert_array_equal(got[("multi", 0)], got[("multi", rep)])
+    m = got[("multi", 0)]
+    for ln, kind, off, n, shape in net._spans:
+        a, b = ref[off:off + n], m[off:off + n]
+        scale = max(float(np.abs(a).max()), 1e-30)
+        assert float(np.abs(a - b).max()) <= 1e-6 * scale, (ln.name, kind, float(np.abs(a - b).max()), scale)

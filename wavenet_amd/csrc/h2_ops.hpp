@@ -62,4 +62,30 @@ __device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory");
 }
 
+#if defined(WN_SC_MODE) && WN_SC_MODE == 3
+#define WN_SC_BITS "sc0 sc1"
+#define WN_SC_AUX 17
+#else
+#define WN_SC_BITS "sc1"
+#define WN_SC_AUX 16
+#endif
+// The same request with the sc1 bit: coherent at agent scope (the line is fetched from memory, not from a possibly stale copy
+// in this XCD's L2).  For data another XCD wrote earlier in the SAME launch with st16_sc1.
+__device__ __forceinline__ void lds_dma16_sc1(const void* src, void* lds_dst) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off " WN_SC_BITS ::"v"(src), "s"(m0v) : "memory");
+}
+// One dword per lane into LDS (lane L's word at lds_dst + 4 L), sc1: a way to request words whose VALUE is needed later
+// without giving the compiler a register to wait for -- the kernel's own counted s_waitcnt covers the request.
+__device__ __forceinline__ void lds_dma4_sc1(const void* src, void* lds_dst) {
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc1" ::"v"(src), "s"(m0v) : "memory");
+}
+// 16-byte store written through to memory at agent scope (sc1): visible to every XCD once the wave's vmcnt has counted it.
+typedef float h2_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st16_sc1(float* dst, float a, float b, float c, float d) {
+    const h2_f32x4 v = {a, b, c, d};
+    asm volatile("global_store_dwordx4 %0, %1, off " WN_SC_BITS ::"v"(dst), "v"(v) : "memory");
+}
+
 }  // namespace wn

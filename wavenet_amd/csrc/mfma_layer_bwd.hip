@@ -188,11 +188,13 @@ __device__ unsigned long long g_bwd_stamps[1024 * 8];
 #endif
 static constexpr int kCWaveFloats = 8192;                       // two groups of four 4 KB slots per wave
 static constexpr int kCWFloats = 2048 + 2048 + 1024;            // Wf, Wg, Wp
-static constexpr int kCLdsBytes = (kCWFloats + kCWaves * kCWaveFloats) * 4;
+static constexpr int kCLdsBytes = (kCWFloats + kCWaves * kCWaveFloats + kCWaves * 64) * 4;   // + 256 B per wave: dataflow words (MULTI)
 static constexpr int kCMaxBlocks = 256;
 
 #define WN_LDS_DMA16(src, dst) \
     __builtin_amdgcn_global_load_lds((src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+#define WN_LDS_DMA16_SC1(src, dst) \
+    __builtin_amdgcn_global_load_lds((src), (__attribute__((address_space(3))) void*)(dst), 16, 0, WN_SC_AUX)
 
 // ---- fp16 x 2 split products for the weight-gradient contractions (H2W) ------------------------------------------------
 // The 80 fp32 MFMAs per tile that contract over time (dWf, dWg: [da; dg] x [x[t-d]; x[t]], dWp: dout x z) are half of the
@@ -242,15 +244,66 @@ __device__ __forceinline__ void lb_h2_product(const H2Op& a, const H2Op& b, floa
 // Tile order: workgroups are dealt to the 8 XCDs round-robin, so XCD k = blockIdx % 8 gets the k-th contiguous eighth
 // of the tiles (x[t-d] and U[t+dU] of a tile are rows a neighbouring CU of the same XCD fetches in the same round).
 // ---------------------------------------------------------------------------------------------
+// ---- several layers in ONE launch (MULTI) ------------------------------------------------------------------------------
+// A launch gives a wave four tiles: the weight images, the first tile's fetch burst (every workgroup of the grid at once),
+// the half-empty pipeline of the first and last tile and the partial-tile reduction are a third of it.  The multi-layer
+// form keeps the tile code and walks the layers of a stack (entries 0, 1, ... = stack layers layer[0] > layer[1] > ...)
+// inside one launch of co-resident workgroups (one per CU: the LDS footprint guarantees it).
+//
+// Synchronisation is DATAFLOW, per tile, not a grid barrier.  (A grid barrier was built first and measured: counter in
+// device memory, one arrival per workgroup and layer.  With agent-scope fences around it -- buffer_wbl2 / buffer_inv sc1,
+// 32 per XCD and layer -- the layer backward went 1.35 -> 2.03 ms; without cache maintenance, (V, U) travelling with the
+// sc1 bit instead, 1.35 -> 1.51 ms = +4 us per layer, while the same launch with every barrier open ran 0.17 ms FASTER
+// than the per-layer launches: a barrier costs ~9 us per layer, mostly waiting for the slowest of 256 workgroups before
+// any workgroup may request the next layer's (V, U).)  Every tile of the gradient stream has a word in device memory
+// holding the number of entries it has completed.  Entry e's tile X (rows 32 X ..) may
+//   * READ  V[X] and U[X + dU/32 (+1)] of entry e - 1 once those tiles have completed e - 1, i.e. show >= e, and
+//   * WRITE its own V, U -- into the buffer entry e - 1 read (two buffers, ping-pong) -- once the READERS of those rows
+//     in entry e - 1, tiles X and X - dU'/32 (-1), show >= e as well,
+// so one test, "five words >= e", covers both; tiles the previous entry did not process (below its live range, outside the
+// clip) impose nothing.  A wave publishes a tile (one sc1 store of e + 1) when the tile's stores have been counted by
+// vmcnt -- at the top of the next loop body, whose wait already guarantees it -- and requests the words of the tile it
+// will fetch NEXT one body ahead, so that the test costs no memory round trip.  Waits only ever point at earlier
+// entries, so there is no cycle; in steady state nothing waits at all (the words a tile needs were written two bodies
+// ago by waves that walk the same tile sequence).  (V, U) are stored and loaded with the sc1 bit (written through to
+// memory / fetched from memory: st16_sc1, lds_dma16_sc1, aux = 16 of the builtin): the only data that crosses XCDs
+// inside the launch.  Everything of the NEXT layer that the forward pass wrote -- weights, z, sigmoid, dz_skip, x of the
+// first tile -- is requested at the layer boundary before the finished layer's partial tile is reduced.  The partial
+// weight-gradient tiles leave per layer exactly as in the per-layer form (same sums, same order: results are
+// bit-identical when both forms use the same grid).
+static constexpr int kChainMaxL = 48;
+struct ChainArgs {
+    const float* Wf[kChainMaxL]; const float* Wg[kChainMaxL]; const float* Wp[kChainMaxL];     // per entry of the launch
+    int d[kChainMaxL], Z[kChainMaxL], tile_lo[kChainMaxL], vu_t0[kChainMaxL], dU[kChainMaxL], rot[kChainMaxL];
+    int layer[kChainMaxL];             // stack index of entry i (descending): selects x, z, sigmoid, dz, the V/U parity, the partial tiles
+    const float* x0;                   // input of stack layer 0
+    const float* xs;                   // (L, B, T, 32): layer l's input is xs[l - 1]
+    const float* z; const float* g;    // (L, B, T, 32)
+    const float* dz;                   // (L, B, T, 32); rows below dz_t0 are not read
+    float* V[3]; float* U[3];          // three pairs in rotation: layer l reads [(l + 1) % 3], writes [l % 3]
+    float* part; long long part_stride;
+    unsigned* sync;                    // [0]: set if a wait gave up (results void), [1]: always "done", [2 + b * tiles_all + X]: entries
+                                       // tile X of clip b has completed; all zeroed by k_chain_zero_sync before the launch
+    int n, B, T, dz_t0;
+};
+static constexpr int kChainSyncHead = 2;
+#ifdef WN_MULTI_STAMPS
+__device__ unsigned long long g_multi_stamps[kChainMaxL + 1][256][4];     // [entry][workgroup][wave]: s_memtime when the wave finished the entry's tiles
+__device__ unsigned long long g_multi_spins[kChainMaxL + 1][256][4];      // cycles spent inside dep_wait (<< 20) | number of reloads
+__device__ unsigned long long g_multi_seg[256][4][8];                     // cycles per segment of the layer boundary, summed over entries
+#define MST(v) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory"); } while (0)
+#endif
+
 // FROM_Z: the forward saved z and sigmoid only; `f` points at z and tanh is recovered as z / sigmoid (z = tanh * sigmoid was
 // rounded once in fp32, so the quotient is tanh to ~1.2e-7 relative; where sigmoid underflowed, da and dg are 0 anyway).
-template <bool HAS_DO, bool HAS_U, bool HAS_DZ, bool FROM_Z, bool H2W>
-__global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
+template <bool HAS_DO, bool HAS_U, bool HAS_DZ, bool FROM_Z, bool H2W, bool MULTI>
+__device__ __forceinline__ void chain_body(
     const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
     const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
     const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, int vu_t0,
     const float* __restrict__ dzs, int dz_t0, float* __restrict__ Vout, float* __restrict__ Uout,
-    float* __restrict__ part, int B, int T, int d, int Z, int tile_lo, int tiles_per_b, int ntiles) {
+    float* __restrict__ part, int B, int T, int d, int Z, int tile_lo, int tiles_per_b, int ntiles,
+    const ChainArgs* __restrict__ ma) {
     // tiles_per_b counts the LIVE tiles of a clip: tile k of the grid is tile tile_lo + k % tiles_per_b of clip
     // k / tiles_per_b.  Columns below 32 * tile_lo cannot receive gradient (they are further from the loss window than
     // the layers above reach): they are not computed, and Vin / Uin rows below vu_t0 (which the layer above did not
@@ -271,23 +324,167 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     constexpr bool PL = H2W;
     // two slot groups per wave (software pipeline)
     float* pbase = wbase + wv * kCWaveFloats;   // group k: pbase + 4096 k = {f | dout, g | z, V | da, U | dg}
+    // Tile order.  A wave walks ids first, first + stride, ... < last; id -> (clip b, tile X of the clip) is
+    //     b = cb0 + id % nb,   X = tiles_all - 1 - id / nb
+    // i.e. clips interleaved, time running BACKWARDS from the end of the clip.  The live tiles of a layer (X >= tile_lo) are
+    // then the ids below nb * tiles_per_b whatever tile_lo is: a tile belongs to the same wave in every layer (MULTI: what a
+    // tile waits for was finished by waves walking the same sequence, two or more loop bodies earlier), and the tiles a
+    // tile's U rows come from (larger X) precede it.  With the workgroups dealt to the 8 XCDs round-robin (blockIdx % 8)
+    // and B a multiple of 8, XCD k owns clips k B/8 .. (nb = B/8): x[t - d] and U[t + dU] of a tile are rows a neighbouring
+    // CU of the same XCD fetches in the same round.  Otherwise nb = B and the ids are dealt to all waves in turn.
+    const int tiles_all = (T + 31) / 32;
     int first, stride, last;
-    if ((gridDim.x & 7) == 0) {
-        const int per_xcd = (ntiles + 7) >> 3;
-        const int xcd = blockIdx.x & 7;
+    int nb, cb0;
+    if ((gridDim.x & 7) == 0 && (B & 7) == 0) {
+        nb = B >> 3;
+        cb0 = (blockIdx.x & 7) * nb;
         stride = (gridDim.x >> 3) * NW;
-        first = xcd * per_xcd + (blockIdx.x >> 3) * NW + wv;
-        last = (xcd + 1) * per_xcd < ntiles ? (xcd + 1) * per_xcd : ntiles;
+        first = (blockIdx.x >> 3) * NW + wv;
     } else {
+        nb = B;
+        cb0 = 0;
         stride = gridDim.x * NW;
         first = blockIdx.x * NW + wv;
-        last = ntiles;
     }
+    auto decode = [&](int id, int& b, int& t0) {
+        const int r = id / nb;
+        b = cb0 + (id - r * nb);
+        t0 = (tiles_all - 1 - r) * 32;
+    };
+    // MULTI: the ids are dealt to the waves ROTATED by rot[entry].  A layer's live tiles are rarely a whole number per wave
+    // (config 2: 385 .. 512 live tiles per clip on 128 waves = 3 or 4 each): with a fixed deal the same waves would carry the
+    // extra tile in every layer and everybody else would wait for them at the next wide dependency; the host advances
+    // rot by each entry's surplus, so the extra tiles walk around the waves and every wave does the AVERAGE number of
+    // tiles over the launch -- which the dataflow synchronisation (no barrier) lets it turn into time.
+    const int first0 = first;
+    int li = 0;                        // MULTI: the current entry of the launch's table
+    auto partition = [&]() {
+        last = nb * tiles_per_b;
+        if constexpr (MULTI) {
+            first = first0 - ma->rot[li];
+            if (first < 0) first += stride;
+        }
+    };
+    // MULTI: entry i of the launch's table becomes the current layer (uniform: scalar loads from the kernel arguments)
+    int dUp = 0, lo_p = 0;             // dU and first live tile of the entry TWO back: its tiles read the rows of the (V, U) pair
+                                       // the current entry rewrites (three pairs in rotation)
+    auto set_layer = [&](int i) {
+        const int l = ma->layer[i];
+        dUp = i > 1 ? ma->dU[i - 2] : 0;
+        lo_p = i > 1 ? ma->tile_lo[i - 2] : 0;
+        const long long lo = (long long)l * B * T * 32;
+        x = l == 0 ? ma->x0 : ma->xs + (lo - (long long)B * T * 32);
+        f = ma->z + lo;
+        g = ma->g + lo;
+        dzs = ma->dz + lo;
+        Wp = ma->Wp[i]; Wf = ma->Wf[i]; Wg = ma->Wg[i];
+        Vin = ma->V[(l + 1) % 3]; Uin = ma->U[(l + 1) % 3];
+        Vout = ma->V[l % 3]; Uout = ma->U[l % 3];
+        part = ma->part + (long long)l * ma->part_stride;
+        dU = ma->dU[i]; vu_t0 = ma->vu_t0[i]; d = ma->d[i]; Z = ma->Z[i];
+        tile_lo = ma->tile_lo[i];
+        tiles_per_b = (T + 31) / 32 - tile_lo;
+        ntiles = B * tiles_per_b;
+    };
+    if constexpr (MULTI) set_layer(0);
+    partition();
     const int lr = lane >> 3, lp = lane & 7;
+    // ---- MULTI: the per-tile dataflow words (see "several layers in ONE launch" above)
+    bool gave_up = false;
+    // request the five words tile `tile` of the current entry depends on (lanes 0..4; every other lane, and every word that
+    // imposes nothing, reads as "done"); the value is tested later by dep_wait
+    auto dep_ptr = [&](int tile) -> const unsigned* {
+        const unsigned* ptr = ma->sync + 1;                           // the word that always reads "done"
+        if (li > 0) {
+            int b, t0;
+            decode(tile, b, t0);
+            const int X = t0 >> 5;                                 // tile index inside the clip
+            const int k = dU >> 5, kp = dUp >> 5;
+            int q = -1, lo = vu_t0 >> 5;                           // lo: first tile the previous entry processed
+            if (lane == 0) q = X;                                  // V[X]
+            else if (lane == 1) q = X + k;                         // U rows 32 X + dU ..
+            else if (lane == 2) q = (dU & 31) ? X + k + 1 : -1;
+            else if (lane == 3 && li > 1) { q = X - kp; lo = lo_p; }                          // who read U rows 32 X .. of the pair this
+            else if (lane == 4 && li > 1) { q = (dUp & 31) ? X - kp - 1 : -1; lo = lo_p; }    // tile rewrites, two entries back
+            if (q >= lo && q < tiles_all) ptr = ma->sync + kChainSyncHead + b * tiles_all + q;
+        }
+        return ptr;
+    };
+    // lanes 0..2 must show the previous entry done (>= li), lanes 3, 4 the entry before it (>= li - 1)
+    const unsigned dep_slack = (lane == 3 || lane == 4) ? 1u : 0u;
+    auto dep_request = [&](int tile) -> unsigned {
+        unsigned v = 0xffffffffu;
+        if constexpr (MULTI) {
+            if (li > 0) v = __hip_atomic_load(dep_ptr(tile), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return v;
+    };
+    // the same request through LDS (lds_dma4_sc1): for the tile loop, where a register destination would make hipcc wait for
+    // every vector-memory operation issued since -- the eight (V, U) stores the loop deliberately leaves in flight included.
+    // The loop's own s_waitcnt vmcnt(8) at the top of the next body covers the request; dep_take reads the words then.
+    unsigned* const dep_lds = reinterpret_cast<unsigned*>(wbase + kCWaves * kCWaveFloats) + wv * 64;
+    auto dep_request_lds = [&](int tile) {
+        if constexpr (MULTI) lds_dma4_sc1(dep_ptr(tile), dep_lds);
+    };
+    auto dep_take = [&]() -> unsigned {
+        unsigned v = 0xffffffffu;
+        if constexpr (MULTI) v = dep_lds[lane];
+        return v;
+    };
+#ifdef WN_MULTI_STAMPS
+    unsigned long long dbg_spin = 0;
+#endif
+    auto dep_wait = [&](int tile, unsigned v) {
+        if constexpr (MULTI) {
+            unsigned spins = 0;
+#ifdef WN_MULTI_STAMPS
+            unsigned long long w0; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w0) :: "memory");
+#endif
+            while (!gave_up && __builtin_amdgcn_ballot_w64(v < (unsigned)li - dep_slack) != 0ull) {   // a word still shows an earlier entry
+                __builtin_amdgcn_s_sleep(1);
+                v = dep_request(tile);
+                if (++spins > (1u << 18)) {          // never hang the GPU: give up for good, flag it, the results are void
+                    gave_up = true;
+                    if (lane == 0) __hip_atomic_store(ma->sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#ifdef WN_MULTI_STAMPS
+            if (spins) { unsigned long long w1; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w1) :: "memory");
+                         dbg_spin += ((w1 - w0) << 20) | spins; }
+#endif
+        }
+    };
+    auto publish = [&](int tile) {
+        if constexpr (MULTI) {
+            int b, t0;
+            decode(tile, b, t0);
+            const int X = t0 >> 5;
+            if (lane == 0)
+                __hip_atomic_store(ma->sync + kChainSyncHead + b * tiles_all + X, (unsigned)(li + 1), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    unsigned dep_1 = 0xffffffffu;                             // requested words of the entry's second tile
+    int pub = 0;                                              // next tile of this wave to publish
 
-    auto fetch_a = [&](int tile, float* grp, float4 (&dz4)[4]) {
-        const int b = tile / tiles_per_b;
-        const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
+    // which: 1 = z (or tanh), sigmoid and dz_skip; 2 = V, U; 3 = everything.  ASM: the LDS-DMA as inline asm (h2_ops.hpp): hipcc
+    // then puts no vmcnt(0) in front of later LDS reads, so the requests stay in flight across the layer boundary's LDS
+    // work -- the caller waits for them itself
+    auto fetch_some = [&](int tile, float* grp, float4 (&dz4)[4], const int which, const bool use_asm) {
+        int b, t0;
+        decode(tile, b, t0);
+        auto dma = [&](const float* src, float* dst) {
+            if (use_asm) lds_dma16(src, dst);
+            else WN_LDS_DMA16(src, dst);
+        };
+        auto dma_vu = [&](const float* src, float* dst) {       // MULTI: (V, U) were written by other XCDs in this launch
+            if constexpr (MULTI) {
+                if (use_asm) lds_dma16_sc1(src, dst);
+                else WN_LDS_DMA16_SC1(src, dst);
+            } else {
+                dma(src, dst);
+            }
+        };
         if (t0 + 32 + (HAS_U ? dU : 0) <= T) {
             // interior tile (wave-uniform test): one base address per tensor, the four pieces are 1 KB apart
             const long long o = ((long long)b * T + t0 + lr) * 32 + ((lp ^ lr) << 2);
@@ -297,10 +494,12 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
             const float* pu = Uin + o + (long long)dU * 32;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                WN_LDS_DMA16(pf + k * 256, grp + k * 256);
-                WN_LDS_DMA16(pg + k * 256, grp + 1024 + k * 256);
-                if (HAS_DO) WN_LDS_DMA16(pv + k * 256, grp + 2048 + k * 256);
-                if (HAS_U) WN_LDS_DMA16(pu + k * 256, grp + 3072 + k * 256);
+                if (which & 1) {
+                    dma(pf + k * 256, grp + k * 256);
+                    dma(pg + k * 256, grp + 1024 + k * 256);
+                }
+                if ((which & 2) && HAS_DO) dma_vu(pv + k * 256, grp + 2048 + k * 256);
+                if ((which & 2) && HAS_U) dma_vu(pu + k * 256, grp + 3072 + k * 256);
             }
         } else {
 #pragma unroll
@@ -310,13 +509,15 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
                 const int ttc = tt < T ? tt : T - 1;
                 const int ttu = ttc + dU < T ? ttc + dU : T - 1;
                 const long long o = ((long long)b * T + ttc) * 32 + ((lp ^ (r & 7)) << 2);
-                WN_LDS_DMA16(f + o, grp + k * 256);
-                WN_LDS_DMA16(g + o, grp + 1024 + k * 256);
-                if (HAS_DO) WN_LDS_DMA16(Vin + o, grp + 2048 + k * 256);
-                if (HAS_U) WN_LDS_DMA16(Uin + ((long long)b * T + ttu) * 32 + ((lp ^ (r & 7)) << 2), grp + 3072 + k * 256);
+                if (which & 1) {
+                    dma(f + o, grp + k * 256);
+                    dma(g + o, grp + 1024 + k * 256);
+                }
+                if ((which & 2) && HAS_DO) dma_vu(Vin + o, grp + 2048 + k * 256);
+                if ((which & 2) && HAS_U) dma_vu(Uin + ((long long)b * T + ttu) * 32 + ((lp ^ (r & 7)) << 2), grp + 3072 + k * 256);
             }
         }
-        if (HAS_DZ) {
+        if (HAS_DZ && (which & 1)) {
             // dz_skip exists for columns t >= dz_t0 only (the loss window): tiles below it load nothing, the tile
             // that straddles dz_t0 selects (the memory below dz_t0 is uninitialised)
             if (t0 + 32 > dz_t0) {
@@ -338,9 +539,10 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
             }
         }
     };
+    auto fetch_a = [&](int tile, float* grp, float4 (&dz4)[4]) { fetch_some(tile, grp, dz4, 3, false); };
     auto fetch_x = [&](int tile, float (&xc)[16], float (&xo)[16]) {
-        const int b = tile / tiles_per_b;
-        const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
+        int b, t0;
+        decode(tile, b, t0);
         if (t0 - d >= 0 && t0 + 32 <= T) {               // interior tile: rows 2s+h are 256 B apart from one base
             if constexpr (PL) {                          // rows 16 (s >> 3) + 8 h + (s & 7): the k order of the tr reads
                 const float* pc = x + ((long long)b * T + t0 + 8 * h) * 32 + j;
@@ -383,8 +585,8 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
         float* tg = grp + 1024;
         float* tv = grp + 2048;
         float* tu = grp + 3072;
-        const int b = tile / tiles_per_b;
-        const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
+        int b, t0;
+        decode(tile, b, t0);
         const int t = t0 + j;
         const bool valid = t < T;
         const bool vin = t >= vu_t0;                                  // select, never multiply: unwritten rows may hold anything
@@ -563,16 +765,20 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     // returns true when the tile is complete and the eight stores were issued unconditionally (they can then be left in
     // flight across the next s_waitcnt vmcnt)
     auto store_vu = [&](int tile) -> bool {
-        const int b = tile / tiles_per_b;
-        const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
+        int b, t0;
+        decode(tile, b, t0);
         const bool full = t0 + 32 <= T;
+        auto st = [&](float* p, const float* v) {
+            if constexpr (MULTI) st16_sc1(p, v[0], v[1], v[2], v[3]);     // read by other XCDs within this launch
+            else *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        };
         if (full) {
             float* pv = Vout + ((long long)b * T + t0 + lr) * 32 + ((lp ^ lr) << 2);
             float* pu = Uout + ((long long)b * T + t0 + lr) * 32 + ((lp ^ lr) << 2);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                *reinterpret_cast<float4*>(pv + k * 256) = make_float4(vv[4 * k], vv[4 * k + 1], vv[4 * k + 2], vv[4 * k + 3]);
-                *reinterpret_cast<float4*>(pu + k * 256) = make_float4(uu[4 * k], uu[4 * k + 1], uu[4 * k + 2], uu[4 * k + 3]);
+                st(pv + k * 256, vv + 4 * k);
+                st(pu + k * 256, uu + 4 * k);
             }
         } else {
 #pragma unroll
@@ -580,8 +786,8 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
                 const int r = 8 * k + lr;
                 if (t0 + r < T) {
                     const long long o = ((long long)b * T + t0 + r) * 32 + ((lp ^ (r & 7)) << 2);
-                    *reinterpret_cast<float4*>(Vout + o) = make_float4(vv[4 * k], vv[4 * k + 1], vv[4 * k + 2], vv[4 * k + 3]);
-                    *reinterpret_cast<float4*>(Uout + o) = make_float4(uu[4 * k], uu[4 * k + 1], uu[4 * k + 2], uu[4 * k + 3]);
+                    st(Vout + o, vv + 4 * k);
+                    st(Uout + o, uu + 4 * k);
                 }
             }
         }
@@ -589,8 +795,8 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     };
     struct WOps { float a_da[16], a_dg[16], a_do[16], b_z[16], b_xc[16], b_xo[16]; };
     auto take = [&](int tile, const float* grp, const float (&xc)[16], const float (&xo)[16], WOps& w) {
-        const int b = tile / tiles_per_b;
-        const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
+        int b, t0;
+        decode(tile, b, t0);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int r = 2 * s + h;
@@ -631,8 +837,8 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     };
     // x[t], x[t-d] of the tile (rows in tr order), masked, split with the wave's own scale; then the five products
     auto wgrad_t = [&](int tile, const WOpsT& w, const float (&xc)[16], const float (&xo)[16]) {
-        const int b = tile / tiles_per_b;
-        const int t0 = (tile_lo + tile - b * tiles_per_b) * 32;
+        int b, t0;
+        decode(tile, b, t0);
         float bxc[16], bxo[16];
         float mx = 0.f;
 #pragma unroll
@@ -700,84 +906,105 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     constexpr int kThreads = 64 * NW;
     constexpr int NK = 512 / kThreads;                  // float4 pieces of Wf (and of Wg) per thread
     float4 s_wf[NK], s_wg[NK];
+    float4 s_wp;
+    auto load_weights = [&]() {
 #pragma unroll
-    for (int k = 0; k < NK; ++k) {
-        s_wf[k] = reinterpret_cast<const float4*>(Wf)[threadIdx.x + k * kThreads];
-        s_wg[k] = reinterpret_cast<const float4*>(Wg)[threadIdx.x + k * kThreads];
-    }
-    const float4 s_wp = reinterpret_cast<const float4*>(Wp)[threadIdx.x & 255];
+        for (int k = 0; k < NK; ++k) {
+            s_wf[k] = reinterpret_cast<const float4*>(Wf)[threadIdx.x + k * kThreads];
+            s_wg[k] = reinterpret_cast<const float4*>(Wg)[threadIdx.x + k * kThreads];
+        }
+        s_wp = reinterpret_cast<const float4*>(Wp)[threadIdx.x & 255];
+    };
     float4 dza[4], dzb[4];
     float xc[16], xo[16];
-    const bool any = first < last;
+    bool any = first < last;
     bool stores_in_flight = false;                     // the last eight vector-memory operations are unconditional V/U stores
+    // The layer's weight images from the registers load_weights() filled.  H2W: `between` runs after the weight loads have
+    // been waited for and before the LDS-only barrier of the maximum exchange -- what it requests travels under the split.
+    auto build_images = [&](auto&& between) {
+        if constexpr (H2W) {
+            // fp16 x 2 images of the three weight matrices in A-operand order: 1 KB per (matrix, tap, k-step, part), lane
+            // (j, h) element e = W[cd = bch(8 ks + e, h)][cr = j][tap] (Wp: [cr = bch(..)][cd = j]) scaled by one power of two
+            // taken from the largest weight of the layer (every workgroup sees all of them: 20 values per thread)
+            float mw = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wf[k].x), fabsf(s_wf[k].y)), fmaxf(fabsf(s_wf[k].z), fabsf(s_wf[k].w))));
+                mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wg[k].x), fabsf(s_wg[k].y)), fmaxf(fabsf(s_wg[k].z), fabsf(s_wg[k].w))));
+            }
+            mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wp.x), fabsf(s_wp.y)), fmaxf(fabsf(s_wp.z), fabsf(s_wp.w))));
+            mw = lb_wave_max(mw);
+            float* red = wbase + kCWaves * kCWaveFloats - 8;   // last 32 bytes of the slot area: free until tile data lands there
+            if (lane == 0) red[wv] = mw;
+            // the first tile's fetch goes out only now, behind the weight loads (which the maximum above has waited for), and
+            // the exchange of the four maxima uses an LDS-only barrier: splitting and scattering the images (~2 k cycles) runs
+            // under the fetch's HBM round trip instead of behind it (a __syncthreads() here would drain it)
+            between();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            mw = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            float sw;
+            lb_pow2_scale(mw, sw, w_inv);
+            char* img = reinterpret_cast<char*>(dyn);
+            auto put = [&](int mat_tap, int kidx, int jj, float v) {      // kidx: the contraction channel, jj: the output row
+                const int hh = (kidx >> 2) & 1, ks = kidx >> 4, e = (kidx & 3) + 4 * ((kidx >> 3) & 1);
+                const float xs = v * sw;
+                const _Float16 hv = (_Float16)xs;
+                const _Float16 mv = (_Float16)(xs - (float)hv);
+                char* dst = img + ((mat_tap * 2 + ks) * 2) * 1024 + (hh * 32 + jj) * 16 + e * 2;
+                *reinterpret_cast<_Float16*>(dst) = hv;
+                *reinterpret_cast<_Float16*>(dst + 1024) = mv;
+            };
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const int e0 = (threadIdx.x + k * kThreads) * 4;        // flat index into W[cd][cr][tap]
+                const int cd = e0 >> 6, cr = (e0 >> 1) & 31;
+                put(0, cd, cr, s_wf[k].x); put(1, cd, cr, s_wf[k].y); put(0, cd, cr + 1, s_wf[k].z); put(1, cd, cr + 1, s_wf[k].w);
+                put(2, cd, cr, s_wg[k].x); put(3, cd, cr, s_wg[k].y); put(2, cd, cr + 1, s_wg[k].z); put(3, cd, cr + 1, s_wg[k].w);
+            }
+            if (threadIdx.x < 256) {
+                const int e0 = threadIdx.x * 4;                           // flat index into Wp[cr][cd]
+                const int cr = e0 >> 5, cd = e0 & 31;
+                put(4, cr, cd, s_wp.x); put(4, cr, cd + 1, s_wp.y); put(4, cr, cd + 2, s_wp.z); put(4, cr, cd + 3, s_wp.w);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                reinterpret_cast<float4*>(lWf)[threadIdx.x + k * kThreads] = s_wf[k];
+                reinterpret_cast<float4*>(lWg)[threadIdx.x + k * kThreads] = s_wg[k];
+            }
+            if (threadIdx.x < 256) reinterpret_cast<float4*>(lWp)[threadIdx.x] = s_wp;
+        }
+    };
+    load_weights();
     if (!H2W && any) { fetch_a(first, pbase, dza); fetch_x(first, xc, xo); }
-    if constexpr (H2W) {
-        // fp16 x 2 images of the three weight matrices in A-operand order: 1 KB per (matrix, tap, k-step, part), lane
-        // (j, h) element e = W[cd = bch(8 ks + e, h)][cr = j][tap] (Wp: [cr = bch(..)][cd = j]) scaled by one power of two
-        // taken from the largest weight of the layer (every workgroup sees all of them: 20 values per thread)
-        float mw = 0.f;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wf[k].x), fabsf(s_wf[k].y)), fmaxf(fabsf(s_wf[k].z), fabsf(s_wf[k].w))));
-            mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wg[k].x), fabsf(s_wg[k].y)), fmaxf(fabsf(s_wg[k].z), fabsf(s_wg[k].w))));
-        }
-        mw = fmaxf(mw, fmaxf(fmaxf(fabsf(s_wp.x), fabsf(s_wp.y)), fmaxf(fabsf(s_wp.z), fabsf(s_wp.w))));
-        mw = lb_wave_max(mw);
-        float* red = wbase + kCWaves * kCWaveFloats - 8;   // last 32 bytes of the slot area: free until tile data lands there
-        if (lane == 0) red[wv] = mw;
-        // the first tile's fetch goes out only now, behind the weight loads (which the maximum above has waited for), and
-        // the exchange of the four maxima uses an LDS-only barrier: splitting and scattering the images (~2 k cycles) runs
-        // under the fetch's HBM round trip instead of behind it (a __syncthreads() here would drain it)
-        if (any) { fetch_a(first, pbase, dza); fetch_x(first, xc, xo); }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        mw = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        float sw;
-        lb_pow2_scale(mw, sw, w_inv);
-        char* img = reinterpret_cast<char*>(dyn);
-        auto put = [&](int mat_tap, int kidx, int jj, float v) {      // kidx: the contraction channel, jj: the output row
-            const int hh = (kidx >> 2) & 1, ks = kidx >> 4, e = (kidx & 3) + 4 * ((kidx >> 3) & 1);
-            const float xs = v * sw;
-            const _Float16 hv = (_Float16)xs;
-            const _Float16 mv = (_Float16)(xs - (float)hv);
-            char* dst = img + ((mat_tap * 2 + ks) * 2) * 1024 + (hh * 32 + jj) * 16 + e * 2;
-            *reinterpret_cast<_Float16*>(dst) = hv;
-            *reinterpret_cast<_Float16*>(dst + 1024) = mv;
-        };
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const int e0 = (threadIdx.x + k * kThreads) * 4;        // flat index into W[cd][cr][tap]
-            const int cd = e0 >> 6, cr = (e0 >> 1) & 31;
-            put(0, cd, cr, s_wf[k].x); put(1, cd, cr, s_wf[k].y); put(0, cd, cr + 1, s_wf[k].z); put(1, cd, cr + 1, s_wf[k].w);
-            put(2, cd, cr, s_wg[k].x); put(3, cd, cr, s_wg[k].y); put(2, cd, cr + 1, s_wg[k].z); put(3, cd, cr + 1, s_wg[k].w);
-        }
-        if (threadIdx.x < 256) {
-            const int e0 = threadIdx.x * 4;                           // flat index into Wp[cr][cd]
-            const int cr = e0 >> 5, cd = e0 & 31;
-            put(4, cr, cd, s_wp.x); put(4, cr, cd + 1, s_wp.y); put(4, cr, cd + 2, s_wp.z); put(4, cr, cd + 3, s_wp.w);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            reinterpret_cast<float4*>(lWf)[threadIdx.x + k * kThreads] = s_wf[k];
-            reinterpret_cast<float4*>(lWg)[threadIdx.x + k * kThreads] = s_wg[k];
-        }
-        if (threadIdx.x < 256) reinterpret_cast<float4*>(lWp)[threadIdx.x] = s_wp;
-    }
+    build_images([&]() { if (any) { fetch_a(first, pbase, dza); fetch_x(first, xc, xo); } });
     __syncthreads();                                   // (also drains vmcnt: the first tile has landed)
 #ifdef WN_BWD_STAMPS
     unsigned long long st_wait = 0, st_take = 0, st_body = 0, st_n = 0, st_t0 = 0, st_t1 = 0;
     BST(st_k1);
 #endif
+    int tile = first;
+    int it = 0;
+#ifdef WN_MULTI_STAMPS
+    if constexpr (MULTI) { unsigned long long tt; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
+          if (lane == 0 && blockIdx.x < 256) g_multi_stamps[0][blockIdx.x][wv] = tt; }
+#endif
+    for (;;) {                                         // MULTI: one pass per layer of the launch
     if (any) {
-        if (first + stride < last) fetch_a(first + stride, pbase + 4096, dzb);
+        if (first + stride < last) {
+            dep_wait(first + stride, dep_1);
+            fetch_a(first + stride, pbase + 4096, dzb);
+        }
+        if (MULTI && first + 2 * stride < last) dep_request_lds(first + 2 * stride);
         phase_a(first, pbase, dza);
         stores_in_flight = store_vu(first);
     }
+    pub = first;
     // Loop over the tiles that have a successor (one basic block: no branch between the MFMAs of the two tiles, and the
     // accumulators flow through a single path -- an if/else around the weight-gradient MFMAs made the compiler copy all
     // 80 accumulator registers every iteration); the last tile's weight gradients follow the loop.
-    int it = 0;
-    int tile = first;
+    it = 0;
+    tile = first;
 #ifdef WN_BWD_STAMPS
     BST(st_t0);
 #endif
@@ -792,6 +1019,9 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
 #endif
         if (stores_in_flight) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (MULTI) {                             // the stores of the tile before `tile` have been counted
+            if (pub < tile) { publish(pub); pub += stride; }
+        }
 #ifdef WN_BWD_STAMPS
         BST(c1);
 #endif
@@ -813,7 +1043,11 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
 #pragma unroll
         for (int q = 0; q < 4; ++q) dza[q] = dzb[q];
         fetch_x(tile + stride, xc, xo);
-        if (tile + 2 * stride < last) fetch_a(tile + 2 * stride, grp, dzb);
+        if (tile + 2 * stride < last) {
+            dep_wait(tile + 2 * stride, dep_take());
+            fetch_a(tile + 2 * stride, grp, dzb);
+        }
+        if (MULTI && tile + 3 * stride < last) dep_request_lds(tile + 3 * stride);
         // one basic block: 80 weight-gradient MFMAs of `tile` and the first half of the next tile
         if constexpr (PL) wgrad_t(tile, wt, xcw, xow);
         else wgrad(w);
@@ -830,6 +1064,9 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
     if (any) {
         if (stores_in_flight) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (MULTI) {                             // the last tile but one: before the last weight-gradient products, not after
+            if (pub < tile) { publish(pub); pub += stride; }
+        }
         if constexpr (PL) {
             WOpsT wt;
             take_t(pbase + (it & 1) * 4096, wt);
@@ -840,6 +1077,90 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
             take(tile, pbase + (it & 1) * 4096, xc, xo, w);
             wgrad(w);
         }
+    }
+    if constexpr (!MULTI) {
+        break;
+    } else {
+        if (li + 1 >= ma->n) break;
+        // ---- layer boundary (workgroup-local: no grid barrier).  (1) this layer's V / U stores have been counted: its last
+        // tiles are published; (2) everything of the next layer that the forward pass wrote is requested: weights, and of its
+        // first tile z, sigmoid (LDS-DMA as inline asm into group 0's first two slots), dz_skip and x (registers), together
+        // with the dataflow words of its first two tiles; (3) the finished layer's accumulators -> this wave's own region of
+        // LDS (the V / U slots of group 0 and group 1: dead), one LDS-only barrier, fixed-order sum, partial tile; (4) the next
+        // layer's weight images; (5) the first tile's V, U as soon as its words allow.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef WN_MULTI_STAMPS
+        { unsigned long long tt; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt) :: "memory");
+          if (lane == 0 && blockIdx.x < 256) { g_multi_stamps[li + 1][blockIdx.x][wv] = tt; g_multi_spins[li][blockIdx.x][wv] = dbg_spin; }
+          dbg_spin = 0; }
+#endif
+        if (any) {
+            while (pub <= tile) { publish(pub); pub += stride; }
+        }
+#ifdef WN_MULTI_STAMPS
+        unsigned long long sg0, sg1, sg2, sg3, sg4, sg5; MST(sg0);
+#endif
+        float* const part_done = part;
+        ++li;
+        set_layer(li);
+        partition();
+        any = first < last;
+        load_weights();
+        unsigned dep_0 = 0xffffffffu;
+        dep_1 = 0xffffffffu;
+        if (any) {
+            dep_0 = dep_request(first);
+            if (first + stride < last) dep_1 = dep_request(first + stride);
+            fetch_some(first, pbase, dza, 1, true);
+            fetch_x(first, xc, xo);
+        }
+        {
+            float* red = pbase + 2048;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                red[(0 * 16 + r) * 64 + lane] = aWf0[r]; red[(1 * 16 + r) * 64 + lane] = aWf1[r];
+                red[(2 * 16 + r) * 64 + lane] = aWg0[r]; red[(3 * 16 + r) * 64 + lane] = aWg1[r];
+                red[(4 * 16 + r) * 64 + lane] = aWp[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { aWf0[r] = 0.f; aWf1[r] = 0.f; aWg0[r] = 0.f; aWg1[r] = 0.f; aWp[r] = 0.f; }
+        }
+#ifdef WN_MULTI_STAMPS
+        MST(sg1);
+#endif
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            float* __restrict__ o = part_done + (long long)blockIdx.x * kPartFloats;
+            const float* rb = wbase + 2048;
+#pragma unroll
+            for (int i = 0; i < kPartFloats / (64 * NW); ++i) {
+                const int e = threadIdx.x + i * 64 * NW;
+                o[e] = (rb[e] + rb[kCWaveFloats + e]) + (rb[2 * kCWaveFloats + e] + rb[3 * kCWaveFloats + e]);
+            }
+        }
+#ifdef WN_MULTI_STAMPS
+        MST(sg2);
+#endif
+        build_images([]() {});
+#ifdef WN_MULTI_STAMPS
+        MST(sg3);
+#endif
+        if (any) {
+            dep_wait(first, dep_0);
+            fetch_some(first, pbase, dza, 2, true);
+        }
+#ifdef WN_MULTI_STAMPS
+        MST(sg4);
+#endif
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // images published, first tile landed
+#ifdef WN_MULTI_STAMPS
+        MST(sg5);
+        if (lane == 0 && blockIdx.x < 256) {
+            unsigned long long* q = g_multi_seg[blockIdx.x][wv];
+            q[0] += sg1 - sg0; q[1] += sg2 - sg1; q[2] += sg3 - sg2; q[3] += sg4 - sg3; q[4] += sg5 - sg4; q[5] += 1;
+        }
+#endif
+    }
     }
 #ifdef WN_BWD_STAMPS
     BST(st_k2);
@@ -875,6 +1196,24 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
             o[e] = (wbase[e] + wbase[kPartFloats + e]) + (wbase[2 * kPartFloats + e] + wbase[3 * kPartFloats + e]);
         }
     }
+}
+
+template <bool HAS_DO, bool HAS_U, bool HAS_DZ, bool FROM_Z, bool H2W>
+__global__ __launch_bounds__(256, 1) void k_layer_bwd_chainsp(
+    const float* __restrict__ x, const float* __restrict__ f, const float* __restrict__ g,
+    const float* __restrict__ Wp, const float* __restrict__ Wf, const float* __restrict__ Wg,
+    const float* __restrict__ Vin, const float* __restrict__ Uin, int dU, int vu_t0,
+    const float* __restrict__ dzs, int dz_t0, float* __restrict__ Vout, float* __restrict__ Uout,
+    float* __restrict__ part, int B, int T, int d, int Z, int tile_lo, int tiles_per_b, int ntiles) {
+    chain_body<HAS_DO, HAS_U, HAS_DZ, FROM_Z, H2W, false>(x, f, g, Wp, Wf, Wg, Vin, Uin, dU, vu_t0, dzs, dz_t0, Vout, Uout, part,
+                                                          B, T, d, Z, tile_lo, tiles_per_b, ntiles, nullptr);
+}
+
+// Layers a.layer[0] > a.layer[1] > ... of a stack in one launch (see MULTI above); every layer has V, U and dz_skip inputs.
+template <bool FROM_Z, bool H2W>
+__global__ __launch_bounds__(256, 1) void k_layer_bwd_chain_multi(const ChainArgs a) {
+    chain_body<true, true, true, FROM_Z, H2W, true>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0,
+                                                    nullptr, a.dz_t0, nullptr, nullptr, nullptr, a.B, a.T, 1, 0, 0, 1, 1, &a);
 }
 
 // dx[t] = V[t] + U[t + dU]   (the split gradient of the stack input, materialised once at the bottom)
@@ -1103,6 +1442,81 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
     return WN_OK;
 }
 
+// Entries 0 .. n-1 (stack layers layer[0] > layer[1] > ...) in ONE launch of co-resident workgroups with a grid barrier
+// between layers (k_layer_bwd_chain_multi).  Only the fp16 x 2 form reading z and sigmoid (FROM_Z), every layer with V, U
+// and dz_skip inputs.  `sync` points at mfma_chain_multi_sync_words(B, T) words of device memory (zeroed here).  *nwg receives the number of partial tiles
+// every layer writes (= the grid).
+__global__ void k_chain_zero_sync(unsigned* sync, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) sync[i] = i == 1 ? 0xffffffffu : 0u;
+}
+size_t mfma_chain_multi_sync_words(int B, int T) { return (size_t)kChainSyncHead + (size_t)B * ((T + 31) / 32); }
+int mfma_chain_multi_max_layers() { return kChainMaxL; }
+int mfma_layer_bwd_chain_multi(int n, const int* layer, const float* const* Wf, const float* const* Wg,
+                               const float* const* Wp, const int* d, const int* Z, const int* t_live, const int* vu_t0,
+                               const int* dU, const float* x0, const float* xs, const float* z, const float* g,
+                               const float* dz, float* const* V, float* const* U, float* part, size_t part_stride,
+                               unsigned* sync, int B, int T, int dz_t0, int* nwg, hipStream_t s) {
+    WN_CHECK_ARG(n >= 1 && n <= kChainMaxL, "mfma_layer_bwd_chain_multi: 1..%d layers", kChainMaxL);
+    WN_CHECK_ARG(gemm_mode() == WN_GEMM_FP16X2, "mfma_layer_bwd_chain_multi: fp16x2 only");
+    const int tiles_all = (T + 31) / 32;
+    ChainArgs a{};
+    int blocks = 1;
+    for (int i = 0; i < n; ++i) {
+        a.Wf[i] = Wf[i]; a.Wg[i] = Wg[i]; a.Wp[i] = Wp[i];
+        a.d[i] = d[i]; a.Z[i] = Z[i]; a.vu_t0[i] = vu_t0[i]; a.dU[i] = dU[i]; a.layer[i] = layer[i];
+        a.tile_lo[i] = t_live[i] > 0 ? t_live[i] / 32 : 0;
+        const long long nt = (long long)B * (tiles_all - a.tile_lo[i]);
+        WN_CHECK_SHAPE(nt < (1ll << 31), "mfma_layer_bwd_chain_multi: too many tiles");
+        WN_CHECK_ARG(nt > 0, "mfma_layer_bwd_chain_multi: no live column");
+        const int bl = (int)((nt + kCWaves - 1) / kCWaves);
+        if (bl > blocks) blocks = bl;
+    }
+    if (blocks > kCMaxBlocks) blocks = kCMaxBlocks;
+    // every workgroup must be RESIDENT (they wait for each other's tiles): one per CU by LDS footprint, so no more workgroups
+    // than the device has CUs.  (The waits are bounded -- a tile that never comes is given up after ~0.3 s and flagged in
+    // sync[0] -- so a violated assumption costs time and the result, never the GPU.)
+    {
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            WN_HIP(hipGetDevice(&dev));
+            WN_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        if (blocks > n_cu) { wn::set_error("mfma_layer_bwd_chain_multi: %d workgroups on %d CUs", blocks, n_cu); return WN_ESHAPE; }
+    }
+    {   // the rotation of the deal (see `partition` in chain_body): entry i + 1 starts where entry i's surplus tiles ended
+        const bool xcd = (blocks & 7) == 0 && (B & 7) == 0;
+        const int nbx = xcd ? B >> 3 : B;
+        const int stride = (xcd ? blocks >> 3 : blocks) * kCWaves;
+        int rot = 0;
+        for (int i = 0; i < n; ++i) {
+            a.rot[i] = rot;
+            rot = (int)((rot + (long long)nbx * (tiles_all - a.tile_lo[i])) % stride);
+        }
+    }
+    a.x0 = x0; a.xs = xs; a.z = z; a.g = g; a.dz = dz;
+    for (int k = 0; k < 3; ++k) { a.V[k] = V[k]; a.U[k] = U[k]; }
+    a.part = part; a.part_stride = (long long)part_stride; a.sync = sync;
+    a.n = n; a.B = B; a.T = T; a.dz_t0 = dz_t0;
+    if (nwg) *nwg = blocks;
+    // the words are zeroed by a KERNEL: a memset node in front of the launch (hipMemsetAsync under stream capture) was not
+    // ordered before it when graph replays follow each other without a host synchronisation -- the launch then saw the
+    // previous replay's words, every wait was open, and the layers raced on the nearly-right (V, U) of the step before
+    // (fast, and wrong in the fourth digit of the loss after a hundred steps)
+    const int nsync = (int)mfma_chain_multi_sync_words(B, T);
+    hipLaunchKernelGGL(k_chain_zero_sync, dim3(cdiv(nsync, 256)), dim3(256), 0, s, sync, nsync);
+    WN_LAUNCH_CHECK();
+    static bool attr_set = false;
+    if (!attr_set) {
+        WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chain_multi<true, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kCLdsBytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_layer_bwd_chain_multi<true, true>), dim3(blocks), dim3(256), kCLdsBytes, s, a);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
 size_t mfma_chain_part_floats() { return (size_t)kCMaxBlocks * kPartFloats; }
 
 // Sum the partial tiles of L layers (layer l: nwg[l] tiles at part + l * mfma_chain_part_floats()) into their weight
@@ -1131,6 +1545,18 @@ int mfma_chain_combine(const float* V, const float* U, float* dx, int B, int T, 
 
 }  // namespace wn
 
+#ifdef WN_MULTI_STAMPS
+extern "C" int wn_debug_multi_stamps(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wn::g_multi_stamps), sizeof(unsigned long long) * (wn::kChainMaxL + 1) * 256 * 4);
+}
+extern "C" int wn_debug_multi_seg(unsigned long long* dst, int zero) {
+    if (zero) { static unsigned long long z[256 * 4 * 8]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(wn::g_multi_seg), z, sizeof(z)); }
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wn::g_multi_seg), sizeof(unsigned long long) * 256 * 4 * 8);
+}
+extern "C" int wn_debug_multi_spins(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wn::g_multi_spins), sizeof(unsigned long long) * (wn::kChainMaxL + 1) * 256 * 4);
+}
+#endif
 #ifdef WN_BWD_STAMPS
 extern "C" int wn_debug_bwd_stamps(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wn::g_bwd_stamps), sizeof(unsigned long long) * 1024 * 8);

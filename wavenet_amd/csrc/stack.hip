@@ -55,7 +55,8 @@ size_t wn_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T) {
     tot += 2 * n * d->Cr;           // ping-pong gradient of the residual stream
     bool fast = true;               // chained MFMA path: every layer keeps its partial weight-gradient tiles until the end
     for (int l = 0; l < d->n_layers && fast; ++l) fast = wn_layer_fast_path(d->Cr, d->cd[l], d->fw) != 0;
-    if (fast) tot += (size_t)d->n_layers * mfma_chain_part_floats();
+    // + the multi-layer launch's dataflow words (rounded to 256 B) and its third (V, U) pair
+    if (fast) tot += (size_t)d->n_layers * mfma_chain_part_floats() + ((mfma_chain_multi_sync_words(B, T) + 63) / 64) * 64 + 2 * n * d->Cr;
     return tot * sizeof(float);
 }
 
@@ -224,8 +225,13 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
         float* vu = dab + mfma_layer_bwd_extra_ws_floats();
         std::vector<float*> dWp_eff(L);
         std::vector<int> nwg(L);
-        float* Vb[2] = {vu, vu + n * d->Cr};
-        float* Ub[2] = {vu + 2 * n * d->Cr, vu + 3 * n * d->Cr};
+        // three (V, U) pairs, layer l writes pair l % 3 and reads pair (l + 1) % 3: with two, a layer rewrites the rows the layer
+        // above it READ, and the multi-layer launch would have to hold a tile back until the readers of the previous layer
+        // are through; with three the readers are two layers back
+        unsigned* sync = reinterpret_cast<unsigned*>(parts + (size_t)L * mfma_chain_part_floats());
+        float* vu3 = reinterpret_cast<float*>(sync) + ((mfma_chain_multi_sync_words(B, T) + 63) / 64) * 64;
+        float* Vb[3] = {vu, vu + n * d->Cr, vu3};
+        float* Ub[3] = {vu + 2 * n * d->Cr, vu + 3 * n * d->Cr, vu3 + n * d->Cr};
         const float* Vin = dout;
         const float* Uin = nullptr;
         int dU = 0;
@@ -235,20 +241,56 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
         int t_live = dout ? 0 : t_off;               // first column of the current layer that can carry gradient
         int vu_t0 = 0;                               // first written row of Vin / Uin
         wn::ProfScope prof__("wn_layer_bwd", stream);        // one bracket: 40 layer kernels + the tile reduction
+        // fp16 x 2, z + sigmoid saved, loss on the skip sum: every layer that has V, U and dz_skip inputs (all but the top
+        // one) runs in ONE launch with grid barriers between layers (k_layer_bwd_chain_multi); the per-layer loop below
+        // then only collects their parameters
+        const bool multi = gemm_mode() == WN_GEMM_FP16X2 && f == nullptr && dskip && d->Cs % 32 == 0 && L >= 3 &&
+                           L - 1 <= mfma_chain_multi_max_layers() && !exec_flag(WN_EXEC_NO_MULTI_LAYER_BWD);
+        std::vector<int> m_layer, m_d, m_Z, m_live, m_vu_t0, m_dU;
+        std::vector<const float*> m_Wf, m_Wg, m_Wp;
         for (int l = L - 1; l >= 0; --l) {
             const float* in = l == 0 ? x : xs + (size_t)(l - 1) * n * d->Cr;
             int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
             const int live = (t_live / 32) * 32;
-            rc = mfma_layer_bwd_chain(in, f ? f + off[l] : z + off[l], g + off[l], d->Wf[l], d->Wg[l], d->Wp[l], Vin, Uin,
-                                      dU, vu_t0, dskip ? dzp[l] : nullptr, (dskip && d->Cs % 32 == 0) ? t_off : 0,
-                                      Vb[l & 1], Ub[l & 1], parts + (size_t)l * mfma_chain_part_floats(), B, T,
-                                      d->dilation[l], Z, live, &nwg[l], as_stream(stream), f == nullptr);
-            if (rc) return rc;
+            if (multi && Vin && Uin) {
+                m_layer.push_back(l); m_d.push_back(d->dilation[l]); m_Z.push_back(Z); m_live.push_back(live);
+                m_vu_t0.push_back(vu_t0); m_dU.push_back(dU);
+                m_Wf.push_back(d->Wf[l]); m_Wg.push_back(d->Wg[l]); m_Wp.push_back(d->Wp[l]);
+            } else {
+                rc = mfma_layer_bwd_chain(in, f ? f + off[l] : z + off[l], g + off[l], d->Wf[l], d->Wg[l], d->Wp[l], Vin, Uin,
+                                          dU, vu_t0, dskip ? dzp[l] : nullptr, (dskip && d->Cs % 32 == 0) ? t_off : 0,
+                                          Vb[l % 3], Ub[l % 3], parts + (size_t)l * mfma_chain_part_floats(), B, T,
+                                          d->dilation[l], Z, live, &nwg[l], as_stream(stream), f == nullptr);
+                if (rc) return rc;
+            }
             dWp_eff[l] = (Vin || Uin) ? dWp[l] : nullptr;
-            Vin = Vb[l & 1]; Uin = Ub[l & 1]; dU = d->dilation[l];
+            Vin = Vb[l % 3]; Uin = Ub[l % 3]; dU = d->dilation[l];
             vu_t0 = live;
             t_live = t_live - (d->fw - 1) * d->dilation[l];      // the layer below: one more dilation of reach
             if (t_live < 0) t_live = 0;
+        }
+        if (!m_layer.empty()) {
+            int grid = 0;
+            rc = mfma_layer_bwd_chain_multi((int)m_layer.size(), m_layer.data(), m_Wf.data(), m_Wg.data(), m_Wp.data(),
+                                            m_d.data(), m_Z.data(), m_live.data(), m_vu_t0.data(), m_dU.data(), x, xs, z, g,
+                                            ws /* dz of layer l at ws + l n 32 */, Vb, Ub, parts, mfma_chain_part_floats(),
+                                            sync, B, T, t_off, &grid, as_stream(stream));
+            if (rc == WN_ESHAPE) {                  // fewer CUs than workgroups: one launch per layer after all
+                wn::set_error("");
+                for (size_t i = 0; i < m_layer.size(); ++i) {
+                    const int l = m_layer[i];
+                    const float* in = l == 0 ? x : xs + (size_t)(l - 1) * n * d->Cr;
+                    rc = mfma_layer_bwd_chain(in, z + off[l], g + off[l], d->Wf[l], d->Wg[l], d->Wp[l], Vb[(l + 1) % 3],
+                                              Ub[(l + 1) % 3], m_dU[i], m_vu_t0[i], dzp[l], t_off, Vb[l % 3], Ub[l % 3],
+                                              parts + (size_t)l * mfma_chain_part_floats(), B, T, m_d[i], m_Z[i], m_live[i],
+                                              &nwg[l], as_stream(stream), true);
+                    if (rc) return rc;
+                }
+                grid = 0;
+            }
+            if (rc) return rc;
+            if (grid)
+                for (int l : m_layer) nwg[l] = grid;
         }
         rc = mfma_chain_reduce_all(parts, L, nwg.data(), dWf, dWg, dWp_eff.data(), as_stream(stream));
         if (rc) return rc;

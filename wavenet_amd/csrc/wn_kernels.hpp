@@ -92,6 +92,13 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
                          const float* Wp, const float* Vin, const float* Uin, int dU, int vu_t0, const float* dzs,
                          int dz_t0, float* Vout, float* Uout, float* part, int B, int T, int d, int Z, int t_live,
                          int* nwg, hipStream_t s, bool from_z = false);   // from_z: `f` holds z, tanh = z / sigmoid
+int mfma_chain_multi_max_layers();
+int mfma_layer_bwd_chain_multi(int n, const int* layer, const float* const* Wf, const float* const* Wg,
+                               const float* const* Wp, const int* d, const int* Z, const int* t_live, const int* vu_t0,
+                               const int* dU, const float* x0, const float* xs, const float* z, const float* g,
+                               const float* dz, float* const* V, float* const* U, float* part, size_t part_stride,
+                               unsigned* sync, int B, int T, int dz_t0, int* nwg, hipStream_t s);
+size_t mfma_chain_multi_sync_words(int B, int T);
 size_t mfma_chain_part_floats();
 int mfma_chain_reduce_all(const float* part, int L, const int* nwg, float* const* dWf, float* const* dWg,
                           float* const* dWp, hipStream_t s);
