@@ -508,6 +508,21 @@ def main():
         bound, amount, launches, knames = units[dom]
         launch_ms = per_step[dom] / launches
         traffic_kernel, traffic = pmc_find(knames)
+        kernel_launch = None
+        if dom == "wn_layer_bwd":
+            # The chained backward of the stack is ONE launch for every layer below the top one (k_layer_bwd_chain_multi) + the top
+            # layer's own launch + the partial-tile reduction.  The roofline unit stays "one layer": bytes = (multi launch + top
+            # layer) / layers, time = the bracket around all of it / layers.
+            mk, mb = pmc_find([r"wn::k_layer_bwd_chain_multi"])
+            tk, tb = pmc_find([r"wn::k_layer_bwd_chainsp<false, false, true"])
+            if mb:
+                traffic_kernel, traffic = mk, (mb + (tb or 0.0)) / nl
+                kernel_launch = {"kernel": mk, "layers_per_launch": nl - 1, "hbm_bytes_per_launch": mb,
+                                 "top_layer_kernel": tk, "top_layer_hbm_bytes": tb,
+                                 "bracket_ms": per_step[dom],
+                                 "note": "launch_ms / traffic / algorithmic bytes of `roofline` are per LAYER (bracket / %d layers); the "
+                                         "rocprofv3 average duration of the multi-layer kernel is ~ bracket_ms minus the top layer's "
+                                         "launch (~0.026 ms) and the partial-tile reduction (~0.044 ms)" % nl}
         # fp32-equivalent flops of one launch of the dominant unit
         layer_flops = {"wn_layer_bwd": 2 * 2 * (2 * 2 * Cr * Cd + Cd * Cr) * n_col, "wn_layer_fwd": 2 * (2 * 2 * Cr * Cd + Cd * Cr) * n_col}
         # matrix peak of the fused layer kernels: fp32 MFMA, or three f16 MFMAs per product under fp16x2
@@ -520,7 +535,7 @@ def main():
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "basis": "measured HBM bytes (PMC)" if traffic else "SURVEY 8(d) algorithmic bytes",
                                "traffic": traffic, "traffic_kernel": traffic_kernel,
-                               "traffic_source": traffic_source, "launch_ms": launch_ms,
+                               "traffic_source": traffic_source, "launch_ms": launch_ms, "kernel_launch": kernel_launch,
                                "traffic_frac": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                                "survey_8d": {"algorithmic_bytes_per_launch": amount, "achieved": alg, "frac": alg / HBM_PEAK_GBS},
                                "algorithmic_bytes_per_launch": amount,
