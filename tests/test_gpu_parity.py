@@ -720,6 +720,30 @@ def test_fast_step_full_window_output_is_the_references_shape_and_values():
     np.testing.assert_allclose(lg, want, atol=1e-4)
 
 
+def test_generate_with_keep_window_drops_the_stale_window_history():
+    """generate() advances the decoder n - 1 steps on the device; the host-side ring of window logits still
+    holds the prefill state.  A later full_window=True call must not answer with that stale window: it raises until the
+    caller prefills again; the newest-column face keeps working from the decoder's (current) state and equals a fresh
+    generate() of the same draws."""
+    over = dict(quantization_steps=256, causal_conv_channels=[16], residual_conv_channels=[16] * 4,
+                residual_num_blocks=2, softmax_conv_channels=[32, 256])
+    p, w, net = build(over, cls=FasterWaveNet)
+    net.keep_window = True
+    u = np.random.RandomState(3).random_sample(12)
+    toks = to_np(net.generate(10, u[:10]))
+    with pytest.raises(Exception, match="window history was dropped"):
+        net._forward_one_step(int(toks[-1]), full_window=True)
+    pr = net._forward_one_step(int(toks[-1]), apply_softmax=True, as_numpy=True)        # step 11 from the decoder's state
+    _, probs = net.generate(11, u[:11], return_probs=True)
+    np.testing.assert_allclose(pr[0, :, 0, -1], to_np(probs)[10], atol=2e-6)
+    net.prev_causal_outputs = None                                                      # prefill again: full_window is back
+    iw = net.input_width
+    buf = np.random.RandomState(4).randint(0, 256, (iw,)).astype(np.int32)
+    net._forward_one_step(data.onehot_pixel_image(buf.reshape(1, -1), 256))
+    out = net._forward_one_step(int(buf[-1]), as_numpy=True, full_window=True)
+    assert out.shape == (1, 256, 1, iw)
+
+
 def test_fast_equals_slow_cfg2_topology_with_extra_causal_layer_and_fw3():
     """KAT-6 on the GPU: incremental decode == full-window forward, same head activation."""
     over = dict(quantization_steps=32, causal_conv_channels=[12, 8], causal_conv_filter_width=3,

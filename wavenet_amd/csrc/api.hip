@@ -14,7 +14,7 @@ void set_error(const char* fmt, ...) {
 }
 static thread_local const WnExec* g_exec = nullptr;
 static thread_local int g_exec_depth = 0;
-static thread_local const void* g_absmax_key[16];
+static thread_local const void* g_absmax_key[64];          // one per word of the scratch tail (kExecTail / 4)
 static thread_local int g_absmax_n = 0;
 static constexpr size_t kExecTail = 256;                  // bytes at the end of the scratch kept for the absmax words
 ExecScope::ExecScope(const WnExec* ex) : prev(g_exec) { g_exec = ex; ++g_exec_depth; }
@@ -36,7 +36,7 @@ const unsigned* exec_absmax(const float* x, long long n, hipStream_t s) {
     unsigned* slots = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(g_exec->ws) + g_exec->ws_bytes - kExecTail);
     for (int i = 0; i < g_absmax_n; ++i)
         if (g_absmax_key[i] == x) return slots + i;
-    if (g_absmax_n >= 16) { set_error("exec_absmax: more than 16 arrays in one call"); return nullptr; }
+    if (g_absmax_n >= 64) { set_error("exec_absmax: more than 64 range words in one call"); return nullptr; }
     if (generic_absmax(x, n, slots + g_absmax_n, s) != WN_OK) return nullptr;
     g_absmax_key[g_absmax_n] = x;
     return slots + g_absmax_n++;
@@ -50,8 +50,8 @@ unsigned* exec_word(const void* key, bool* fresh, hipStream_t s) {
     unsigned* slots = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(g_exec->ws) + g_exec->ws_bytes - kExecTail);
     for (int i = 0; i < g_absmax_n; ++i)
         if (g_absmax_key[i] == key) return slots + i;
-    if (g_absmax_n >= 16) { set_error("exec_word: more than 16 range words in one call"); return nullptr; }
-    if (hipMemsetAsync(slots + g_absmax_n, 0, sizeof(unsigned), s) != hipSuccess) { set_error("exec_word: memset failed"); return nullptr; }
+    if (g_absmax_n >= 64) { set_error("exec_word: more than 64 range words in one call"); return nullptr; }
+    if (generic_zero_word(slots + g_absmax_n, s) != WN_OK) return nullptr;      // (a kernel, not a memset node: generic_kernels.hip)
     g_absmax_key[g_absmax_n] = key;
     *fresh = true;
     return slots + g_absmax_n++;

@@ -1171,8 +1171,18 @@ __global__ void k_absmax(const float* __restrict__ x, long long n4, long long n,
         atomicMax(slot, __float_as_uint(m));
     }
 }
+// One word = 0, by a KERNEL.  hipMemsetAsync under stream capture becomes a memset node, and with graph replays launched back
+// to back a memset node in front of a kernel node was observed NOT to be ordered before it (the
+// multi-layer backward spun on a counter that still held the previous replay's value).  Every word a following kernel
+// accumulates into with atomicMax is therefore cleared by a kernel node.
+__global__ void k_zero_word(unsigned* w) { *w = 0u; }
+int generic_zero_word(unsigned* w, hipStream_t s) {
+    hipLaunchKernelGGL(k_zero_word, dim3(1), dim3(1), 0, s, w);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
 int generic_absmax(const float* x, long long n, unsigned* slot, hipStream_t s) {
-    WN_HIP(hipMemsetAsync(slot, 0, sizeof(unsigned), s));
+    if (int rc = generic_zero_word(slot, s)) return rc;
     if (n <= 0) return WN_OK;
     if (reinterpret_cast<uintptr_t>(x) & 15) { wn::set_error("absmax: the array must be 16-byte aligned"); return WN_EARG; }
     // one atomicMax per block, and atomics on ONE address retire at ~13 ns each: 2,048 blocks of 256 threads spent 27 of the

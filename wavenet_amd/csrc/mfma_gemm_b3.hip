@@ -853,7 +853,9 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
         // the weights' own range: |w| <= 2^7 was an assumption (a weight above ~254 saturated the fp16 parts silently); one
         // pass of the same grid over the weight tiles measures it, per entry-point call and weight set
         bool fresh = false;
-        unsigned* wm = exec_word(a.W[0], &fresh, s);
+        // keyed by the first weight array AND the launch's form: a second launch of the same call that starts at the same
+        // array but covers another weight set (more sources, another mode) must measure its own maximum
+        unsigned* wm = exec_word(reinterpret_cast<const char*>(a.W[0]) + (((unsigned)mode & 7u) << 8 | ((unsigned)a.nsrc & 255u)), &fresh, s);
         if (!wm) return WN_EARG;
         a.wmax_dev = wm;
         if (fresh) hipLaunchKernelGGL(k_split_w<true>, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img, 3);
@@ -1533,7 +1535,12 @@ int launch_wgrad_b3w(WGArgs& a_io, hipStream_t s) {
     a.part = reinterpret_cast<float*>(exec_scratch(part_bytes + cs_bytes, "the weight-gradient partial tiles"));
     if (!a.part) return WN_EARG;
     a.colsum_part = cs ? a.part + part_bytes / sizeof(float) : nullptr;
-    if (h2 && a.lda == 256 && (long long)a.rows_B_per_b * a.ldb * 4 < (1ll << 31) && !exec_flag(WN_EXEC_NO_PIPELINED_GEMM)) {
+    // the pipelined kernel clamps B's rows to the end of the slab only: every row a chunk can reach must lie inside B's clip,
+    // i.e. a non-negative shift that keeps A's rows inside B's and no per-problem shift (the skip path's shape); anything else
+    // takes k_wgrad_b3w, which masks rows outside the clip
+    bool clip_ok = a.off >= 0 && (long long)a.rows_A_per_b + a.off <= a.rows_B_per_b;
+    for (int q = 0; q < a.nprob && clip_ok; ++q) clip_ok = a.offp[q] == 0;
+    if (h2 && clip_ok && a.lda == 256 && (long long)a.rows_B_per_b * a.ldb * 4 < (1ll << 31) && !exec_flag(WN_EXEC_NO_PIPELINED_GEMM)) {
         static bool attr_p = false;
         if (!attr_p) {
             WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgrad_h2p<WN_ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, kWpLds));

@@ -59,6 +59,7 @@ const unsigned* exec_absmax(const float* x, long long n, hipStream_t s);
 // handed out for the same key before
 unsigned* exec_word(const void* key, bool* fresh, hipStream_t s);
 int generic_absmax(const float* x, long long n, unsigned* slot, hipStream_t s);
+int generic_zero_word(unsigned* w, hipStream_t s);        // by a kernel: see generic_kernels.hip
 int generic_scale_by_dev(float* x, const float* sdev, long long n, hipStream_t s);
 int generic_rule(int rule, float* p, const float* g, float* s1, float* s2, long long n, float lr, float hy, float eps,
                  float wd, const float* sqnorm, float clip, float gmult, const float* lr_dev, hipStream_t s);

@@ -155,6 +155,9 @@ class FasterWaveNet(WaveNet):
         lib = _lib.lib()
         prob = torch.empty((1, 1, Q), device=self.device, dtype=torch.float32)
         if self._hist is None:
+            if full_window:
+                raise Exception("full_window=True: the window history was dropped (generate() advanced the decoder on the "
+                                "device); set prev_causal_outputs = None and prefill again")
             check(lib.wn_decoder_step(self._decoder(), token, ptr(prob), 1 if apply_softmax else 0, stream_ptr()),
                   "wn_decoder_step")
             out = _as_view(prob)
@@ -208,4 +211,8 @@ class FasterWaveNet(WaveNet):
             first = int(out[0].item())
             check(lib.wn_decoder_run(self._decoder(), first, ptr(u[1:]), n_samples - 1, ptr(out[1:]),
                                      ptr(probs[1:]) if return_probs else None, stream_ptr()), "wn_decoder_run")
+            # the decoder advanced n_samples - 1 steps on the device (its rings are current: step-by-step decoding may go
+            # on from here), but the host-side window history -- what _forward_one_step(..., full_window=True) returns
+            # the older columns from -- still holds the prefill state: drop it rather than answer with a stale window
+            self._hist = None
         return (out, probs) if return_probs else out
