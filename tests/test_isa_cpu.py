@@ -1,0 +1,92 @@
+"""Build-time check on the ISA of the one kernel whose correctness rests on how hipcc treats inline-asm load outputs
+(ADVICE r3, low): `k_colgemm_h2q` (wavenet_amd/csrc/mfma_gemm_b3.hip) keeps its X ring as the OUTPUTS of inline-asm
+`global_load_dwordx4` that are still in flight across loop iterations, waited for by a hand-counted `s_waitcnt vmcnt`.
+hipcc believes an asm output is ready when the statement ends: if it ever copies or spills such a register between the
+request and the wait, the copy reads a register the load has not written yet (exactly this miscompiled in
+`k_wgrad_h2p`'s first form: intermittently wrong sums at full size).  The committed build is fine -- the ring sits in
+fixed registers, never moved -- and this test keeps it so across compiler / flag changes: it compiles the file to gfx950
+assembly (device only, ~35 s) and requires, in every instantiation of the kernel,
+  * no scratch (spill) instruction at all,
+  * every asm-issued ring load writes one of at most 8 fixed 4-register slots (a rotating ring would show more), and
+  * with the vector-memory queue modelled (in-order retirement, `s_waitcnt vmcnt(N)` leaves the N youngest in flight; the
+    pipelined region scanned twice for the loop-carried requests): no `v_mov_b32` / `v_accvgpr_write` / `v_pk_mov` /
+    `v_swap` / `ds_write` / `global_store` reads a ring register whose load is still in the queue.
+No GPU needed (hipcc cross-compiles)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "wavenet_amd", "csrc", "mfma_gemm_b3.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _regs(tok):
+    """registers named by an operand token: v12 -> {12}; v[130:133] -> {130..133}"""
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_the_pipelined_skip_gemm_never_moves_its_in_flight_ring_registers(tmp_path):
+    out = tmp_path / "b3.s"
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out), SRC],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text().splitlines()
+    starts = [i for i, l in enumerate(text) if re.match(r"^_ZN2wn13k_colgemm_h2q\w+:", l)]
+    assert len(starts) >= 3, "k_colgemm_h2q instantiations not found"
+    for s0 in starts:
+        end = next(i for i in range(s0, len(text)) if ".end_amdhsa_kernel" in text[i])
+        body = text[s0:end]
+        assert not any(re.search(r"\bscratch_(load|store)", l) for l in body), text[s0]
+        ring, in_asm, slots, load_lines = set(), False, set(), []
+        for i, l in enumerate(body):                     # pass 1: the ring = every destination of an asm-issued dwordx4 load
+            ins = l.strip()
+            if ins.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif ins.startswith(";;#ASMEND"):
+                in_asm = False
+            elif in_asm and ins.startswith("global_load_dwordx4"):
+                dst = _regs(re.split(r"[ ,]+", ins)[1])
+                slots.add(min(dst))
+                ring |= dst
+                load_lines.append(i)
+        assert 1 <= len(slots) <= 8 and len(ring) == 4 * len(slots), (sorted(slots), text[s0][:60])
+        # pass 2: model the vector-memory queue (operations retire in issue order; `s_waitcnt vmcnt(N)` leaves the N youngest in
+        # flight) over the pipelined part of the kernel -- first ring request to last -- twice, the second time starting
+        # from the queue the first pass ended with (the loop-carried requests): no copy / spill / store may read a ring
+        # register whose load is still in the queue
+        def scan(lines, queue):
+            for l in lines:
+                ins = l.strip().split(";")[0].strip()
+                if not ins or ins.startswith("."):
+                    continue
+                ops = [o for o in re.split(r"[ ,]+", ins) if o]
+                if ops[0] == "s_waitcnt":
+                    m = re.search(r"vmcnt\((\d+)\)", ins)
+                    if m:
+                        n = int(m.group(1))
+                        queue = queue[len(queue) - n:] if n else []
+                    continue
+                if ops[0].startswith(("global_load", "global_store", "global_atomic", "buffer_", "scratch_")):
+                    dst = _regs(ops[1]) & ring if ops[0].startswith("global_load_dword") else set()
+                    queue = queue + [dst]
+                    if ops[0].startswith(("global_store", "scratch_store")):
+                        srcs = set().union(*[_regs(o) for o in ops[1:]])
+                        busy = set().union(*queue[:-1]) if len(queue) > 1 else set()
+                        assert not (srcs & busy), "a ring register in flight is stored: %s  [%s]" % (ins, text[s0][:60])
+                    continue
+                if ops[0].startswith(("v_mov_b32", "v_accvgpr_write", "v_pk_mov", "v_swap", "ds_write")):
+                    srcs = set().union(*[_regs(o) for o in (ops[1:] if ops[0].startswith("ds_write") else ops[2:])])
+                    busy = set().union(*queue) if queue else set()
+                    assert not (srcs & busy), "a ring register in flight is copied: %s  [%s]" % (ins, text[s0][:60])
+            return queue
+        region = body[load_lines[0]:load_lines[-1] + 1]
+        q1 = scan(region, [])
+        scan(region, q1)
