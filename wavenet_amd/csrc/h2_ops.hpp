@@ -39,6 +39,38 @@ __device__ __forceinline__ void lb_pow2_scale(float mx, float& s, float& inv) {
     s = __int_as_float(f << 23);
     inv = __int_as_float((254 - f) << 23);                     // f = 254: 0 (the tile is all zeros or denormals)
 }
+// x s = h + m for 16 values.  The residual m = x s - h is ONE instruction per value, v_fma_mix{lo,hi}_f16 (fp32 x fp32 - fp16
+// -> fp16: s is a power of two, so x s is exact and the fused form equals the two-step one bit for bit); written in C,
+// hipcc's SLP pass turns the residual into "convert h back to fp32, packed subtract, convert again": six instructions per
+// pair of values instead of four -- a third of all the vector instructions of a split, in kernels that are bound by
+// vector-instruction issue.  One instruction per asm statement and no `volatile`: the scheduler moves them as freely as
+// any other VALU instruction (the four-instruction asm chains of an earlier attempt could not be interleaved with the
+// MFMAs and lost 5 %).
+#ifndef WN_SPLIT_C_ONLY
+__device__ __forceinline__ void lb_split16(const float (&v)[16], float s, H2Op& o) {
+    typedef unsigned h2_u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        h2_u32x4 mp;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float a = v[8 * ks + 2 * p], b = v[8 * ks + 2 * p + 1];
+            typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+            h16x2_t hp;
+            hp[0] = (_Float16)(a * s);
+            hp[1] = (_Float16)(b * s);
+            o.h[ks][2 * p] = hp[0];
+            o.h[ks][2 * p + 1] = hp[1];
+            const unsigned hu = __builtin_bit_cast(unsigned, hp);
+            unsigned m;
+            asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(m) : "v"(a), "v"(s), "v"(hu));
+            asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(m) : "v"(b), "v"(s), "v"(hu));
+            mp[p] = m;
+        }
+        o.m[ks] = __builtin_bit_cast(h16x8, mp);
+    }
+}
+#else
 __device__ __forceinline__ void lb_split16(const float (&v)[16], float s, H2Op& o) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -50,6 +82,7 @@ __device__ __forceinline__ void lb_split16(const float (&v)[16], float s, H2Op& 
             o.m[ks][e] = (_Float16)(xs - (float)hh);
         }
 }
+#endif
 
 // LDS-DMA of one 1 KB piece (global_load_lds_dwordx4: lane L's 16 bytes at `src` land at lds_dst + 16 L; lds_dst is
 // wave-uniform) as inline asm.  With the builtin, hipcc knows that LDS is written asynchronously and puts `s_waitcnt
