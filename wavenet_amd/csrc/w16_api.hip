@@ -206,13 +206,21 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
     }
     {
         wn::ProfScope prof__("wn16_layer_bwd", stream);
+        // Dead columns (as in the fp32 stack, stack.hip): the loss reaches the stack through skip[t_off:] only, so layer l
+        // receives gradient at columns t >= t_off - (reach of the layers above it) and nowhere else.  Tiles wholly below that
+        // load and compute nothing; they store the zeros their readers (the dx kernel, the deferred weight-gradient launch,
+        // the layer below) expect.  12.5 % of the sample-layers at config 5's window.
+        int t_live = t_off;
         for (int l = L - 1; l >= 0; --l) {
             const bf16* in = l == 0 ? xb : xsb + (size_t)(l - 1) * n * 128;
             const int dl = d->dilation[l];
             const int Z = compat_zero_prefix ? zero_prefix(T, dl, 2) : 0;
             bf16* dadg = w.dadg + (size_t)l * n * 256;
+            const int live = (t_live / 32) * 32;
+            t_live = t_live - dl > 0 ? t_live - dl : 0;       // the layer below (and this layer's dx): one more dilation of reach
+            const int live_dx = (t_live / 32) * 32;
             if ((rc = gate_bwd_layer(in, img + (size_t)l * kLayerImg, gout, dsk ? w.dzs + (size_t)l * nw * 128 : nullptr,
-                                     t_off, dadg, B, T, dl, Z, s)))
+                                     t_off, dadg, B, T, dl, Z, live, s)))
                 return rc;
             bf16* gin = l == 0 ? reinterpret_cast<bf16*>(dx) : w.dxb[l & 1];
             if (!gin) break;                               // l == 0 and the caller does not want dx
@@ -220,7 +228,7 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
             // projection gradient dWp_{l-1} += dx_l z_{l-1}^T is taken in the same pass
             const bf16* zprev = l > 0 ? zb + (size_t)(l - 1) * n * 128 : nullptr;
             if ((rc = dx_layer(dadg, img + (size_t)l * kLayerImg, gout, zprev, gin,
-                               l > 0 ? w.parts + (size_t)(l - 1) * part_stride : nullptr, B, T, dl, s)))
+                               l > 0 ? w.parts + (size_t)(l - 1) * part_stride : nullptr, B, T, dl, live_dx, s)))
                 return rc;
             if (l > 0) dWp_eff[l - 1] = dWp[l - 1];
             gout = gin;

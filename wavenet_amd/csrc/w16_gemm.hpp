@@ -62,11 +62,12 @@ int embed_fwd16(const int32_t* idx, const float* W, const float* bias, bf16* out
 
 // w16_layer.hip
 int fwd_layer(const bf16* x, const bf16* img, bf16* out, bf16* z, int B, int T, int d, int Z, hipStream_t s);
+// t_live (multiple of 32): columns below it receive no gradient -- their tiles store zeros and do nothing else
 int gate_bwd_layer(const bf16* x, const bf16* img, const bf16* dout, const bf16* dzs, int dz_t0, bf16* dadg, int B, int T,
-                   int d, int Z, hipStream_t s);
+                   int d, int Z, int t_live, hipStream_t s);
 int dx_grid(int B, int T);
 int dx_layer(const bf16* dadg, const bf16* img, const bf16* dout, const bf16* zprev, bf16* dx, float* dwp_part, int B,
-             int T, int d, hipStream_t s);
+             int T, int d, int t_live, hipStream_t s);
 int reduce_parts(const float* part, long long layer_stride, int nwg, int n, float* const* dW_dev, int L, hipStream_t s);
 
 }  // namespace w16

@@ -233,7 +233,9 @@ template <bool HAS_DO, bool HAS_DZ>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k16_gate_bwd(
     const bf16* __restrict__ x, const bf16* __restrict__ convA, const bf16* __restrict__ dzA,
     const bf16* __restrict__ dout, const bf16* __restrict__ dzs, int dz_t0, bf16* __restrict__ dadg, int B, int T, int d,
-    int Z, int tiles_per_b, int ntiles) {
+    int Z, int tiles_per_b, int ntiles, int t_live) {
+    // t_live (a multiple of 32): no gradient reaches this layer's columns below it (they are further from the loss window than
+    // the layers above can see).  Such tiles load and compute nothing: they store the zeros their readers expect.
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     auto xold = [&](int buf) { return lds + buf * kLTileB; };
     auto xcur = [&](int buf) { return lds + (2 + buf) * kLTileB; };
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     auto issue = [&](int tile, int buf) {
         const int b = tile / tiles_per_b;
         const int t0 = (tile - b * tiles_per_b) * kLT;
+        if (t0 + kLT <= t_live) return;                    // a dead tile
         const bf16* xb = x + (long long)b * T * 128;
         dma_pieces(xcur(buf), lane, w, 1, 1, [&](int r) {
             const int t = t0 + r < T ? t0 + r : T - 1;
@@ -311,6 +314,16 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (full_prev) wait_vm<kStores>(); else wait_vm<0>();
         barrier();
         if (tile + stride < last) issue(tile + stride, buf ^ 1);
+        if (t0 + kLT <= t_live) {                          // dead tile (workgroup-uniform): [da | dg] = 0, two stores per wave as below
+            const int r = 4 * w + (lane >> 4);
+            const int c = (lane & 15) ^ key(r);
+            bf16* o = dadg + ((long long)b * T + t0 + r) * 256 + c * 8;
+            const u32x4 zero4 = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(o) = zero4;
+            *reinterpret_cast<u32x4*>(o + 128) = zero4;
+            full_prev = true;
+            continue;
+        }
         const bool fix_old = t0 < d;
         const bool fix_do = false;
         if (fix_old || fix_do) {
@@ -396,7 +409,8 @@ template <bool HAS_DO, bool HAS_Z>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k16_dx(const bf16* __restrict__ dadg, const bf16* __restrict__ dxA,
                                                   const bf16* __restrict__ dout, const bf16* __restrict__ zprev,
                                                   bf16* __restrict__ dx, float* __restrict__ dwp_part, int B, int T, int d,
-                                                  int tiles_per_b, int ntiles) {
+                                                  int tiles_per_b, int ntiles, int t_live) {
+    // t_live (a multiple of 32): dx is exactly zero below it (no gradient reaches those columns); such tiles store zeros
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     auto tile_at = [&](int buf, int which) { return lds + (buf * 6 + which) * kLTileB; };   // da dg da' dg' dout z
     float* xch = reinterpret_cast<float*>(lds + 12 * kLTileB);
@@ -421,6 +435,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     auto issue = [&](int tile, int buf) {
         const int b = tile / tiles_per_b;
         const int t0 = (tile - b * tiles_per_b) * kLT;
+        if (t0 + kLT <= t_live) return;                    // a dead tile
         const bf16* ab = dadg + (long long)b * T * 256;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -460,6 +475,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         if (full_prev) wait_vm<1>(); else wait_vm<0>();  // one dx store per wave and tile
         barrier();
         if (tile + stride < last) issue(tile + stride, buf ^ 1);
+        if (t0 + kLT <= t_live) {                          // dead tile (workgroup-uniform): dx = 0, one store per wave as below
+            const int r = 4 * w + (lane >> 4);
+            const int c = (lane & 15) ^ key(r);
+            const u32x4 zero4 = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4*>(dx + ((long long)b * T + t0 + r) * 128 + c * 8) = zero4;
+            full_prev = true;
+            continue;
+        }
         if (t0 + kLT + d > T) {                          // dab[t + d] beyond the clip end contributes nothing
             for (int r = w; r < kLT; r += 8)
                 if (t0 + r + d >= T) {
@@ -574,7 +597,7 @@ int fwd_layer(const bf16* x, const bf16* img, bf16* out, bf16* z, int B, int T, 
 }
 
 int gate_bwd_layer(const bf16* x, const bf16* img, const bf16* dout, const bf16* dzs, int dz_t0, bf16* dadg, int B, int T,
-                   int d, int Z, hipStream_t s) {
+                   int d, int Z, int t_live, hipStream_t s) {
     const int tiles_per_b = (T + kLT - 1) / kLT;
     const int ntiles = B * tiles_per_b;
     const int grid = grid_for(ntiles, 1);
@@ -587,7 +610,7 @@ int gate_bwd_layer(const bf16* x, const bf16* img, const bf16* dout, const bf16*
             attr = true;                                                                                               \
         }                                                                                                              \
         hipLaunchKernelGGL((k16_gate_bwd<DO, DZ>), dim3(grid), dim3(512), kGateLds, s, x, img + kOffConvA8,           \
-                           img + kOffDzA8, dout, dzs, dz_t0, dadg, B, T, d, Z, tiles_per_b, ntiles);                   \
+                           img + kOffDzA8, dout, dzs, dz_t0, dadg, B, T, d, Z, tiles_per_b, ntiles, t_live);          \
     } while (0)
     if (dout && dzs) GB_LAUNCH(true, true);
     else if (dout) GB_LAUNCH(true, false);
@@ -602,7 +625,7 @@ int dx_grid(int B, int T) { return grid_for(B * ((T + kLT - 1) / kLT), 1); }
 
 // dx = dout + conv^T(dadg); zprev (the z of the layer BELOW, may be NULL) -> that layer's dWp partial tiles
 int dx_layer(const bf16* dadg, const bf16* img, const bf16* dout, const bf16* zprev, bf16* dx, float* dwp_part, int B,
-             int T, int d, hipStream_t s) {
+             int T, int d, int t_live, hipStream_t s) {
     const int tiles_per_b = (T + kLT - 1) / kLT;
     const int ntiles = B * tiles_per_b;
     const int grid = dx_grid(B, T);
@@ -615,7 +638,7 @@ int dx_layer(const bf16* dadg, const bf16* img, const bf16* dout, const bf16* zp
             attr = true;                                                                                               \
         }                                                                                                              \
         hipLaunchKernelGGL((k16_dx<DO, ZZ>), dim3(grid), dim3(512), kDxLds, s, dadg, img + kOffDxA, dout,                \
-                           zprev, dx, dwp_part, B, T, d, tiles_per_b, ntiles);                                         \
+                           zprev, dx, dwp_part, B, T, d, tiles_per_b, ntiles, t_live);                                \
     } while (0)
     if (dout && zprev) DX_LAUNCH(true, true);
     else if (dout) DX_LAUNCH(true, false);
