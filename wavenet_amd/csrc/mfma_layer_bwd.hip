@@ -902,6 +902,31 @@ __device__ __forceinline__ void chain_body(
         }
     };
 
+    // The five accumulator tiles of a wave -> LDS and the workgroup's partial tile -> memory in ONE layout,
+    //     float index ((k * 4 + r / 4) * 64 + lane) * 4 + r % 4        (k: Wf0, Wf1, Wg0, Wg1, Wp; r: accumulator register),
+    // so that both the LDS traffic and the partial tile's stores are 128-bit (k_layer_bwd_reduce_all decodes the same layout)
+    auto acc_to_lds = [&](float* red) {
+        const f32x16* accs[5] = {&aWf0, &aWf1, &aWg0, &aWg1, &aWp};
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(red + ((k * 4 + q) * 64 + lane) * 4) =
+                    make_float4((*accs[k])[4 * q], (*accs[k])[4 * q + 1], (*accs[k])[4 * q + 2], (*accs[k])[4 * q + 3]);
+    };
+    // every thread adds the four waves' copies of its 20 elements in a fixed order and stores them
+    auto sum_to_part = [&](const float* rb, int wave_stride, float* __restrict__ o) {
+#pragma unroll
+        for (int i = 0; i < kPartFloats / 4 / (64 * NW); ++i) {
+            const int e4 = (threadIdx.x + i * 64 * NW) * 4;
+            const float4 a = *reinterpret_cast<const float4*>(rb + e4);
+            const float4 b = *reinterpret_cast<const float4*>(rb + wave_stride + e4);
+            const float4 c = *reinterpret_cast<const float4*>(rb + 2 * wave_stride + e4);
+            const float4 d4 = *reinterpret_cast<const float4*>(rb + 3 * wave_stride + e4);
+            *reinterpret_cast<float4*>(o + e4) = make_float4((a.x + b.x) + (c.x + d4.x), (a.y + b.y) + (c.y + d4.y),
+                                                             (a.z + b.z) + (c.z + d4.z), (a.w + b.w) + (c.w + d4.w));
+        }
+    };
     // ---- prologue: weights -> LDS, first tile's operands, its first half -----------------------------------
     constexpr int kThreads = 64 * NW;
     constexpr int NK = 512 / kThreads;                  // float4 pieces of Wf (and of Wg) per thread
@@ -1114,30 +1139,14 @@ __device__ __forceinline__ void chain_body(
             fetch_some(first, pbase, dza, 1, true);
             fetch_x(first, xc, xo);
         }
-        {
-            float* red = pbase + 2048;
+        acc_to_lds(pbase + 2048);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                red[(0 * 16 + r) * 64 + lane] = aWf0[r]; red[(1 * 16 + r) * 64 + lane] = aWf1[r];
-                red[(2 * 16 + r) * 64 + lane] = aWg0[r]; red[(3 * 16 + r) * 64 + lane] = aWg1[r];
-                red[(4 * 16 + r) * 64 + lane] = aWp[r];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { aWf0[r] = 0.f; aWf1[r] = 0.f; aWg0[r] = 0.f; aWg1[r] = 0.f; aWp[r] = 0.f; }
-        }
+        for (int r = 0; r < 16; ++r) { aWf0[r] = 0.f; aWf1[r] = 0.f; aWg0[r] = 0.f; aWg1[r] = 0.f; aWp[r] = 0.f; }
 #ifdef WN_MULTI_STAMPS
         MST(sg1);
 #endif
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        {
-            float* __restrict__ o = part_done + (long long)blockIdx.x * kPartFloats;
-            const float* rb = wbase + 2048;
-#pragma unroll
-            for (int i = 0; i < kPartFloats / (64 * NW); ++i) {
-                const int e = threadIdx.x + i * 64 * NW;
-                o[e] = (rb[e] + rb[kCWaveFloats + e]) + (rb[2 * kCWaveFloats + e] + rb[3 * kCWaveFloats + e]);
-            }
-        }
+        sum_to_part(wbase + 2048, kCWaveFloats, part_done + (long long)blockIdx.x * kPartFloats);
 #ifdef WN_MULTI_STAMPS
         MST(sg2);
 #endif
@@ -1178,24 +1187,9 @@ __device__ __forceinline__ void chain_body(
     // order for its 20 elements and writes the workgroup's partial tile with coalesced stores.  (The two-level tree it
     // replaces cost four barriers and left the 80 stores of the tile to one wave.)
     __syncthreads();                                   // every wave is done with its slot groups
-    {
-        float* red = wbase + wv * kPartFloats;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            red[(0 * 16 + r) * 64 + lane] = aWf0[r]; red[(1 * 16 + r) * 64 + lane] = aWf1[r];
-            red[(2 * 16 + r) * 64 + lane] = aWg0[r]; red[(3 * 16 + r) * 64 + lane] = aWg1[r];
-            red[(4 * 16 + r) * 64 + lane] = aWp[r];
-        }
-    }
+    acc_to_lds(wbase + wv * kPartFloats);
     __syncthreads();
-    {
-        float* __restrict__ o = part + (long long)blockIdx.x * kPartFloats;
-#pragma unroll
-        for (int i = 0; i < kPartFloats / (64 * NW); ++i) {
-            const int e = threadIdx.x + i * 64 * NW;
-            o[e] = (wbase[e] + wbase[kPartFloats + e]) + (wbase[2 * kPartFloats + e] + wbase[3 * kPartFloats + e]);
-        }
-    }
+    sum_to_part(wbase, kPartFloats, part + (long long)blockIdx.x * kPartFloats);
 }
 
 template <bool HAS_DO, bool HAS_U, bool HAS_DZ, bool FROM_Z, bool H2W>
@@ -1282,7 +1276,8 @@ __global__ void k_layer_bwd_reduce_all(const float* __restrict__ part, long long
     __syncthreads();
     if (sp != 0) return;
     const float acc = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-    const int tile = e >> 10, r = (e >> 6) & 15, ln = e & 63;
+    const int tile = e >> 10, x = e & 1023;                  // partial-tile layout: ((tile * 4 + r / 4) * 64 + lane) * 4 + r % 4
+    const int r = 4 * (x >> 8) + (x & 3), ln = (x >> 2) & 63;
     const int j = ln & 31, i = bch(r, ln >> 5);
     if (tile < 4) {
         float* dW = tile < 2 ? a.dWf[l] : a.dWg[l];
