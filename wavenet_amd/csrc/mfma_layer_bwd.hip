@@ -906,6 +906,11 @@ __device__ __forceinline__ void chain_body(
     //     float index ((k * 4 + r / 4) * 64 + lane) * 4 + r % 4        (k: Wf0, Wf1, Wg0, Wg1, Wp; r: accumulator register),
     // so that both the LDS traffic and the partial tile's stores are 128-bit (k_layer_bwd_reduce_all decodes the same layout)
     auto acc_to_lds = [&](float* red) {
+        if constexpr (MULTI) {
+            // a wait that gave up means this launch's results are void: make that LOUD -- a NaN in the layer's weight gradient
+            // (the next loss is NaN) instead of a silently wrong step.  (sync[0] says the same to whoever looks.)
+            if (gave_up) aWf0[0] = __builtin_nanf("");
+        }
         const f32x16* accs[5] = {&aWf0, &aWf1, &aWg0, &aWg1, &aWp};
 #pragma unroll
         for (int k = 0; k < 5; ++k)
