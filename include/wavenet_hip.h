@@ -231,6 +231,7 @@ int wn_btc_to_nchw(const float* src, float* dst, int B, int C, int T, void* stre
  * Persistent per-layer state in HBM: a ring of (fw-1)*d input columns per residual layer (and
  * per extra causal layer) instead of the reference's full-window caches that are rolled every
  * step; the head runs on the newest column only.                                               */
+#define WN_DECODER_ONE_WORKGROUP 64u
 typedef struct WnDecoderDesc {
     int Q, fw_causal, n_causal, fw, n_blocks, n_layers;  /* n_layers per block; dilation fw^l */
     int Cr, Cs, n_head;
@@ -245,7 +246,9 @@ typedef struct WnDecoderDesc {
     const float* const* Ws; const float* const* bs;
     const float* const* head_W; const float* const* head_b;                     /* n_head      */
     int head_act;                     /* WN_ACT_ELU for FasterWaveNet, WN_ACT_RELU for WaveNet  */
-    unsigned flags;                   /* WN_EXEC_FORCE_GENERIC: never the specialised 32/256-channel decode kernel */
+    unsigned flags;                   /* WN_EXEC_FORCE_GENERIC: never the specialised 32/256-channel decode kernel;
+                                         WN_DECODER_ONE_WORKGROUP: wn_decoder_run of that kernel on one workgroup instead of
+                                         three (chain | skip rows | head: same results, bit for bit) */
 } WnDecoderDesc;
 
 int wn_decoder_create(void** handle, const WnDecoderDesc* desc, void* stream);

@@ -112,6 +112,31 @@ def test_cfg4_decoder_2048_steps_match_the_committed_oracle_trace():
                                   err_msg="(%d of %d uniforms of the fixture were margin-replaced)" % (replaced, n))
 
 
+def test_cfg4_decoder_on_nine_workgroups_equals_the_one_workgroup_kernel():
+    """k_decode_fast3 (the chain on one CU, the skip rows and their share of the logits on eight more, flag-in-data exchange
+    through device memory) against k_decode_fast (WN_DECODER_ONE_WORKGROUP): same products, other summation order for the
+    skip rows (eight partial sums per row) and the logits (eight shares): 3,000 tokens equal, probabilities within 1e-6
+    (measured ~1e-7) -- a stale or torn exchange entry is a wrong addend, O(1e-2) -- and two runs of the nine-workgroup
+    form agree bit for bit (its order is fixed)."""
+    from wavenet_amd import _lib
+    u = np.random.RandomState(23).random_sample(3000)
+    res = []
+    for flags in (_lib.WN_DECODER_ONE_WORKGROUP, 0, 0):
+        net = FasterWaveNet(Params(R.make_params(**CFG2)), seed=1234)
+        net.exec_flags = flags
+        net.to_gpu()
+        toks, probs = net.generate(3000, u, return_probs=True)
+        torch.cuda.synchronize()
+        res.append((to_np(toks).copy(), to_np(probs).copy()))
+        del net
+    np.testing.assert_array_equal(res[1][0], res[2][0])
+    np.testing.assert_array_equal(res[1][1], res[2][1])
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=0, atol=1e-6)
+    assert np.abs(res[0][1] - res[1][1]).max() > 0            # and it really is the other kernel
+    assert len(set(res[0][0].tolist())) > 20
+
+
 def test_cfg2_full_batch_gradients_fp16x2_against_exact_fp32_on_the_device():
     """At the bench's full size (B = 8 x T = 16,384: 4,096 tiles per layer, one workgroup per CU in the chained backward)
     the oracle is out of reach (memory), but the exact-fp32-MFMA mode -- held to the oracle at T = 16,384, B = 2 above --

@@ -196,6 +196,7 @@ def stream_ptr() -> Optional[int]:
 GEMM_PRECISIONS = ("fp32", "bf16x3", "bf16", "fp16x2")
 WN_EXEC_FORCE_GENERIC, WN_EXEC_NO_FUSED_WIDE, WN_EXEC_NO_FWD_GROUPS, WN_EXEC_NO_PIPELINED_GEMM = 1, 2, 4, 8
 WN_EXEC_NO_MULTI_LAYER_BWD = 16
+WN_DECODER_ONE_WORKGROUP = 64          # WnDecoderDesc.flags: wn_decoder_run on one workgroup instead of three
 
 
 def default_exec_flags() -> int:
@@ -213,6 +214,8 @@ def default_exec_flags() -> int:
         f |= WN_EXEC_NO_PIPELINED_GEMM
     if os.environ.get("WAVENET_HIP_NO_MULTI_LAYER_BWD") == "1":
         f |= WN_EXEC_NO_MULTI_LAYER_BWD
+    if os.environ.get("WAVENET_HIP_DECODER_ONE_WORKGROUP") == "1":
+        f |= WN_DECODER_ONE_WORKGROUP
     return f
 
 

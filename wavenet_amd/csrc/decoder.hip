@@ -40,6 +40,7 @@ struct Decoder {
     size_t lds_bytes = 0;
     float* fastP = nullptr;       // packed weights of the specialised kernel (decoder_fast.hip), or NULL
     int head_bias_off = -1;
+    bool three_wgs = true;        // wn_decoder_run on three workgroups (decoder_fast.hip); WN_DECODER_ONE_WORKGROUP clears it
 };
 
 // the shape decoder_fast.hip is written for (BASELINE.json config 4 with the reference's default biases)
@@ -424,6 +425,7 @@ int wn_decoder_create(void** handle, const WnDecoderDesc* d, void* stream) {
     if (fast_shape(d)) {
         DEC_HIP(hipMalloc(&D->fastP, decode_fast_pack_floats(M.nlayers) * sizeof(float)));
         D->head_bias_off = D->heads[0].b;
+        D->three_wgs = !(d->flags & WN_DECODER_ONE_WORKGROUP);
     }
 #undef DEC_HIP
     rc = pack_weights(D, d, s);
@@ -488,7 +490,7 @@ int wn_decoder_step(void* handle, int32_t token, float* prob, int apply_softmax,
     if (D->fastP) {
         int rc = decode_fast_launch(D->fastP, D->meta.nlayers, D->head_bias_off >= 0 ? D->arena + D->head_bias_off : nullptr,
                                     D->arena + D->causal[0].w, D->d_layers, D->arena, D->tok_ring, D->step, 1, (int)token,
-                                    nullptr, nullptr, prob, D->meta.Q, apply_softmax, 0, D->meta.head_act,
+                                    nullptr, nullptr, prob, D->meta.Q, apply_softmax, 0, D->meta.head_act, false,
                                     as_stream(stream));
         if (rc) return rc;
         D->step += 1;
@@ -512,7 +514,7 @@ int wn_decoder_run(void* handle, int32_t first_token, const double* uniforms, in
         int rc = decode_fast_launch(D->fastP, D->meta.nlayers, D->head_bias_off >= 0 ? D->arena + D->head_bias_off : nullptr,
                                     D->arena + D->causal[0].w, D->d_layers, D->arena, D->tok_ring, D->step, n,
                                     (int)first_token, uniforms, out_tokens, prob_trace, D->meta.Q, 1, 1,
-                                    D->meta.head_act, as_stream(stream));
+                                    D->meta.head_act, D->three_wgs, as_stream(stream));
         if (rc) return rc;
         D->step += n;
         return WN_OK;

@@ -203,6 +203,25 @@ __device__ __forceinline__ void old_layer(const FastLds& S, const OldW& w, int l
 // second: the LDS pipeline serves them in that order, so a counter value >= l + 2 proves the data read saw wave 1's
 // write) and looked at only at the bottom: two LDS round trips (the spin's read, then the data's) left the 40-layer
 // critical path.  Wave 1 is normally many layers ahead; when it is not, the bounded spin and a second read follow.
+// zx != NULL (three-workgroup form): z also goes to the skip workgroup, every lane's value in ONE 8-byte store together with
+// the step's sequence number (flag-in-data: the reader spins on the entry itself, so no ordering between a data store and
+// a flag store is needed and the chain never waits for a store).
+#ifndef XSLEEP
+#define XSLEEP 1
+#endif
+typedef unsigned long long u64;
+__device__ __forceinline__ void xput(u64* p, float v, unsigned seq) {
+    __hip_atomic_store(p, ((u64)seq << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float xget(const u64* p, unsigned seq) {            // spin (bounded) until the entry is this step's
+    int spins = 0;
+    u64 w;
+    while ((unsigned)((w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != seq) {
+        __builtin_amdgcn_s_sleep(XSLEEP);
+        if (++spins > (1 << 21)) __builtin_trap();       // (a global poll is ~0.5 us: a second or two, then abort -- never a hang)
+    }
+    return __uint_as_float((unsigned)w);
+}
 __device__ __forceinline__ float chain_layer(const FastLds& S, const ChainW& w, float& a_old, int l, int nlayers, int lane,
                                              float xc) {
     int c_next = 0;
@@ -508,11 +527,294 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
     if (tid == 0) tok_ring[0] = s_tok[1];          // the token before the next one to be consumed
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same decode on NINE workgroups (nine CUs).  A step of k_decode_fast streams 2.5 MB of fp32 weights into one CU --
+// 69.5 k cycles at the 36 B/clk one CU gets out of L2, which is the step time whatever the four waves do (DESIGN.md,
+// round 3) -- and runs head, softmax and sampling (18 k cycles) behind the 40-layer chain.  Here
+//   workgroup 0      keeps the chain (wave 0), the x[n-d] halves (wave 1), softmax and the numpy-compatible sampler; its
+//                    wave 2 follows the chain through the LDS layer counter and publishes every layer's z to the others
+//                    (the chain wave itself must not store: vector-memory operations retire in order, and a write-through
+//                    store in its queue held back the next layer's weight loads -- 60 k cycles for the chain instead of 49);
+//   workgroups 1..8  own 32 skip rows each and keep their slice of ALL layers' skip weights in REGISTERS for the whole
+//                    launch (thread = (row, eighth of the 32 gate channels): one float4 per layer, 40 float4): no weight
+//                    streaming, a layer costs four FMAs; they poll eight layers of z per memory round trip;
+//                    and, having their 32 activated skip values, add those columns' share of EVERY logit (thread q: 32 more
+//                    resident weights of head row q) -- workgroup 0 adds the eight shares: no separate head hop.
+// Exchange is through `X` in device memory, flag-in-data: every float travels in an 8-byte entry with the step's
+// sequence number (xput / xget above), written once and polled by its reader; entries are zeroed by a kernel before the
+// launch.  Two hops follow the chain's last layer (z -> partial logits -> workgroup 0).  Skip rows and logits are summed
+// in another order than k_decode_fast's (eight partial sums per row added pairwise; eight shares per logit): probabilities agree to rounding
+// (~1e-7), not bit for bit; the launch itself is deterministic.  At most 40 layers (the weights must fit the registers).
+// ---------------------------------------------------------------------------------------------
+static constexpr int kXZ = 0;                                   // X layout (u64 entries): z [L][64] | partial logits [8][256]
+static constexpr int kD10MaxL = 40;
+static constexpr int kD10Skip = 8;                              // skip workgroups
+__device__ __forceinline__ int x_pl(int nlayers) { return nlayers * 64; }
+
+__global__ __launch_bounds__(kFT, 1) void k_decode_fast3(
+    const float* __restrict__ P, const float* __restrict__ Ph, const float* __restrict__ hbias,
+    const float* __restrict__ E, const DecLayer* __restrict__ layers, int nlayers, float* __restrict__ arena,
+    int* __restrict__ tok_ring, long long n0, int nsteps, int first_token, const double* __restrict__ uniforms,
+    int32_t* __restrict__ out_tokens, float* __restrict__ prob_out, int prob_stride, int apply_softmax,
+    int do_sample, int head_act, u64* __restrict__ X) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+
+    if (blockIdx.x >= 1 && blockIdx.x <= kD10Skip) {
+        // ---- 32 skip rows: thread (r = tid / 8, s = tid % 8) holds Ws_l[row][4 s .. 4 s + 3] of every layer ----
+        float* zs = sm;                                               // [L][32]
+        float* hs = sm + kD10MaxL * 32;                               // [32]
+        const int row = 32 * (blockIdx.x - 1) + (tid >> 3), sl = tid & 7;
+        float4 wh[8];                                                 // head row `tid`, the 32 columns of this workgroup's skip rows
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) wh[jj] = *reinterpret_cast<const float4*>(Ph + (8 * (blockIdx.x - 1) + jj) * 1024 + 4 * tid);
+        float4 w[kD10MaxL];
+#pragma unroll
+        for (int l = 0; l < kD10MaxL; ++l)
+            w[l] = l < nlayers ? *reinterpret_cast<const float4*>(P + (long long)l * kLayerFloats + kGateFloats + kProjFloats +
+                                                                  ((row & 1) * 8 + sl) * 512 + 4 * (row >> 1))
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int it = 0; it < nsteps; ++it) {
+            const unsigned seq = (unsigned)(it + 1);
+            float acc = 0.f;
+#pragma unroll
+            for (int l0 = 0; l0 < kD10MaxL; l0 += 8) {
+                if (l0 < nlayers) {
+                    // a poll is a round trip to memory: the four waves fetch EIGHT layers per round trip (wave w the layers
+                    // l0 + 2 w and l0 + 2 w + 1, one per half wave) into a shared table; the chain needs ~0.55 us per layer
+                    const int lp = l0 + 2 * wv + (lane >> 5);
+                    if (lp < nlayers) zs[lp * 32 + (lane & 31)] = xget(X + kXZ + lp * 64 + (lane & 31), seq);
+                    lds_barrier();
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (l0 + u < nlayers) acc += dot4(w[l0 + u], *reinterpret_cast<const float4*>(zs + (l0 + u) * 32 + 4 * sl));
+                }
+            }
+            // the row's eight partial sums, pairwise (lanes 8 r .. 8 r + 7 of a row of 16 DPP lanes: xor 1, 2, then 4)
+            acc += dpp_f(acc, 101);
+            acc += dpp_f(acc, 102);
+            acc += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(acc), 0x101F));    // xor 4 inside groups of 32
+            // this workgroup's 32 activated skip values -> LDS, then its share of EVERY logit: thread q adds the 32 products
+            // of head row q with them (8 float4 of head weights per thread, resident); workgroup 0 adds the eight shares
+            if (sl == 0) hs[tid >> 3] = act_apply(acc, head_act);
+            lds_barrier();
+            float pl = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) pl += dot4(wh[jj], *reinterpret_cast<const float4*>(hs + 4 * jj));
+            xput(X + x_pl(nlayers) + (blockIdx.x - 1) * 256 + tid, pl, seq);
+            lds_barrier();                                            // zs / hs are rewritten by the next step
+        }
+        return;
+    }
+    // ---- workgroup 0: the chain, softmax, sampling (k_decode_fast without its skip waves and head) ----
+    float* Elds = sm;                                   // [256][2][32] embedding table of the causal layer
+    float* xold = Elds + 256 * 2 * 32;
+    float* xcur = xold + kMaxFastLayers * 32;
+    float* zall = xcur + (kMaxFastLayers + 1) * 32;
+    float* hvec = zall + kMaxFastLayers * 32;
+    float* lg = hvec + 256;
+    float* red = lg + 256;
+    double* cdf = reinterpret_cast<double*>(red + 16);
+    int* s_tok = reinterpret_cast<int*>(cdf + 256);
+    int* ringt = s_tok + 4;
+    int* dmask = ringt + kMaxFastLayers;
+    int* ready = dmask + kMaxFastLayers;
+    float* aold = reinterpret_cast<float*>(ready + 4);
+    for (int i = tid; i < 256 * 2 * 32 / 4; i += kFT)
+        reinterpret_cast<float4*>(Elds)[i] = reinterpret_cast<const float4*>(E)[i];
+    for (int i = tid; i < nlayers; i += kFT) { ringt[i] = layers[i].ring; dmask[i] = layers[i].d - 1; }
+    if (tid == 0) { s_tok[0] = first_token; s_tok[1] = tok_ring[0]; }
+    const float hb = hbias ? hbias[tid] : 0.f;
+    __syncthreads();
+    FastLds S{xold, xcur, zall, aold, ready, ready + 1};
+
+    for (int it = 0; it < nsteps; ++it) {
+        const unsigned n = (unsigned)(n0 + it);
+        const unsigned seq = (unsigned)(it + 1);
+        const int token = s_tok[0], tprev = s_tok[1];
+        const double u_draw = do_sample ? uniforms[it] : 0.0;
+#ifdef WN_DEC3_STAMPS
+        long long st0 = clock64();
+#endif
+        if (it == 0) {                                    // later steps: fetched during the previous step's wait (below)
+            for (int i = tid; i < nlayers * 32; i += kFT) {
+                const int l = i >> 5;
+                xold[i] = arena[ringt[l] + (long long)(n & (unsigned)dmask[l]) * 32 + (i & 31)];
+            }
+        }
+        if (tid < 32) xcur[tid] = Elds[(tprev * 2 + 0) * 32 + tid] + Elds[(token * 2 + 1) * 32 + tid];
+        if (tid == 0) {
+            __hip_atomic_store(ready, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(ready + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (wv == 0) {
+            ChainW w[2];
+            load_chain(w[0], P, 0, 4u * lane);
+            __syncthreads();
+            float xc = xcur[lane & 31];
+            wait_count(S.ready_old, 1);
+            float a_old = aold[lane];
+            for (int l0 = 0; l0 < nlayers; l0 += kUnroll) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const int l = l0 + u;
+                    if (l < nlayers) {
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                        if (l + 1 < nlayers) load_chain(w[(u + 1) & 1], P, l + 1, 4u * lane);
+                        xc = chain_layer(S, w[u & 1], a_old, l, nlayers, lane, xc);
+                    }
+                }
+            }
+        } else if (wv == 1) {
+            OldW wo[2];
+            load_old(wo[0], P, 0, 4u * lane);
+            __syncthreads();
+            for (int l0 = 0; l0 < nlayers; l0 += kUnroll) {
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    const int l = l0 + u;
+                    if (l < nlayers) {
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                        if (l + 1 < nlayers) load_old(wo[(u + 1) & 1], P, l + 1, 4u * lane);
+                        old_layer(S, wo[u & 1], l, lane);
+                    }
+                }
+            }
+        } else if (wv == 2) {
+            __syncthreads();
+            // the publisher: follows the chain through the layer counter in LDS and hands every layer's z to the other CUs
+            for (int l = 0; l < nlayers; ++l) {
+                wait_layer(S, l + 1);
+                xput(X + kXZ + l * 64 + lane, zall[l * 32 + (lane & 31)], seq);
+            }
+        } else {
+            __syncthreads();
+        }
+        lds_barrier();                                    // the chain has written every x_cur
+#ifdef WN_DEC3_STAMPS
+        long long st1 = clock64();
+#endif
+        for (int i = tid; i < nlayers * 32; i += kFT) {   // this step's x_cur of every layer becomes the newest ring column
+            const int l = i >> 5;
+            const unsigned dm = (unsigned)dmask[l];
+            float* ring = arena + ringt[l] + (i & 31);
+            const float xn = xcur[i];
+            ring[(long long)(n & dm) * 32] = xn;
+            // ... and the NEXT step's x[n + 1 - d] is fetched now, under the wait for the logits: with d = 1 it is the value just
+            // stored, otherwise a column written d - 1 steps ago (the chain and wave 1 are through with xold: barrier above)
+            xold[i] = dm == 0u ? xn : ring[(long long)((n + 1u) & dm) * 32];
+        }
+        // logit `tid` = bias + the eight workgroups' shares, added in workgroup order.  The eight entries are requested
+        // together (one memory round trip), re-requested together until all carry this step's number
+        float v;
+        {
+            const u64* e = X + x_pl(nlayers) + tid;
+            u64 wd[kD10Skip];
+            int spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < kD10Skip; ++k) wd[k] = __hip_atomic_load(e + k * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int k = 0; k < kD10Skip; ++k) ok = ok && (unsigned)(wd[k] >> 32) == seq;
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 21)) __builtin_trap();
+            }
+            v = hb;
+#pragma unroll
+            for (int k = 0; k < kD10Skip; ++k) v += __uint_as_float((unsigned)wd[k]);
+        }
+#ifdef WN_DEC3_STAMPS
+        long long st2 = clock64();
+#endif
+        if (apply_softmax) {
+            float m = wave_allmax(v);
+            if (lane == 0) red[wv] = m;
+            lds_barrier();
+            m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            const float e = expf(v - m);
+            float s = wave_allsum(e);
+            if (lane == 0) red[4 + wv] = s;
+            lds_barrier();
+            s = red[4] + red[5] + red[6] + red[7];
+            v = e * (1.f / s);
+        }
+        lg[tid] = v;
+        if (prob_out) prob_out[(long long)it * prob_stride + tid] = v;
+        lds_barrier();
+        if (do_sample) {
+            double c = wave_scan_f64((double)lg[tid]);
+            if (lane == 63) cdf[wv] = c;
+            lds_barrier();
+            {
+                const double w0 = cdf[0], w1 = cdf[1], w2 = cdf[2], w3 = cdf[3];
+                c += wv > 0 ? w0 : 0.0;
+                c += wv > 1 ? w1 : 0.0;
+                c += wv > 2 ? w2 : 0.0;
+                const double tot = ((w0 + w1) + w2) + w3;
+                const double q = c / tot;
+                const bool gt = q > u_draw;
+                const bool near = fabs(q - u_draw) < 1e-12;
+                const unsigned long long bal = __ballot(gt), nb = __ballot(near);
+                if (lane == 0) {
+                    reinterpret_cast<int*>(red)[8 + wv] = bal ? wv * 64 + __ffsll((long long)bal) - 1 : 256;
+                    reinterpret_cast<int*>(red)[12 + wv] = nb ? 1 : 0;
+                }
+            }
+            lds_barrier();
+            const int* rr = reinterpret_cast<const int*>(red);
+            const bool ambiguous = (rr[12] | rr[13] | rr[14] | rr[15]) != 0;
+            if (ambiguous) {
+                if (tid == 0) {
+                    double cs = 0.0;
+                    for (int i = 0; i < 256; ++i) { cs += (double)lg[i]; cdf[i] = cs; }
+                }
+                lds_barrier();
+                {
+                    const double tot = cdf[255];
+                    const bool gt = cdf[tid] / tot > u_draw;
+                    const unsigned long long bal = __ballot(gt);
+                    lds_barrier();
+                    if (lane == 0) reinterpret_cast<int*>(red)[8 + wv] = bal ? wv * 64 + __ffsll((long long)bal) - 1 : 256;
+                }
+                lds_barrier();
+            }
+            if (tid == 0) {
+                const int* r = reinterpret_cast<const int*>(red) + 8;
+                int idx = min(min(r[0], r[1]), min(r[2], r[3]));
+                if (idx > 255) idx = 255;
+                out_tokens[it] = idx;
+                s_tok[1] = token;
+                s_tok[0] = idx;
+            }
+        } else if (tid == 0) {
+            s_tok[1] = token;
+        }
+        __syncthreads();                           // full barrier: orders this step's ring stores before the next step's loads
+#ifdef WN_DEC3_STAMPS
+        if (tid == 0) {
+            u64* D = X + nlayers * 64 + 8 * 256;
+            D[0] += (u64)(st1 - st0); D[1] += (u64)(st2 - st1); D[2] += (u64)(clock64() - st2); D[3] += 1;
+        }
+#endif
+    }
+    if (tid == 0) tok_ring[0] = s_tok[1];
+}
+
+static u64* g_dbg_decX = nullptr;
+static int g_dbg_decL = 0;
+__global__ void k_decode_zero_x(u64* X, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) X[i] = 0ull;
+}
+
 size_t decode_fast_lds_bytes() {
     return (size_t)(256 * 2 * 32 + kMaxFastLayers * 32 + (kMaxFastLayers + 1) * 32 + kMaxFastLayers * 32 + 256 + 256 + 16) * 4 +
            256 * 8 + (4 + 2 * kMaxFastLayers + 4) * 4 + kMaxFastLayers * 64 * 4;
 }
-size_t decode_fast_pack_floats(int nlayers) { return (size_t)nlayers * kLayerFloats + 256 * 256; }
+size_t decode_fast_pack_floats(int nlayers) {            // weights, then the exchange entries of the three-workgroup form (8 bytes each)
+    return (size_t)nlayers * kLayerFloats + 256 * 256 + 2 * ((size_t)nlayers * 64 + 8 * 256 + 16);
+}
 
 int decode_fast_pack(const WnDecoderDesc* d, float* dst, hipStream_t s) {
     const int L = d->n_blocks * d->n_layers;
@@ -527,12 +829,26 @@ int decode_fast_pack(const WnDecoderDesc* d, float* dst, hipStream_t s) {
 int decode_fast_launch(const float* P, int nlayers, const float* hbias, const float* E, const DecLayer* layers,
                        float* arena, int* tok_ring, long long n0, int nsteps, int first_token,
                        const double* uniforms, int32_t* out_tokens, float* prob_out, int prob_stride,
-                       int apply_softmax, int do_sample, int head_act, hipStream_t s) {
+                       int apply_softmax, int do_sample, int head_act, bool three_wgs, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
         WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_fast),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)decode_fast_lds_bytes()));
+        WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_fast3),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)decode_fast_lds_bytes()));
         attr = true;
+    }
+    if (three_wgs && nsteps > 1 && nsteps < (1 << 30) && nlayers <= kD10MaxL) {
+        // the exchange entries live behind the packed weights (decode_fast_pack_floats); cleared by a kernel, in stream order
+        u64* X = reinterpret_cast<u64*>(const_cast<float*>(P) + (size_t)nlayers * kLayerFloats + 256 * 256);
+        const int nx = nlayers * 64 + 8 * 256 + 16;
+        g_dbg_decX = X; g_dbg_decL = nlayers;
+        hipLaunchKernelGGL(k_decode_zero_x, dim3(cdiv(nx, 256)), dim3(256), 0, s, X, nx);
+        hipLaunchKernelGGL(k_decode_fast3, dim3(kD10Skip + 1), dim3(kFT), decode_fast_lds_bytes(), s, P,
+                           P + (size_t)nlayers * kLayerFloats, hbias, E, layers, nlayers, arena, tok_ring, n0, nsteps,
+                           first_token, uniforms, out_tokens, prob_out, prob_stride, apply_softmax, do_sample, head_act, X);
+        WN_LAUNCH_CHECK();
+        return WN_OK;
     }
     hipLaunchKernelGGL(k_decode_fast, dim3(1), dim3(kFT), decode_fast_lds_bytes(), s, P,
                        P + (size_t)nlayers * kLayerFloats, hbias, E, layers, nlayers, arena, tok_ring, n0, nsteps,
@@ -542,3 +858,10 @@ int decode_fast_launch(const float* P, int nlayers, const float* hbias, const fl
 }
 
 }  // namespace wn
+
+#ifdef WN_DEC3_STAMPS
+extern "C" int wn_debug_dec3_stamps(unsigned long long* dst) {
+    if (!wn::g_dbg_decX) return -1;
+    return (int)hipMemcpy(dst, wn::g_dbg_decX + wn::g_dbg_decL * 64 + 8 * 256, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+#endif

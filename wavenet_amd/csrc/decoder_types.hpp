@@ -13,5 +13,5 @@ int decode_fast_pack(const WnDecoderDesc* d, float* dst, hipStream_t s);
 int decode_fast_launch(const float* P, int nlayers, const float* hbias, const float* E, const DecLayer* layers,
                        float* arena, int* tok_ring, long long n0, int nsteps, int first_token,
                        const double* uniforms, int32_t* out_tokens, float* prob_out, int prob_stride,
-                       int apply_softmax, int do_sample, int head_act, hipStream_t s);
+                       int apply_softmax, int do_sample, int head_act, bool three_wgs, hipStream_t s);
 }  // namespace wn
