@@ -802,8 +802,10 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast3(
     if (tid == 0) tok_ring[0] = s_tok[1];
 }
 
-static u64* g_dbg_decX = nullptr;
+#ifdef WN_DEC3_STAMPS
+static u64* g_dbg_decX = nullptr;        // diagnostic build only: where wn_debug_dec3_stamps finds the last launch's stamps
 static int g_dbg_decL = 0;
+#endif
 __global__ void k_decode_zero_x(u64* X, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) X[i] = 0ull;
 }
@@ -842,7 +844,9 @@ int decode_fast_launch(const float* P, int nlayers, const float* hbias, const fl
         // the exchange entries live behind the packed weights (decode_fast_pack_floats); cleared by a kernel, in stream order
         u64* X = reinterpret_cast<u64*>(const_cast<float*>(P) + (size_t)nlayers * kLayerFloats + 256 * 256);
         const int nx = nlayers * 64 + 8 * 256 + 16;
+#ifdef WN_DEC3_STAMPS
         g_dbg_decX = X; g_dbg_decL = nlayers;
+#endif
         hipLaunchKernelGGL(k_decode_zero_x, dim3(cdiv(nx, 256)), dim3(256), 0, s, X, nx);
         hipLaunchKernelGGL(k_decode_fast3, dim3(kD10Skip + 1), dim3(kFT), decode_fast_lds_bytes(), s, P,
                            P + (size_t)nlayers * kLayerFloats, hbias, E, layers, nlayers, arena, tok_ring, n0, nsteps,
