@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -174,19 +175,82 @@ def test_eve_loss_feedback_scalars_follow_the_reference_recurrence():
                             softmax_conv_channels=[8, 16], optimizer="no-such-rule")))
 
 
-def test_hdf5_checkpoint_import_is_guarded():
-    """The reference's checkpoints are Chainer HDF5 files; reading them needs h5py, which this image lacks: a clear error,
-    not a crash at import time (and the .npz path with the same key names keeps working)."""
+_TINY = dict(quantization_steps=16, causal_conv_channels=[4], residual_conv_channels=[4, 4], residual_num_blocks=2,
+             softmax_conv_channels=[8, 16])
+_H5 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chainer_layout_tiny.h5")
+_H5_NPZ = _H5[:-3] + ".npz"
+
+
+def _need_hdf5():
+    from wavenet_amd import hdf5_io
+    if not hdf5_io.available():
+        pytest.skip("no HDF5 C library on this machine")
+    return hdf5_io
+
+
+def test_hdf5_checkpoint_written_by_h5py_is_imported():
+    """wavenet.py:627-639 reads `wavenet.model`, a Chainer HDF5 file.  tests/golden/chainer_layout_tiny.h5 was written by
+    h5py itself in the layout Chainer's HDF5Serializer produces (groups per link, gzip-4 datasets W / b;
+    tests/golden/make_hdf5_fixture.py): load_hdf5 must put exactly those arrays into the model."""
+    _need_hdf5()
     from wavenet_amd import Params, WaveNet
-    net = WaveNet(Params(dict(quantization_steps=16, causal_conv_channels=[4], residual_conv_channels=[4], residual_num_blocks=1,
-                              softmax_conv_channels=[8, 16])))
-    try:
-        import h5py  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError, match="h5py"):
-            net.load_hdf5("/nonexistent/wavenet.model")
-    keys = sorted(net.state_dict())
-    assert "causal_0/W" in keys and "residual_0_block_0_wf/W" in keys and "softmax_0/b" in keys     # Chainer's dataset paths
+    net = WaveNet(Params(_TINY), seed=99)                             # other weights than the file's
+    with np.load(_H5_NPZ) as z:
+        want = {k: z[k] for k in z.files}
+    assert any(not np.array_equal(net.state_dict()[k], want[k]) for k in want)
+    net.load_hdf5(_H5)
+    got = net.state_dict()
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k].dtype == np.float32 and np.array_equal(got[k], want[k]), k
+    assert "causal_0/W" in got and "residual_0_block_0_wf/W" in got and "softmax_0/W" in got      # Chainer's dataset paths
+
+
+def test_hdf5_checkpoint_round_trip_and_load_prefers_the_reference_file(tmp_path):
+    """save_hdf5 writes the container the reference's own load() reads; load() picks a bare `wavenet.model` up."""
+    hdf5_io = _need_hdf5()
+    from wavenet_amd import Params, WaveNet
+    a = WaveNet(Params(_TINY), seed=3)
+    a.save_hdf5(str(tmp_path / "wavenet.model"))
+    raw = hdf5_io.read_datasets(str(tmp_path / "wavenet.model"))
+    assert sorted(raw) == sorted(a.state_dict())
+    b = WaveNet(Params(_TINY), seed=4)
+    b.load(str(tmp_path))                                             # no .npz there: the HDF5 file is the checkpoint
+    for k, v in a.state_dict().items():
+        assert np.array_equal(b.state_dict()[k], v), k
+    # a file of another model is refused, not half-loaded
+    c = WaveNet(Params(dict(_TINY, residual_conv_channels=[4, 4, 4])), seed=4)
+    with pytest.raises(KeyError):
+        c.load_hdf5(str(tmp_path / "wavenet.model"))
+    d = WaveNet(Params(dict(_TINY, causal_conv_channels=[6])), seed=4)
+    with pytest.raises(Exception, match="shape of"):
+        d.load_hdf5(str(tmp_path / "wavenet.model"))
+    with pytest.raises(OSError):
+        b.load_hdf5(str(tmp_path / "missing.model"))
+
+
+def test_hdf5_files_written_here_are_read_by_h5py(tmp_path):
+    """The other direction, when the image's second interpreter (the one that has h5py) exists: h5py must see float32
+    datasets at Chainer's paths with the values written."""
+    hdf5_io = _need_hdf5()
+    py39 = "/opt/conda/bin/python3.9"
+    if not os.path.exists(py39) or subprocess.run([py39, "-c", "import h5py"], capture_output=True).returncode != 0:
+        pytest.skip("no interpreter with h5py on this machine")
+    rng = np.random.RandomState(2)
+    arrays = {"causal_0/W": rng.standard_normal((4, 16, 1, 2)).astype(np.float32),
+              "causal_0/b": rng.standard_normal(4).astype(np.float32), "t": np.asarray(7)}
+    fn = str(tmp_path / "w.model")
+    hdf5_io.write_datasets(fn, arrays)
+    code = ("import h5py, numpy as np, sys\n"
+            "f = h5py.File(sys.argv[1], 'r')\n"
+            "w = f['causal_0/W']\n"
+            "assert w.dtype == np.float32 and w.shape == (4, 16, 1, 2) and w.compression == 'gzip' and w.compression_opts == 4\n"
+            "assert f['t'].shape == () and int(f['t'][()]) == 7\n"
+            "np.save(sys.argv[2], np.concatenate([np.asarray(w).ravel(), np.asarray(f['causal_0/b'])]))\n")
+    r = subprocess.run([py39, "-c", code, fn, str(tmp_path / "back.npy")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    back = np.load(str(tmp_path / "back.npy"))
+    assert np.array_equal(back, np.concatenate([arrays["causal_0/W"].ravel(), arrays["causal_0/b"]]))
 
 
 def test_get_optimizer_names_and_the_setters():

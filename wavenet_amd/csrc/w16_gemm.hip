@@ -255,6 +255,11 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int spk = a.ksrc >> 6;                         // stages per source
     const int nst = a.nsrc * spk;
     const int lr = lane >> 3, lp = lane & 7;
+    // The epilogue's arguments are fetched HERE: hipcc otherwise hoists their s_load to just in front of the stage loop, and
+    // with a scalar load pending at the loop's entry (scalar loads return out of order) it can no longer count the LDS reads
+    // in flight -- it put s_waitcnt lgkmcnt(0) behind the six fresh reads of every stage's first k-step (now lgkmcnt(6)).
+    // Measured: no difference in time -- like every other instruction-level change to this kernel.
+    asm volatile("" ::"s"(a.out), "s"(a.bias), "s"(a.ldo), "s"(a.ob_stride), "s"(a.ob_col), "s"(a.rows_per_b), "s"(a.x_src_stride));
 
     // Requests as `scalar base + fixed 32-bit lane offset`: the rows and chunk positions a lane copies do not change from
     // stage to stage, only the uniform k offset (and source) does.  (With a 64-bit pointer per piece computed in vector

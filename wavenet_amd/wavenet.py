@@ -959,27 +959,42 @@ class WaveNet(object):
             ptr_array([lay.projection_softmax.b for lay in L]), int_array([lay.cd for lay in L]), ptr(skip), B, T,
             t_off, Tw, self._Cs, 0, self._exec(B), stream_ptr()), "wn_skip_sum_fwd")
 
-    # -- checkpoints (wavenet.py:619-639): reference key names, .npz container (h5py is absent) --
+    # -- checkpoints (wavenet.py:619-639): reference key names; .npz for weights + optimizer, and the reference's own
+    #    HDF5 container for the weights (read and written through h5py when importable, else through the HDF5 C library:
+    #    hdf5_io.py) --
     def save(self, model_dir="./"):
         os.makedirs(model_dir, exist_ok=True)
         np.savez(os.path.join(model_dir, "wavenet.model.npz"), **self.state_dict())
         np.savez(os.path.join(model_dir, "wavenet.opt.npz"), **self.optimizer.state_dict())
 
+    def save_hdf5(self, filename):
+        """The weights in the file format and layout of the reference's ``serializers.save_hdf5(model_dir +
+        "/wavenet.model", self.chain)`` (wavenet.py:619-625): one group per link, datasets ``W`` and ``b``, gzip 4 --
+        a file the reference's ``load`` (wavenet.py:627-639) reads."""
+        from . import hdf5_io
+        hdf5_io.write_datasets(filename, self.state_dict(), compression=4)
+
     def load_hdf5(self, filename):
         """Weights saved by the reference itself (``serializers.save_hdf5(model_dir + "/wavenet.model", self.chain)``,
         wavenet.py:619-625): Chainer writes one dataset per parameter at ``<link name>/W`` and ``<link name>/b`` -- the
-        key names of :meth:`state_dict`.  Needs h5py (not in this image: the import is attempted here, not at module load)."""
+        key names of :meth:`state_dict`.  Read with h5py when it is importable, otherwise with the HDF5 C library through
+        ``hdf5_io`` (ImportError, naming what was looked for, when neither exists).  A file that lacks one of the model's
+        parameters, or holds it in another shape, is refused (KeyError / Exception from :meth:`load_state_dict`) -- the
+        reference's deserializer fails on such a file too."""
         try:
             import h5py
-        except ImportError as e:
-            raise ImportError("reading the reference's HDF5 checkpoints needs h5py (%s); convert to .npz with the same "
-                              "keys (%s, ...) instead" % (e, ", ".join(sorted(self.state_dict())[:2])))
-        sd = {}
-        with h5py.File(filename, "r") as f:
-            def visit(name, obj):
-                if isinstance(obj, h5py.Dataset):
-                    sd[name] = np.asarray(obj)
-            f.visititems(visit)
+        except ImportError:
+            h5py = None
+        if h5py is not None:
+            sd = {}
+            with h5py.File(filename, "r") as f:
+                def visit(name, obj):
+                    if isinstance(obj, h5py.Dataset):
+                        sd[name] = np.asarray(obj)
+                f.visititems(visit)
+        else:
+            from . import hdf5_io
+            sd = hdf5_io.read_datasets(filename)
         self.load_state_dict({k: v for k, v in sd.items() if k in self.state_dict()})
 
     def load(self, model_dir="./"):
