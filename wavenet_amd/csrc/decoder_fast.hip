@@ -122,17 +122,38 @@ __global__ void k_pack_fast_head(const float* __restrict__ Wh, float* __restrict
         for (int e = 0; e < 4; ++e) dst[(j * 256 + tid) * 4 + e] = Wh[tid * 256 + 4 * j + e];
 }
 
-struct ChainW { float4 g[8]; float4 p[8]; };      // gate rows, x[n] half | projection rows
+typedef float f4v __attribute__((ext_vector_type(4)));
+struct ChainW { f4v g[8]; f4v p[8]; };            // gate rows, x[n] half | projection rows
 struct OldW { float4 g[8]; };                      // gate rows, x[n-d] half (wave 1)
 struct SkipW { float4 s[16]; };
 
-// uniform plane base (SGPRs) + a 32-bit per-lane offset: global_load with an saddr, no 64-bit VALU adds
-__device__ __forceinline__ void load_chain(ChainW& w, const float* __restrict__ P, int l, unsigned l4) {
+// The chain wave's 16 loads of a layer: uniform layer base in an SGPR pair + one of four loop-invariant 32-bit lane
+// offsets + an immediate (the immediate reaches 4 KB, the 16 planes of a layer span 16 KB).  Written as asm: from the C
+// form hipcc built a 64-bit address per group in vector registers (eleven VALU / carry instructions per layer on the
+// chain's critical path).  The loads are invisible to the compiler's counters: chain_run() waits for them itself
+// (s_waitcnt vmcnt(0) at the top of the layer that uses them) and re-defines the registers behind that wait.
+struct ChainOff { unsigned o[4]; };                // byte offsets 16 lane + 8192 + 4096 k
+__device__ __forceinline__ ChainOff chain_offsets(int lane) {
+    ChainOff c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c.o[k] = 16u * lane + 8192u + 4096u * k;
+    return c;
+}
+#define WN_CHAIN_LD(dst, off, imm) \
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #imm : "=v"(dst) : "v"(off), "s"(b))
+__device__ __forceinline__ void load_chain(ChainW& w, const float* __restrict__ P, int l, const ChainOff& c) {
     const float* b = P + (long long)l * kLayerFloats;
+    WN_CHAIN_LD(w.g[0], c.o[0], 0); WN_CHAIN_LD(w.g[1], c.o[0], 1024); WN_CHAIN_LD(w.g[2], c.o[0], 2048); WN_CHAIN_LD(w.g[3], c.o[0], 3072);
+    WN_CHAIN_LD(w.g[4], c.o[1], 0); WN_CHAIN_LD(w.g[5], c.o[1], 1024); WN_CHAIN_LD(w.g[6], c.o[1], 2048); WN_CHAIN_LD(w.g[7], c.o[1], 3072);
+    WN_CHAIN_LD(w.p[0], c.o[2], 0); WN_CHAIN_LD(w.p[1], c.o[2], 1024); WN_CHAIN_LD(w.p[2], c.o[2], 2048); WN_CHAIN_LD(w.p[3], c.o[2], 3072);
+    WN_CHAIN_LD(w.p[4], c.o[3], 0); WN_CHAIN_LD(w.p[5], c.o[3], 1024); WN_CHAIN_LD(w.p[6], c.o[3], 2048); WN_CHAIN_LD(w.p[7], c.o[3], 3072);
+}
+#undef WN_CHAIN_LD
+// ... and the wait: everything this wave has in flight has landed, and no use of `w` can be scheduled above this point
+__device__ __forceinline__ void chain_landed(ChainW& w) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w.g[j] = *reinterpret_cast<const float4*>(b + (8 + j) * 256 + l4);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) w.p[j] = *reinterpret_cast<const float4*>(b + kGateFloats + j * 256 + l4);
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(w.g[j]), "+v"(w.p[j]));
 }
 __device__ __forceinline__ void load_old(OldW& w, const float* __restrict__ P, int l, unsigned l4) {
     const float* b = P + (long long)l * kLayerFloats;
@@ -222,11 +243,10 @@ __device__ __forceinline__ float xget(const u64* p, unsigned seq) {            /
     }
     return __uint_as_float((unsigned)w);
 }
-__device__ __forceinline__ float chain_layer(const FastLds& S, const ChainW& w, float& a_old, int l, int nlayers, int lane,
-                                             float xc) {
+__device__ __forceinline__ float chain_layer(const FastLds& S, const ChainW& w, float& a_old, int l, const bool more,
+                                             int lane, float xc) {
     int c_next = 0;
     float a_next = 0.f;
-    const bool more = l + 1 < nlayers;
     if (more) {
         c_next = __hip_atomic_load(S.ready_old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -269,7 +289,7 @@ __device__ __forceinline__ float chain_layer(const FastLds& S, const ChainW& w, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     if (lane == 0) __hip_atomic_store(S.ready, l + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (more) {
-        if (__builtin_amdgcn_readfirstlane(c_next) < l + 2) {       // rare: wave 1 has not been here yet
+        if (__builtin_expect(__builtin_amdgcn_readfirstlane(c_next) < l + 2, 0)) {       // rare: wave 1 has not been here yet
             wait_count(S.ready_old, l + 2);
             a_next = S.aold[(l + 1) * 64 + lane];
         }
@@ -297,6 +317,29 @@ __device__ __forceinline__ void skip_layer(const FastLds& S, const SkipW& w, int
 #endif
 
 static constexpr int kUnroll = 10;      // layers per trip of the layer loop (one block of the 4 x 10 stack)
+
+// The chain wave's walk over the layers of one step.  Layer l's weights were requested a whole layer ago (an L2 hit lands in
+// a fifth of that): the wait in front of the next request costs nothing.
+// WHOLE: the stack is a whole number of kUnroll-layer trips (the 4 x 10 stack is): "is there a layer l?" and "is there a
+// layer l + 1?" are then compile-time facts for nine layers of ten -- each was three scalar branches on the chain's
+// critical path.
+template <bool WHOLE>
+__device__ __forceinline__ float chain_run(const FastLds& S, const float* __restrict__ P, int nlayers, int lane, float xc,
+                                           float a_old, ChainW (&w)[2], const ChainOff& co) {   // w[0]: layer 0's weights, requested by the caller
+    for (int l0 = 0; l0 < nlayers; l0 += kUnroll) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int l = l0 + u;
+            if (WHOLE || l < nlayers) {
+                const bool more = WHOLE && u + 1 < kUnroll ? true : l + 1 < nlayers;
+                chain_landed(w[u & 1]);                      // requested a whole layer ago
+                if (more) load_chain(w[(u + 1) & 1], P, l + 1, co);   // in flight during layer l
+                xc = chain_layer(S, w[u & 1], a_old, l, more, lane, xc);
+            }
+        }
+    }
+    return xc;
+}
 
 __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
     const float* __restrict__ P, const float* __restrict__ Ph, const float* __restrict__ hbias,
@@ -349,27 +392,15 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
         }
         if (wv == 0) {
             ChainW w[2];
-            load_chain(w[0], P, 0, 4u * lane);
+            const ChainOff co = chain_offsets(lane);
+            load_chain(w[0], P, 0, co);
             __syncthreads();
             STAMP(1);
-            float xc = xcur[lane & 31];
+            const float xc0 = xcur[lane & 31];
             wait_count(S.ready_old, 1);
-            float a_old = aold[lane];
-            for (int l0 = 0; l0 < nlayers; l0 += kUnroll) {
-#pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
-                    const int l = l0 + u;
-                    if (l < nlayers) {
-                        // Layer l's weights were requested a whole layer ago.  Waiting for them HERE, in front of the next
-                        // request, costs nothing and leaves hipcc's counter bookkeeping exact: without it the first use of
-                        // w[u & 1] carried `s_waitcnt vmcnt(15)` behind the 16 fresh loads, i.e. it also waited for the
-                        // first load of layer l + 1 -- one exposed L2 round trip per layer on the chain.
-                        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0), expcnt / lgkmcnt untouched
-                        if (l + 1 < nlayers) load_chain(w[(u + 1) & 1], P, l + 1, 4u * lane);   // in flight during layer l
-                        xc = chain_layer(S, w[u & 1], a_old, l, nlayers, lane, xc);
-                    }
-                }
-            }
+            const float a0 = aold[lane];
+            if (nlayers % kUnroll == 0) chain_run<true>(S, P, nlayers, lane, xc0, a0, w, co);
+            else chain_run<false>(S, P, nlayers, lane, xc0, a0, w, co);
         } else if (wv == 1) {
             OldW wo[2];
             load_old(wo[0], P, 0, 4u * lane);
@@ -649,22 +680,14 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast3(
         }
         if (wv == 0) {
             ChainW w[2];
-            load_chain(w[0], P, 0, 4u * lane);
+            const ChainOff co = chain_offsets(lane);
+            load_chain(w[0], P, 0, co);
             __syncthreads();
-            float xc = xcur[lane & 31];
+            const float xc0 = xcur[lane & 31];
             wait_count(S.ready_old, 1);
-            float a_old = aold[lane];
-            for (int l0 = 0; l0 < nlayers; l0 += kUnroll) {
-#pragma unroll
-                for (int u = 0; u < kUnroll; ++u) {
-                    const int l = l0 + u;
-                    if (l < nlayers) {
-                        __builtin_amdgcn_s_waitcnt(0x0F70);
-                        if (l + 1 < nlayers) load_chain(w[(u + 1) & 1], P, l + 1, 4u * lane);
-                        xc = chain_layer(S, w[u & 1], a_old, l, nlayers, lane, xc);
-                    }
-                }
-            }
+            const float a0 = aold[lane];
+            if (nlayers % kUnroll == 0) chain_run<true>(S, P, nlayers, lane, xc0, a0, w, co);
+            else chain_run<false>(S, P, nlayers, lane, xc0, a0, w, co);
         } else if (wv == 1) {
             OldW wo[2];
             load_old(wo[0], P, 0, 4u * lane);
