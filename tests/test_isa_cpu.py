@@ -90,3 +90,20 @@ def test_the_pipelined_skip_gemm_never_moves_its_in_flight_ring_registers(tmp_pa
         region = body[load_lines[0]:load_lines[-1] + 1]
         q1 = scan(region, [])
         scan(region, q1)
+
+
+def test_every_inline_asm_store_carries_its_hazard_wait_states():
+    """A store of more than 8 bytes reads its data registers late: gfx940+ needs two wait states before a VALU instruction
+    overwrites them.  hipcc's hazard recogniser inserts them behind its own stores, never behind inline asm -- the bf16
+    forward's ragged-tile path once computed an address into v[0:1] right behind an asm store of v[0:3] (NaNs in z).  Every
+    asm store of the library therefore ends in `s_nop 1`; this keeps a new one from being added without it."""
+    csrc = os.path.join(ROOT, "wavenet_amd", "csrc")
+    found = 0
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hip", ".hpp")):
+            continue
+        for ln, line in enumerate(open(os.path.join(csrc, fn)), 1):
+            if "asm" in line and re.search(r"(global|buffer|flat)_store_dwordx[234]", line):
+                found += 1
+                assert re.search(r"s_nop\s+[1-9]", line), "%s:%d: asm store without its s_nop" % (fn, ln)
+    assert found >= 2

@@ -118,7 +118,9 @@ __device__ __forceinline__ void lds_dma4_sc1(const void* src, void* lds_dst) {
 typedef float h2_f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st16_sc1(float* dst, float a, float b, float c, float d) {
     const h2_f32x4 v = {a, b, c, d};
-    asm volatile("global_store_dwordx4 %0, %1, off " WN_SC_BITS ::"v"(dst), "v"(v) : "memory");
+    // s_nop 1: the two wait states a VALU write of the data registers needs behind a store of more than 8 bytes (gfx940+);
+    // hipcc's hazard recogniser does not look inside inline asm
+    asm volatile("global_store_dwordx4 %0, %1, off " WN_SC_BITS "\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
 }
 
 }  // namespace wn

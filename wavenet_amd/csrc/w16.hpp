@@ -26,6 +26,27 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define W16_DMA16(src, dst) \
     __builtin_amdgcn_global_load_lds((const void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
+// 16-byte store of streamed output (activations, gradients: written once, far more per launch than the 32 MB of L2):
+// write-through ("sc1").  A plain store leaves the line dirty in this XCD's L2 and the launch ends with the write-back of
+// whatever is still there; written through, the bytes leave while the kernel computes.  Measured on config 5 (same box,
+// alternating libraries): forward 1.45 -> 1.23 ms for its 40 launches with the two stores of k16_fwd alone, and the
+// launches that follow a forward got faster too.  W16_ST_MODE: 0 plain, 1 sc1 (default), 3 nt.
+#ifndef W16_ST_MODE
+#define W16_ST_MODE 1
+#endif
+__device__ __forceinline__ void st16_wt(void* dst, u32x4 v) {
+#if W16_ST_MODE == 1
+    // s_nop 1: a store of more than 8 bytes reads its data registers late -- a VALU instruction that overwrites them needs two
+    // wait states after it (gfx940+).  hipcc's hazard recogniser inserts them behind its own stores, not behind inline asm:
+    // without the s_nop the ragged-tile path of k16_fwd computed the next address into v[0:1] right behind a store of v[0:3].
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+#elif W16_ST_MODE == 3
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst));
+#else
+    *reinterpret_cast<u32x4*>(dst) = v;
+#endif
+}
+
 __device__ __forceinline__ int key(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 // byte offset of 16-byte chunk c of row r inside a tile
 __device__ __forceinline__ int toff(int r, int c) { return (r << 8) + ((c ^ key(r)) << 4); }

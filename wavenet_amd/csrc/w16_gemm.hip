@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const int r = 4 * p + (lane >> 4);
             const int c = (lane & 15) ^ key(r);
             const u32x4 v = *reinterpret_cast<const u32x4*>(xt(0) + p * 1024 + lane * 16);
-            if (r < nrows) *reinterpret_cast<u32x4*>(ob + (long long)r * a.ldo + c * 8) = v;
+            if (r < nrows) st16_wt(ob + (long long)r * a.ldo + c * 8, v);
         }
     }
 }
@@ -381,7 +381,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const int r = 4 * p + (lane >> 4);
             const int c = (lane & 15) ^ key(r);
             const u32x4 v = *reinterpret_cast<const u32x4*>(half + p * 1024 + lane * 16);
-            if (r < nrows) *reinterpret_cast<u32x4*>(o + (long long)r * a.ldo + c * 8) = v;
+            if (r < nrows) st16_wt(o + (long long)r * a.ldo + c * 8, v);
         }
     }
 }

@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const u32x4 vz = *reinterpret_cast<const u32x4*>(zt + p * 1024 + lane * 16);
             const u32x4 vo = *reinterpret_cast<const u32x4*>(ot + p * 1024 + lane * 16);
             if (full || t0 + r < T) {
-                *reinterpret_cast<u32x4*>(zb + r * 128 + pcol[pp]) = vz;
-                *reinterpret_cast<u32x4*>(ob + r * 128 + pcol[pp]) = vo;
+                st16_wt(zb + r * 128 + pcol[pp], vz);
+                st16_wt(ob + r * 128 + pcol[pp], vo);
             }
         }
         full_prev = full;
@@ -319,8 +319,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const int c = (lane & 15) ^ key(r);
             bf16* o = dadg + ((long long)b * T + t0 + r) * 256 + c * 8;
             const u32x4 zero4 = {0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4*>(o) = zero4;
-            *reinterpret_cast<u32x4*>(o + 128) = zero4;
+            st16_wt(o, zero4);
+            st16_wt(o + 128, zero4);
             full_prev = true;
             continue;
         }
@@ -389,8 +389,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const u32x4 vg = *reinterpret_cast<const u32x4*>(dgt + w * 1024 + lane * 16);
             bf16* o = dadg + ((long long)b * T + t0 + r) * 256 + c * 8;
             if (full || t0 + r < T) {
-                *reinterpret_cast<u32x4*>(o) = va;
-                *reinterpret_cast<u32x4*>(o + 128) = vg;
+                st16_wt(o, va);
+                st16_wt(o + 128, vg);
             }
         }
         full_prev = full;
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const int r = 4 * w + (lane >> 4);
             const int c = (lane & 15) ^ key(r);
             const u32x4 zero4 = {0u, 0u, 0u, 0u};
-            *reinterpret_cast<u32x4*>(dx + ((long long)b * T + t0 + r) * 128 + c * 8) = zero4;
+            st16_wt(dx + ((long long)b * T + t0 + r) * 128 + c * 8, zero4);
             full_prev = true;
             continue;
         }
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const int r = 4 * w + (lane >> 4);
             const int c = (lane & 15) ^ key(r);
             const u32x4 v = *reinterpret_cast<const u32x4*>(dxt + w * 1024 + lane * 16);
-            if (full || t0 + r < T) *reinterpret_cast<u32x4*>(dx + ((long long)b * T + t0 + r) * 128 + c * 8) = v;
+            if (full || t0 + r < T) st16_wt(dx + ((long long)b * T + t0 + r) * 128 + c * 8, v);
         }
         full_prev = full;
     }
