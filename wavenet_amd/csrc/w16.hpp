@@ -47,6 +47,23 @@ __device__ __forceinline__ void st16_wt(void* dst, u32x4 v) {
 #endif
 }
 
+// The same store as `uniform base (SGPR pair) + 32-bit lane offset`: no 64-bit address arithmetic in vector registers
+__device__ __forceinline__ void st16_wt_s(const void* base, unsigned off, u32x4 v) {
+#if W16_ST_MODE == 1
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(off), "v"(v), "s"(base) : "memory");
+#else
+    st16_wt(const_cast<char*>(reinterpret_cast<const char*>(base)) + off, v);
+#endif
+}
+// LDS-DMA of 16 bytes per lane from `uniform base + 32-bit lane offset` to the LDS byte address `lds_addr` (uniform; lane L's
+// bytes land at lds_addr + 16 L).  M0 carries the LDS address; the s_nop covers the M0 write -> LDS-DMA hazard.
+__device__ __forceinline__ void dma16_s(const void* base, unsigned off, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
+}
+
 __device__ __forceinline__ int key(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 // byte offset of 16-byte chunk c of row r inside a tile
 __device__ __forceinline__ int toff(int r, int c) { return (r << 8) + ((c ^ key(r)) << 4); }

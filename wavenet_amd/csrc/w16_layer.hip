@@ -39,6 +39,17 @@ __device__ unsigned long long g_stamps[2 * 16 * 16];
 #define STAMP(k) do { } while (0)
 #endif
 
+// z = tanh(a) sigmoid(g) with ONE reciprocal: (1 - e^{-2a}) / ((1 + e^{-2a}) (1 + e^{-g})) -- two exponentials, one reciprocal and
+// eight plain instructions instead of two of each and fourteen (fast_tanh's small-|a| series included): the forward is bound
+// by VALU issue, and the result is rounded to bf16 (8 bits) right away.  a is clamped at -30 (tanh is -1 to
+// the last fp32 bit long before; e^{60} stays finite so that inf / inf cannot arise); a huge e^{-g} makes the
+// denominator inf and z the 0 it should be.
+__device__ __forceinline__ float gate_z(float a, float g) {
+    const float e2 = __builtin_amdgcn_exp2f(fmaxf(a, -30.f) * -2.8853900817779268f);
+    const float eg = __builtin_amdgcn_exp2f(g * -1.4426950408889634f);
+    return (1.f - e2) * __builtin_amdgcn_rcpf((1.f + e2) * (1.f + eg));
+}
+
 static constexpr int kLT = 32;                          // time columns per tile
 static constexpr int kLTileB = kLT * 256;               // 8 KB
 
@@ -89,20 +100,26 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     for (int q = 0; q < 4; ++q) qoff[q] = toff(j, 4 * w + q) + 8 * h;   // accumulator registers 4 q .. 4 q + 3 of this wave
     const int prow = lane >> 4;                                     // row piece / chunk of the whole-row copies
     int pcol[2];
+    unsigned loff[2];                                               // byte offset of this lane's 16 bytes inside a tile of rows
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) pcol[pp] = ((lane & 15) ^ key(4 * (2 * w + pp) + prow)) * 8;
+    for (int pp = 0; pp < 2; ++pp) {
+        pcol[pp] = ((lane & 15) ^ key(4 * (2 * w + pp) + prow)) * 8;
+        loff[pp] = (unsigned)(((4 * (2 * w + pp) + prow) * 128 + pcol[pp]) * 2);
+    }
+    const unsigned lds0 = lds_addr_of(lds);
 
     auto issue = [&](int tile, int buf) {
         const int b = tile / tiles_per_b;
         const int t0 = (tile - b * tiles_per_b) * kLT;
         const bf16* xb = x + (long long)b * T * 128;
-        if (t0 + kLT <= T && t0 >= d) {                  // interior tile: no clamping
+        if (t0 + kLT <= T && t0 >= d) {                  // interior tile: no clamping; uniform base + fixed lane offsets
+            const bf16* bc = xb + (long long)t0 * 128;
+            const bf16* bo = bc - (long long)d * 128;
 #pragma unroll
             for (int pp = 0; pp < 2; ++pp) {
                 const int p = 2 * w + pp;
-                const bf16* src = xb + (long long)(t0 + 4 * p + prow) * 128 + pcol[pp];
-                W16_DMA16(src, xcur(buf) + p * 1024);
-                W16_DMA16(src - (long long)d * 128, xold(buf) + p * 1024);
+                dma16_s(bc, loff[pp], lds0 + (2 + buf) * kLTileB + p * 1024);
+                dma16_s(bo, loff[pp], lds0 + buf * kLTileB + p * 1024);
             }
             return;
         }
@@ -163,7 +180,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             for (int q = 0; q < 4; ++q) {
                 float zz[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) zz[e] = fast_tanh(af[4 * q + e]) * fast_sigmoid(ag[4 * q + e]);
+                for (int e = 0; e < 4; ++e) zz[e] = gate_z(af[4 * q + e], ag[4 * q + e]);
                 *reinterpret_cast<bf16x4*>(zt + qoff[q]) = pack4(zz[0], zz[1], zz[2], zz[3]);
             }
         } else {                                       // the reference's zero prefix: a = g = 0 there, so z = 0
@@ -173,7 +190,7 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 float zz[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    zz[e] = live ? fast_tanh(af[4 * q + e]) * fast_sigmoid(ag[4 * q + e]) : 0.f;
+                    zz[e] = live ? gate_z(af[4 * q + e], ag[4 * q + e]) : 0.f;
                 *reinterpret_cast<bf16x4*>(zt + qoff[q]) = pack4(zz[0], zz[1], zz[2], zz[3]);
             }
         }
@@ -211,8 +228,8 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             const u32x4 vz = *reinterpret_cast<const u32x4*>(zt + p * 1024 + lane * 16);
             const u32x4 vo = *reinterpret_cast<const u32x4*>(ot + p * 1024 + lane * 16);
             if (full || t0 + r < T) {
-                st16_wt(zb + r * 128 + pcol[pp], vz);
-                st16_wt(ob + r * 128 + pcol[pp], vo);
+                st16_wt_s(zb, loff[pp], vz);
+                st16_wt_s(ob, loff[pp], vo);
             }
         }
         full_prev = full;
