@@ -107,3 +107,71 @@ def test_every_inline_asm_store_carries_its_hazard_wait_states():
                 found += 1
                 assert re.search(r"s_nop\s+[1-9]", line), "%s:%d: asm store without its s_nop" % (fn, ln)
     assert found >= 2
+
+
+def _kernel_disassembly(tmp_path):
+    """{kernel symbol: [instruction text, ...]} of every gfx950 code object inside the built library (llvm-objdump extracts the
+    offload bundles next to its input, so it works on a copy)."""
+    import shutil
+    from wavenet_amd import _lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(objdump) and os.path.exists(_lib.LIB_PATH)):
+        pytest.skip("llvm-objdump or the built library is missing")
+    lib = tmp_path / "lib.so"
+    shutil.copy(_lib.LIB_PATH, lib)
+    subprocess.run([objdump, "--offloading", str(lib)], capture_output=True, text=True, timeout=300)
+    objs = [p for p in tmp_path.iterdir() if "gfx950" in p.name]
+    assert objs, "no gfx950 code object extracted from the library"
+    kernels, cur = {}, None
+    for co in objs:
+        r = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(co)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-500:]
+        for line in r.stdout.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\w+)>:", line)
+            if m:
+                cur = kernels.setdefault(m.group(1), [])
+            elif cur is not None and line.startswith("\t"):
+                cur.append(line.split("//")[0].strip())
+    return kernels
+
+
+def test_no_vector_memory_instruction_reads_a_scalar_a_vector_instruction_has_just_written(tmp_path):
+    """gfx9 hazard: a VALU instruction that writes an SGPR (v_readlane / v_readfirstlane / a compare / a carry-out) must be
+    five wait states ahead of a vector-memory instruction that reads that SGPR (its `saddr` base).  hipcc keeps that
+    distance for its own instructions and cannot see inside inline asm; the decoder's chain loads, the bf16 forward's requests
+    and stores and the pipelined GEMMs' requests are inline asm with an SGPR base.  Checked on the disassembly of the library
+    as built: every vector-memory instruction with an s[a:b] operand, in every kernel."""
+    kernels = _kernel_disassembly(tmp_path)
+    assert any("k_decode_fast3" in k for k in kernels) and any("k16_fwd" in k for k in kernels)
+    checked = 0
+    for name, ins in kernels.items():
+        for i, text in enumerate(ins):
+            if not re.match(r"(global|buffer|scratch)_(load|store|atomic)", text):
+                continue
+            m = re.search(r"\bs\[(\d+):(\d+)\]", text)
+            if not m:
+                continue
+            base = set(range(int(m.group(1)), int(m.group(2)) + 1))
+            checked += 1
+            states, k = 0, i - 1
+            while k >= 0 and states < 5:
+                prev = ins[k]
+                if prev.startswith("v_"):
+                    ops = re.split(r",\s*", prev.split(None, 1)[1]) if " " in prev else []
+                    # scalar destinations of a VALU instruction: operand 0 (v_readlane, compares), and operand 1 of the
+                    # instructions with a carry-out / scale flag
+                    dsts = ops[:2] if prev.startswith(("v_add_co", "v_sub_co", "v_addc_co", "v_subb_co", "v_subrev_co",
+                                                       "v_div_scale", "v_mad_u64", "v_mad_i64")) else ops[:1]
+                    written = set()
+                    for d in dsts:
+                        m1, m2 = re.fullmatch(r"s(\d+)", d), re.fullmatch(r"s\[(\d+):(\d+)\]", d)
+                        if m1:
+                            written.add(int(m1.group(1)))
+                        elif m2:
+                            written |= set(range(int(m2.group(1)), int(m2.group(2)) + 1))
+                    assert not (written & base), "%s: `%s` reads s%s %d wait state(s) after `%s`" % (
+                        name, text, sorted(base), states, prev)
+                nop = re.match(r"s_nop (\d+)", prev)
+                states += int(nop.group(1)) + 1 if nop else 1
+                k -= 1
+    assert checked > 100
