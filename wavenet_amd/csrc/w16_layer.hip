@@ -17,6 +17,7 @@
 // accumulator register of two MFMA tiles) and TWO workgroups share a CU: they are not synchronised with each other, so one
 // workgroup's gate arithmetic runs under the other's MFMAs and stores.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "w16_gemm.hpp"
 #include "wn_kernels.hpp"
@@ -29,15 +30,16 @@ using wn::fast_tanh;
 // Diagnostic build (-DWN16_STAMPS): lane 0 of wave 0 of two workgroups records s_memtime at the phase boundaries of its
 // first tiles into a device array that wn16_debug_stamps() copies out.  Never compiled into the product library.
 #ifdef WN16_STAMPS
-__device__ unsigned long long g_stamps[2 * 16 * 16];
-#define STAMP(k)                                                                                          \
+__device__ unsigned long long g_stamps[3 * 2 * 16 * 16];   // [kernel: fwd, gate_bwd, dx][first / last workgroup][tile][stamp]
+#define STAMP_K(kern, k)                                                                                  \
     do {                                                                                                  \
         if (threadIdx.x == 0 && it < 16 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))              \
-            g_stamps[((blockIdx.x != 0) * 16 + it) * 16 + (k)] = __builtin_amdgcn_s_memtime();            \
+            g_stamps[(((kern) * 2 + (blockIdx.x != 0)) * 16 + it) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
-#define STAMP(k) do { } while (0)
+#define STAMP_K(kern, k) do { } while (0)
 #endif
+#define STAMP(k) STAMP_K(0, k)
 
 // z = tanh(a) sigmoid(g) with ONE reciprocal: (1 - e^{-2a}) / ((1 + e^{-2a}) (1 + e^{-g})) -- two exponentials, one reciprocal and
 // eight plain instructions instead of two of each and fourteen (fast_tanh's small-|a| series included): the forward is bound
@@ -48,6 +50,18 @@ __device__ __forceinline__ float gate_z(float a, float g) {
     const float e2 = __builtin_amdgcn_exp2f(fmaxf(a, -30.f) * -2.8853900817779268f);
     const float eg = __builtin_amdgcn_exp2f(g * -1.4426950408889634f);
     return (1.f - e2) * __builtin_amdgcn_rcpf((1.f + e2) * (1.f + eg));
+}
+
+// tanh(a) and sigmoid(g) with ONE reciprocal (the backward needs both): r = 1 / ((1 + e^{-2a}) (1 + e^{-g})),
+// sigmoid = (1 + e^{-2a}) r, tanh = (1 - e^{-2a}) (1 + e^{-g}) r.  g is clamped at -80 so that the product stays finite
+// (sigmoid(-80) = 1.8e-35: a gradient factor of 0 to bf16 either way); a as in gate_z.
+__device__ __forceinline__ void gate_fg(float a, float g, float& f, float& s) {
+    const float e2 = __builtin_amdgcn_exp2f(fmaxf(a, -30.f) * -2.8853900817779268f);
+    const float eg = __builtin_amdgcn_exp2f(fmaxf(g, -80.f) * -1.4426950408889634f);
+    const float p2 = 1.f + e2, pg = 1.f + eg;
+    const float r = __builtin_amdgcn_rcpf(p2 * pg);
+    s = p2 * r;
+    f = (1.f - e2) * (pg * r);
 }
 
 static constexpr int kLT = 32;                          // time columns per tile
@@ -289,10 +303,23 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         for (int s = 0; s < 8; ++s) asm volatile("" ::"v"(zA[s]));
     }
 
+    // this wave's piece of a 32-row tile: rows 4 w .. 4 w + 3; the lane's 16 bytes at a fixed offset from the tile's first row
+    const unsigned off128 = (unsigned)((4 * w + (lane >> 4)) * 256 + (((lane & 15) ^ key(4 * w + (lane >> 4))) << 4));
+    const unsigned lds0 = lds_addr_of(lds);
     auto issue = [&](int tile, int buf) {
         const int b = tile / tiles_per_b;
         const int t0 = (tile - b * tiles_per_b) * kLT;
         if (t0 + kLT <= t_live) return;                    // a dead tile
+        if (t0 + kLT <= T && t0 >= d && (!HAS_DZ || t0 >= dz_t0)) {
+            // interior tile (nothing to clamp): uniform base + the fixed lane offset, no 64-bit address arithmetic per
+            // request -- the four requests cost a wave ~520 cycles of a ~5,900-cycle tile in the clamped form below
+            const bf16* bc = x + ((long long)b * T + t0) * 128;
+            dma16_s(bc, off128, lds0 + (2 + buf) * kLTileB + w * 1024);
+            dma16_s(bc - (long long)d * 128, off128, lds0 + buf * kLTileB + w * 1024);
+            if (HAS_DO) dma16_s(dout + ((long long)b * T + t0) * 128, off128, lds0 + (4 + buf) * kLTileB + w * 1024);
+            if (HAS_DZ) dma16_s(dzs + ((long long)b * Tw + (t0 - dz_t0)) * 128, off128, lds0 + (6 + buf) * kLTileB + w * 1024);
+            return;
+        }
         const bf16* xb = x + (long long)b * T * 128;
         dma_pieces(xcur(buf), lane, w, 1, 1, [&](int r) {
             const int t = t0 + r < T ? t0 + r : T - 1;
@@ -328,9 +355,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int buf = it & 1;
         const int b = tile / tiles_per_b;
         const int t0 = (tile - b * tiles_per_b) * kLT;
+        STAMP_K(1, 0);
         if (full_prev) wait_vm<kStores>(); else wait_vm<0>();
+        STAMP_K(1, 1);
         barrier();
+        STAMP_K(1, 2);
         if (tile + stride < last) issue(tile + stride, buf ^ 1);
+        STAMP_K(1, 3);
         if (t0 + kLT <= t_live) {                          // dead tile (workgroup-uniform): [da | dg] = 0, two stores per wave as below
             const int r = 4 * w + (lane >> 4);
             const int c = (lane & 15) ^ key(r);
@@ -355,10 +386,17 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            // every column operand of the phase is requested before the first MFMA: paired one by one (read -> wait -> MFMA) the
+            // sixteen LDS latencies lay end to end (1,300 cycles for 512 cycles of matrix work, in-kernel stamps)
+            bf16x8 fr[16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cA[s], frag_row(s < 8 ? xold(buf) : xcur(buf), j, s & 7, h), acc,
-                                                          0, 0, 0);
+            for (int s = 0; s < 16; ++s) fr[s] = frag_row(s < 8 ? xold(buf) : xcur(buf), j, s & 7, h);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cA[s], fr[s], acc, 0, 0, 0);
+        }
+        STAMP_K(1, 4);
         // ---- dz = Wp^T dout + dz_skip (registers 0..7; rows 16..31 of the A tile are zero) ----
         f32x16 dz;
 #pragma unroll
@@ -375,10 +413,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
         }
         if (HAS_DO) {
+            bf16x8 fr[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                dz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zA[s], frag_row(dot(buf), j, s, h), dz, 0, 0, 0);
+            for (int s = 0; s < 8; ++s) fr[s] = frag_row(dot(buf), j, s, h);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) dz = __builtin_amdgcn_mfma_f32_32x32x16_bf16(zA[s], fr[s], dz, 0, 0, 0);
         }
+        STAMP_K(1, 5);
         // ---- gate forward + backward, elementwise ----
         const bool live = t >= Z && t < T;
 #pragma unroll
@@ -386,8 +428,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             float da[4], dg[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float f = fast_tanh(live ? acc[4 * q + e] : 0.f);
-                const float g = fast_sigmoid(live ? acc[8 + 4 * q + e] : 0.f);
+                float f, g;
+                gate_fg(live ? acc[4 * q + e] : 0.f, live ? acc[8 + 4 * q + e] : 0.f, f, g);
                 const float dzv = live ? dz[4 * q + e] : 0.f;
                 da[e] = dzv * g * (1.f - f * f);
                 dg[e] = dzv * f * g * (1.f - g);
@@ -396,7 +438,9 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             *reinterpret_cast<bf16x4*>(dat + o) = pack4(da[0], da[1], da[2], da[3]);
             *reinterpret_cast<bf16x4*>(dgt + o) = pack4(dg[0], dg[1], dg[2], dg[3]);
         }
+        STAMP_K(1, 6);
         barrier();
+        STAMP_K(1, 7);
         // ---- [da | dg] rows leave whole: 512-byte rows, da in the first half ----
         const bool full = t0 + kLT <= T;
         {
@@ -411,6 +455,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
         }
         full_prev = full;
+        STAMP_K(1, 8);
     }
 }
 
@@ -449,10 +494,25 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { wp[0][r] = 0.f; wp[1][r] = 0.f; }
 
+    const unsigned off128 = (unsigned)((4 * w + (lane >> 4)) * 256 + (((lane & 15) ^ key(4 * w + (lane >> 4))) << 4));
+    const unsigned off256 = off128 + (unsigned)((4 * w + (lane >> 4)) * 256);          // the same piece of 512-byte [da | dg] rows
+    const unsigned lds0 = lds_addr_of(lds);
     auto issue = [&](int tile, int buf) {
         const int b = tile / tiles_per_b;
         const int t0 = (tile - b * tiles_per_b) * kLT;
         if (t0 + kLT <= t_live) return;                    // a dead tile
+        if (t0 + kLT + d <= T) {                           // interior tile: uniform bases + fixed lane offsets (as in k16_gate_bwd)
+            const bf16* a0 = dadg + ((long long)b * T + t0) * 256;
+            const bf16* a1 = a0 + (long long)d * 256;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                dma16_s(a0 + 128 * half, off256, lds0 + (buf * 6 + half) * kLTileB + w * 1024);
+                dma16_s(a1 + 128 * half, off256, lds0 + (buf * 6 + 2 + half) * kLTileB + w * 1024);
+            }
+            if (HAS_DO) dma16_s(dout + ((long long)b * T + t0) * 128, off128, lds0 + (buf * 6 + 4) * kLTileB + w * 1024);
+            if (HAS_Z) dma16_s(zprev + ((long long)b * T + t0) * 128, off128, lds0 + (buf * 6 + 5) * kLTileB + w * 1024);
+            return;
+        }
         const bf16* ab = dadg + (long long)b * T * 256;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -489,9 +549,13 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const int buf = it & 1;
         const int b = tile / tiles_per_b;
         const int t0 = (tile - b * tiles_per_b) * kLT;
+        STAMP_K(2, 0);
         if (full_prev) wait_vm<1>(); else wait_vm<0>();  // one dx store per wave and tile
+        STAMP_K(2, 1);
         barrier();
+        STAMP_K(2, 2);
         if (tile + stride < last) issue(tile + stride, buf ^ 1);
+        STAMP_K(2, 3);
         if (t0 + kLT <= t_live) {                          // dead tile (workgroup-uniform): dx = 0, one store per wave as below
             const int r = 4 * w + (lane >> 4);
             const int c = (lane & 15) ^ key(r);
@@ -511,19 +575,29 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            bf16x8 fr[16];                               // all sixteen operands requested before the first MFMA (as in k16_gate_bwd)
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s], frag_row(tile_at(buf, 2 * kh + (s >> 3)), j, s & 7, h), acc,
-                                                          0, 0, 0);
-        if (kh == 1) {
+            for (int s = 0; s < 16; ++s) fr[s] = frag_row(tile_at(buf, 2 * kh + (s >> 3)), j, s & 7, h);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xch[(mt * 16 + r) * 64 + lane] = acc[r];
+            for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[s], fr[s], acc, 0, 0, 0);
         }
-        barrier();
-        if (kh == 0) {
+        STAMP_K(2, 4);
+        // the two contraction halves meet: wave kh keeps accumulator quarters 2 kh, 2 kh + 1 and hands the other two to its
+        // partner (before, one half handed over everything and idled through the other's 1,200-cycle combine)
+        auto hand_over = [&](auto KH) {                   // (constant register indices: kh is uniform but not a constant)
+            constexpr int kk = decltype(KH)::value;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) xch[(mt * 16 + 8 * (1 - kk) + r) * 64 + lane] = acc[8 * (1 - kk) + r];
+        };
+        auto combine = [&](auto KH) {
+            constexpr int kk = decltype(KH)::value;
             const bool valid = t0 + j < T;               // rows beyond the clip must not reach dWp
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int qq = 0; qq < 2; ++qq) {
+                constexpr int q0 = 2 * kk;
+                const int q = q0 + qq;
                 const int o = toff(j, 4 * mt + q) + 8 * h;
                 float v[4];
 #pragma unroll
@@ -537,8 +611,14 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 for (int e = 0; e < 4; ++e) v[e] = valid ? v[e] : 0.f;
                 *reinterpret_cast<bf16x4*>(dxt + o) = pack4(v[0], v[1], v[2], v[3]);
             }
-        }
+        };
+        if (kh == 0) hand_over(std::integral_constant<int, 0>{}); else hand_over(std::integral_constant<int, 1>{});
         barrier();
+        STAMP_K(2, 5);
+        if (kh == 0) combine(std::integral_constant<int, 0>{}); else combine(std::integral_constant<int, 1>{});
+        STAMP_K(2, 6);
+        barrier();
+        STAMP_K(2, 7);
         if (HAS_Z) {
             // dWp += dx z^T over this tile's 32 columns (contraction over time: transposed LDS reads)
 #pragma unroll
@@ -551,6 +631,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 }
             }
         }
+        STAMP_K(2, 8);
         const bool full = t0 + kLT <= T;
         {
             const int r = 4 * w + (lane >> 4);
@@ -559,6 +640,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             if (full || t0 + r < T) st16_wt(dx + ((long long)b * T + t0 + r) * 128 + c * 8, v);
         }
         full_prev = full;
+        STAMP_K(2, 9);
     }
     if (HAS_Z) {
         // this workgroup's partial of dWp: [cr][cd] fp32, summed over workgroups by k16_reduce_parts
@@ -677,7 +759,7 @@ int reduce_parts(const float* part, long long layer_stride, int nwg, int n, floa
 
 #ifdef WN16_STAMPS
 int debug_stamps(unsigned long long* dst, int n) {
-    if (n > 2 * 16 * 16) n = 2 * 16 * 16;
+    if (n > 3 * 2 * 16 * 16) n = 3 * 2 * 16 * 16;
     WN_HIP(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), n * sizeof(unsigned long long)));
     return WN_OK;
 }
