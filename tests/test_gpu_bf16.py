@@ -69,7 +69,7 @@ SMALL = dict(quantization_steps=256, causal_conv_channels=[128], residual_conv_c
              softmax_conv_channels=[256, 256])
 
 
-@pytest.mark.parametrize("B,T,tw", [(2, 150, 90), (1, 333, 64), (3, 64, 33)])
+@pytest.mark.parametrize("B,T,tw", [(2, 150, 90), (1, 333, 64), (3, 64, 33), (2, 1000, 611), (1, 96, 96)])
 def test_bf16_stack_every_intermediate_against_the_rounding_oracle(B, T, tw):
     """6 layers (d = 1, 2, 4, 1, 2, 4), ragged T: layer outputs, z, skip, logits, loss, dz_skip, [da | dg], dx of the two
     lowest layers and every gradient."""
