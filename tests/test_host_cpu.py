@@ -218,6 +218,11 @@ def test_hdf5_checkpoint_round_trip_and_load_prefers_the_reference_file(tmp_path
     b.load(str(tmp_path))                                             # no .npz there: the HDF5 file is the checkpoint
     for k, v in a.state_dict().items():
         assert np.array_equal(b.state_dict()[k], v), k
+    # save() leaves the reference's file next to the .npz pair
+    a.save(str(tmp_path / "both"))
+    assert sorted(os.listdir(str(tmp_path / "both"))) == ["wavenet.model", "wavenet.model.npz", "wavenet.opt.npz"]
+    raw2 = hdf5_io.read_datasets(str(tmp_path / "both" / "wavenet.model"))
+    assert all(np.array_equal(raw2[k], v) for k, v in a.state_dict().items())
     # a file of another model is refused, not half-loaded
     c = WaveNet(Params(dict(_TINY, residual_conv_channels=[4, 4, 4])), seed=4)
     with pytest.raises(KeyError):

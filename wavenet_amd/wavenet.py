@@ -963,9 +963,15 @@ class WaveNet(object):
     #    HDF5 container for the weights (read and written through h5py when importable, else through the HDF5 C library:
     #    hdf5_io.py) --
     def save(self, model_dir="./"):
+        """``wavenet.model.npz`` + ``wavenet.opt.npz`` (what :meth:`load` reads first), and -- when an HDF5 library is at hand --
+        the weights once more as ``wavenet.model`` in the reference's own container, the file its ``load`` opens
+        (wavenet.py:627-633)."""
         os.makedirs(model_dir, exist_ok=True)
         np.savez(os.path.join(model_dir, "wavenet.model.npz"), **self.state_dict())
         np.savez(os.path.join(model_dir, "wavenet.opt.npz"), **self.optimizer.state_dict())
+        from . import hdf5_io
+        if hdf5_io.available():
+            self.save_hdf5(os.path.join(model_dir, "wavenet.model"))
 
     def save_hdf5(self, filename):
         """The weights in the file format and layout of the reference's ``serializers.save_hdf5(model_dir +
