@@ -39,6 +39,7 @@ class TrainStepGraph(object):
         self.tgt = tgt.clone()
         opt = net.optimizer
         self._lr = torch.zeros((1,), device=x.device, dtype=torch.float32)
+        self._one = None
         dp = net._dp_group is not None
         self._gmult = 1.0 / net._dp_group.world if dp else 1.0
         # warm-up on the capture stream (per-stream scratch, function attributes, allocator pools), then put the
@@ -90,7 +91,11 @@ class TrainStepGraph(object):
     def _fwd_bwd(self):
         self.net.zero_grads()
         loss = self.loss_fn(self.net, self.x, self.tgt)
-        loss.backward()
+        # the upstream gradient of the loss is a tensor made ONCE (in the warm-up pass, outside the capture): `loss.backward()`
+        # would fill a fresh one in every replay -- a kernel at the launch floor (4.6 us) for one float
+        if self._one is None or self._one.shape != loss.shape:
+            self._one = torch.ones_like(loss)
+        loss.backward(self._one)
         return loss.detach()
 
     def _opt(self):
