@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WN_ABI_VERSION 3
+#define WN_ABI_VERSION 4
 #define WN_OK      0
 #define WN_EARG   -1
 #define WN_ESHAPE -2
@@ -71,7 +71,7 @@ const char* wn_last_error(void);
  * WAVENET_HIP_FORCE_GENERIC / _NO_FUSED_WIDE / _FWD_T1_MIN_BLOCKS inside the .so are per-call fields here):
  *   WN_EXEC_FORCE_GENERIC   every kernel of the call from the any-shape correctness path (generic_kernels.hip), fp32
  *   WN_EXEC_NO_FUSED_WIDE   the 128/128-channel bf16-operand layer forward as two launches instead of one (diagnostic)
- *   WN_EXEC_NO_FWD_GROUPS, WN_EXEC_NO_PIPELINED_GEMM, WN_EXEC_NO_MULTI_LAYER_BWD   see the defines
+ *   WN_EXEC_NO_FWD_GROUPS, WN_EXEC_NO_PIPELINED_GEMM, WN_EXEC_NO_MULTI_LAYER_BWD, WN_EXEC_BF16_MULTI_LAYER_BWD   see the defines
  * fwd_t1_min_blocks: launch size (workgroups of four 32-column tiles) from which the fused 32-channel layer forward takes its
  * one-tile-per-wave form; 0 = the library's default (512: every CU gets two to four workgroups), n > 0 = n (1 = always:
  * parity tests of that kernel at small sizes), < 0 = never.
@@ -84,8 +84,17 @@ enum { WN_GEMM_FP32 = 0, WN_GEMM_BF16X3 = 1, WN_GEMM_BF16 = 2, WN_GEMM_FP16X2 = 
                                       bit for bit -- A/B timing and the parity tests of the per-layer kernel */
 #define WN_EXEC_NO_PIPELINED_GEMM 8u /* fp16x2 skip contractions: the older kernels (k_colgemm_b3, k_wgrad_b3w) instead of
                                         k_colgemm_h2q / k_wgrad_h2p; same results, bit for bit -- A/B timing, parity tests */
-#define WN_EXEC_NO_MULTI_LAYER_BWD 16u /* fp16x2 chained stack backward: one launch per layer instead of the multi-layer launch
-                                          with grid barriers (k_layer_bwd_chain_multi); same results, bit for bit */
+#define WN_EXEC_NO_MULTI_LAYER_BWD 16u /* fp16x2 chained stack backward: one launch per layer instead of the multi-layer
+                                          launch (k_layer_bwd_chain_multi).  That launch has NO grid barrier: co-resident
+                                          workgroups follow one dataflow word per 32-column tile ("layers completed"),
+                                          (V, U) rotate through three buffer pairs, the deal of tiles to waves rotates from
+                                          layer to layer.  Results agree with the per-layer launches to fp32 summation order
+                                          (which wave sums which tiles; ~1e-7) and are bit-reproducible from run to run */
+#define WN_EXEC_BF16_MULTI_LAYER_BWD 32u /* bf16 storage (wn16_stack_bwd): layers L-2 .. 1 of the layer backward in ONE launch
+                                            (k16_bwd_multi: the same dataflow words, k16_gate_bwd / k16_dx tile code unchanged)
+                                            instead of two launches per layer.  Same results, bit for bit.  OPT-IN: measured
+                                            equal to the per-layer launches within 1 %, and it needs every
+                                            workgroup resident -- the library falls back by itself when they would not be */
 typedef struct WnExec {
     int precision;
     unsigned flags;
@@ -350,11 +359,12 @@ int wn16_stack_fwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
                    uint16_t* skip, int B, int T, int t_off, int compat_zero_prefix, void* stream);
 size_t wn16_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T, int t_off);
 /* A15: dout must be NULL (train_audio/train.py:72 discards the stack's residual output), dskip (B,T-t_off,Cs),
- * dx (B,T,128) or NULL; fp32 gradients accumulated */
+ * dx (B,T,128) or NULL; fp32 gradients accumulated.  flags (ABI 4): WN_EXEC_* bits; WN_EXEC_BF16_MULTI_LAYER_BWD selects the
+ * one-launch form of the layer backward (see the define). */
 int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x, const uint16_t* xs, const uint16_t* z,
                    const uint16_t* dout, const uint16_t* dskip, uint16_t* dx, float* const* dWf, float* const* dWg,
                    float* const* dWp, float* const* dWs, void* ws, size_t ws_bytes, int B, int T, int t_off,
-                   int compat_zero_prefix, void* stream);
+                   int compat_zero_prefix, unsigned flags, void* stream);
 /* A12: Wb (Cout,Cin) and WbT (Cin,Cout) are the bf16 images of W; out is bf16 or fp32 (out_f32) */
 int wn16_pack_pointwise(const float* W, uint16_t* Wb, uint16_t* WbT, int Cout, int Cin, void* stream);
 int wn16_pointwise_fwd(const uint16_t* x, const uint16_t* Wb, const float* bias, void* out, int out_f32, int64_t N,

@@ -80,9 +80,10 @@ CFG2 = dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_cha
             residual_num_blocks=4, softmax_conv_channels=[256, 256])
 
 
-def cfg4_decode_trace(n=2048, margin=2e-5):
+def cfg4_decode_trace(n=16000, margin=2e-5):
     """BASELINE config 4 (train_audio/generate.py:24-43 with --fast at config 2's 4 x 10 topology, window 4094): the
-    oracle's literal queue-cached generation for 2,048 steps (round 2: 256; the first 256 are unchanged).  Weights: the product's own seeded initialisation
+    oracle's literal queue-cached generation for all 16,000 samples the config names (round 2: 256 steps, round 3: 2,048;
+    each is a prefix of the next -- the uniform stream and the replacement stream are consumed in order).  Weights: the product's own seeded initialisation
     (``WaveNet(Params, seed=1234)``, CPU only -- identical to the oracle's ``init_weights(p, 1234)``, asserted) so that
     bench.py can reproduce them without importing the oracle.  Uniforms start as ``RandomState(7).random_sample``; a draw
     that lands within ``margin`` of a boundary of the step's cumulative distribution is replaced by the next draw of a
@@ -108,8 +109,9 @@ def cfg4_decode_trace(n=2048, margin=2e-5):
         buf = np.append(buf, [R.choice_from_uniform(prob, u[step])]).astype(np.int32)
     toks = buf[iw:]
     np.savez_compressed(os.path.join(OUT, "cfg4_decode_trace.npz"), tokens=toks.astype(np.uint8), uniforms=u,
-                        probs_every8=np.array(probs[::8], np.float32), margin=np.array(margin),
-                        replaced=np.array(replaced))
+                        probs_every8=np.array(probs[:2048:8], np.float32),        # the first 2,048 steps, as before
+                        probs_every128=np.array(probs[::128], np.float32),       # the whole trace, thinner
+                        margin=np.array(margin), replaced=np.array(replaced))
     print("cfg4 trace: %d draws replaced, token sum %d" % (replaced, int(toks.sum())))
 
 

@@ -334,3 +334,48 @@ def test_cfg5_full_bench_size_gradients_equal_the_two_clip_slice_and_are_bit_rep
         if "projection_block" in ln.name and ln is net.residual_blocks[-1][-1].projection_block:
             continue
         assert np.abs(g8[off:off + n]).max() > 0, ln.name
+
+
+@pytest.mark.parametrize("B,T,tw,cfg", [(2, 1000, 611, "small"), (3, 4133, 1200, "small"), (1, 333, 64, "small"),
+                                        (2, 4294, 200, "cfg5"), (8, 16384, 12290, "cfg5")])
+def test_one_launch_layer_backward_equals_the_per_layer_launches_bit_for_bit(B, T, tw, cfg):
+    """k16_bwd_multi (WN_EXEC_BF16_MULTI_LAYER_BWD, opt-in: measured no faster) -- layers L-2 .. 1 of
+    the bf16 layer backward in ONE launch of co-resident workgroups that follow one dataflow word per 32-column tile instead
+    of eighty launch boundaries.  Tile code, tile -> workgroup deal and per-workgroup dWp partial tiles are those of
+    k16_gate_bwd / k16_dx, so every gradient, the [da | dg] arrays of every layer and the two dx buffers must equal the
+    per-layer launches' BIT FOR BIT --
+    a tile read before its producer had stored it, or a stale line served for it, shows as a difference.  Sizes: ragged
+    last tiles, clips that do not align with the XCD ranges of tile_range(), the full 4 x 10 stack at the oracle-checked
+    window and at the bench's own B = 8 x 16,384 (4,096 tiles, 16 per workgroup), three repetitions of the one-launch
+    form (its waits differ from run to run, its results must not).  The per-layer form is what the rounding-oracle tests
+    above check op by op."""
+    from wavenet_amd import _lib
+    over = SMALL if cfg == "small" else CFG5
+    net = WaveNet(Params(R.make_params(**over)), seed=2, storage="bf16")
+    net.to_gpu()
+    L = len(net._flat_layers)
+    rs = np.random.RandomState(B * 1000 + T)
+    x = dev(rs.randint(0, 256, size=(B, T)).astype(np.int32))
+    tgt = dev(rs.randint(0, 256, size=(B, tw)).astype(np.int32))
+    base = _lib.default_exec_flags() & ~_lib.WN_EXEC_BF16_MULTI_LAYER_BWD
+
+    def step(flags):
+        net.exec_flags = flags
+        c = net.forward_causal_block(x)
+        _, s = net.forward_residual_block(c, t_off=T - tw)
+        loss = net.cross_entropy(net.forward_softmax_block(s, apply_softmax=False), tgt)
+        net.zero_grads()
+        loss.backward()
+        torch.cuda.synchronize()
+        dzs, dadg, dxb = _ws_views(net, L, B, T, tw)
+        # compared on the device as raw bits (2.7 GB of [da | dg] at the bench's size)
+        return (net._grad_arena.view(torch.int32).clone(), dadg.view(torch.int16).clone(),
+                dxb[0].view(torch.int16).clone(), dxb[1].view(torch.int16).clone())
+
+    ref = step(base)
+    g = ref[0].view(torch.float32)
+    assert bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+    for rep in range(3):
+        got = step(base | _lib.WN_EXEC_BF16_MULTI_LAYER_BWD)
+        for a, b, what in zip(ref, got, ("gradient arena", "[da | dg] of every layer", "dx buffer 0", "dx buffer 1")):
+            assert torch.equal(a, b), "%s differs, repetition %d: %d elements" % (what, rep, int((a != b).sum()))

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libwavenet_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert _lib.lib().wn_abi_version() == 3 == int(re.search(r"#define WN_ABI_VERSION (\d+)", hdr).group(1))
+    assert _lib.lib().wn_abi_version() == 4 == int(re.search(r"#define WN_ABI_VERSION (\d+)", hdr).group(1))
     assert not hasattr(lib, "wn_set_gemm_precision")          # ABI v2: no process-wide arithmetic mode
     # ABI v3: no switch read from the process environment inside the library (they are WnExec.flags / fields now)
     csrc = os.path.join(ROOT, "wavenet_amd", "csrc")

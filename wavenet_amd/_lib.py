@@ -10,7 +10,7 @@ from typing import Dict, Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVENET_HIP_LIB") or os.path.join(_HERE, "libwavenet_hip.so")   # (override: same-box A/B of two builds)
-ABI_VERSION = 3
+ABI_VERSION = 4
 XENT_LOSS_WORDS = 2056      # WN_XENT_LOSS_WORDS: loss[0] + per-workgroup sums of wn_softmax_xent
 SQNORM_WORDS = 1040          # WN_SQNORM_WORDS: out[0] + per-workgroup partial sums of wn_sqnorm
 
@@ -104,7 +104,7 @@ _SIGS = {
     "wn16_cvt_to_f32": (_i, [_p, _p, _i64, _p]),
     "wn16_stack_fwd": (_i, [C.POINTER(WnStackDesc), _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "wn16_stack_bwd_workspace_bytes": (C.c_size_t, [C.POINTER(WnStackDesc), _i, _i, _i]),
-    "wn16_stack_bwd": (_i, [C.POINTER(WnStackDesc)] + [_p] * 7 + [_pp] * 4 + [_p, C.c_size_t, _i, _i, _i, _i, _p]),
+    "wn16_stack_bwd": (_i, [C.POINTER(WnStackDesc)] + [_p] * 7 + [_pp] * 4 + [_p, C.c_size_t, _i, _i, _i, _i, C.c_uint, _p]),
     "wn16_pack_pointwise": (_i, [_p, _p, _p, _i, _i, _p]),
     "wn16_pointwise_fwd": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _i, _p]),
     "wn16_pointwise_bwd_workspace_bytes": (C.c_size_t, [_i64, _i]),
@@ -196,6 +196,7 @@ def stream_ptr() -> Optional[int]:
 GEMM_PRECISIONS = ("fp32", "bf16x3", "bf16", "fp16x2")
 WN_EXEC_FORCE_GENERIC, WN_EXEC_NO_FUSED_WIDE, WN_EXEC_NO_FWD_GROUPS, WN_EXEC_NO_PIPELINED_GEMM = 1, 2, 4, 8
 WN_EXEC_NO_MULTI_LAYER_BWD = 16
+WN_EXEC_BF16_MULTI_LAYER_BWD = 32     # bf16 storage: the layer backward of layers L-2 .. 1 in one launch (opt-in; no faster, bit-identical)
 WN_DECODER_ONE_WORKGROUP = 64          # WnDecoderDesc.flags: wn_decoder_run on one workgroup instead of three
 
 
@@ -214,6 +215,8 @@ def default_exec_flags() -> int:
         f |= WN_EXEC_NO_PIPELINED_GEMM
     if os.environ.get("WAVENET_HIP_NO_MULTI_LAYER_BWD") == "1":
         f |= WN_EXEC_NO_MULTI_LAYER_BWD
+    if os.environ.get("WAVENET_HIP_BF16_MULTI_LAYER_BWD") == "1":
+        f |= WN_EXEC_BF16_MULTI_LAYER_BWD
     if os.environ.get("WAVENET_HIP_DECODER_ONE_WORKGROUP") == "1":
         f |= WN_DECODER_ONE_WORKGROUP
     return f

@@ -92,7 +92,7 @@ __device__ __forceinline__ void lb_split16(const float (&v)[16], float s, H2Op& 
 // publish the data needs an explicit wait in front of it (the compiler no longer drains vmcnt there by itself).
 __device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds_dst);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
 }
 
 #if defined(WN_SC_MODE) && WN_SC_MODE == 3
@@ -106,13 +106,13 @@ __device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
 // in this XCD's L2).  For data another XCD wrote earlier in the SAME launch with st16_sc1.
 __device__ __forceinline__ void lds_dma16_sc1(const void* src, void* lds_dst) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds_dst);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off " WN_SC_BITS ::"v"(src), "s"(m0v) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off " WN_SC_BITS ::"v"(src), "s"(m0v) : "memory", "m0");
 }
 // One dword per lane into LDS (lane L's word at lds_dst + 4 L), sc1: a way to request words whose VALUE is needed later
 // without giving the compiler a register to wait for -- the kernel's own counted s_waitcnt covers the request.
 __device__ __forceinline__ void lds_dma4_sc1(const void* src, void* lds_dst) {
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds_dst);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc1" ::"v"(src), "s"(m0v) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc1" ::"v"(src), "s"(m0v) : "memory", "m0");
 }
 // 16-byte store written through to memory at agent scope (sc1): visible to every XCD once the wave's vmcnt has counted it.
 typedef float h2_f32x4 __attribute__((ext_vector_type(4)));

@@ -630,7 +630,7 @@ __device__ __forceinline__ void asm_load16s(f32x4& dst, unsigned voff, const cha
 // two 1 KB pieces of one image tile half: lane offset voff, uniform base sbase, LDS destination m0v (+ 1 KB for the second)
 __device__ __forceinline__ void asm_dma2(unsigned voff, const char* sbase, unsigned m0v) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
-                 :: "v"(voff), "s"(sbase), "s"(m0v) : "memory");
+                 :: "v"(voff), "s"(sbase), "s"(m0v) : "memory", "m0");
 }
 
 // x_stride: bytes from chunk c's X to chunk c + 1's (the launcher's check: equally spaced sources of one chunk each, or
@@ -1351,7 +1351,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_h2p(WGArgs a) {
             const int row = min(r0 + 4 * wv + k, rlast);
             const char* sb = Abase + (long long)row * 1024;
             const unsigned m0v = lds_base + 2 * kWpImg + set * kWpStage + (4 * wv + k) * 1024;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(a_voff), "s"(sb), "s"(m0v) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(a_voff), "s"(sb), "s"(m0v) : "memory", "m0");
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)

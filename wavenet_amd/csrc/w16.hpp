@@ -25,6 +25,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 #define W16_DMA16(src, dst) \
     __builtin_amdgcn_global_load_lds((const void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+// the same request with the sc1 bit (aux = 16): fetched from memory, never from a stale copy in this CU's L1 or this XCD's
+// L2 -- for rows another workgroup wrote EARLIER IN THE SAME LAUNCH with st16_wt (k16_bwd_multi)
+#define W16_DMA16_SC1(src, dst) \
+    __builtin_amdgcn_global_load_lds((const void*)(src), (__attribute__((address_space(3))) void*)(dst), 16, 0, 16)
 
 // 16-byte store of streamed output (activations, gradients: written once, far more per launch than the 32 MB of L2):
 // write-through ("sc1").  A plain store leaves the line dirty in this XCD's L2 and the launch ends with the write-back of
@@ -47,6 +51,17 @@ __device__ __forceinline__ void st16_wt(void* dst, u32x4 v) {
 #endif
 }
 
+// a pointer the program knows to be wave-uniform, as the SGPR pair the `"s"` operands below need: for pointers the compiler
+// cannot prove uniform (picked by a loop variable).  Use it where the pointer is MADE, not next to the request: a vector-memory
+// instruction must not read an SGPR within five wait states of the v_readfirstlane that wrote it, and hipcc does not look
+// inside inline asm (tests/test_isa_cpu.py checks the library's disassembly for exactly that)
+template <class P>
+__device__ __forceinline__ P* uniform_ptr(P* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (P*)(((unsigned long long)hi << 32) | lo);
+}
+
 // The same store as `uniform base (SGPR pair) + 32-bit lane offset`: no 64-bit address arithmetic in vector registers
 __device__ __forceinline__ void st16_wt_s(const void* base, unsigned off, u32x4 v) {
 #if W16_ST_MODE == 1
@@ -57,8 +72,22 @@ __device__ __forceinline__ void st16_wt_s(const void* base, unsigned off, u32x4 
 }
 // LDS-DMA of 16 bytes per lane from `uniform base + 32-bit lane offset` to the LDS byte address `lds_addr` (uniform; lane L's
 // bytes land at lds_addr + 16 L).  M0 carries the LDS address; the s_nop covers the M0 write -> LDS-DMA hazard.
+// (M0 is declared clobbered: the kernels mix this form with the builtin, whose M0 initialisation the compiler emits and may
+// otherwise hoist or merge across an asm block it believes leaves M0 alone.)
 __device__ __forceinline__ void dma16_s(const void* base, unsigned off, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_addr) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds_addr) : "memory", "m0");
+}
+template <bool SC1>
+__device__ __forceinline__ void dma16_sx(const void* base, unsigned off, unsigned lds_addr) {
+    if constexpr (SC1)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 sc1" ::"v"(off), "s"(base), "s"(lds_addr) : "memory", "m0");
+    else
+        dma16_s(base, off, lds_addr);
+}
+// one dword per lane into LDS (lane L's word at lds_addr + 4 L), sc1: words whose VALUE is wanted later, requested without
+// giving the compiler a register to wait for -- the kernel's own counted s_waitcnt covers the request
+__device__ __forceinline__ void dma4_sc1(const void* src, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off sc1" ::"v"(src), "s"(lds_addr) : "memory", "m0");
 }
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const char*)p;
@@ -81,14 +110,28 @@ __device__ __forceinline__ void wait_vm() {
 
 // Fill `npieces` 4-row pieces (first piece p0, stride pstride between this wave's pieces) of a tile from global rows.
 // rowptr(r) must return the (clamped, always valid) global address of channel 0 of tile row r.
-template <class RowPtr>
+// ASM (k16_bwd_multi): the request as inline asm with a per-lane 64-bit address.  With the builtin hipcc knows that LDS is
+// written asynchronously and puts s_waitcnt vmcnt(0) in front of every later LDS access that "may alias" -- inline asm with a
+// memory clobber included --, which also waits for every store issued since; the asm form leaves the kernel's own counted
+// waits as the only ones (every read of the destination must then sit behind one).
+template <bool SC1 = false, bool ASM = false, class RowPtr>
 __device__ __forceinline__ void dma_pieces(char* tile, int lane, int p0, int pstride, int npieces, RowPtr rowptr) {
 #pragma unroll
     for (int i = 0; i < npieces; ++i) {
         const int p = p0 + i * pstride;
         const int r = 4 * p + (lane >> 4);
         const int c = (lane & 15) ^ key(r);
-        W16_DMA16(rowptr(r) + c * 8, tile + p * 1024);
+        if constexpr (ASM) {
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_addr_of(tile + p * 1024));
+            const void* src = rowptr(r) + c * 8;
+            if constexpr (SC1)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off sc1" ::"v"(src), "s"(m0v) : "memory", "m0");
+            else
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+        } else {
+            if constexpr (SC1) W16_DMA16_SC1(rowptr(r) + c * 8, tile + p * 1024);
+            else W16_DMA16(rowptr(r) + c * 8, tile + p * 1024);
+        }
     }
 }
 

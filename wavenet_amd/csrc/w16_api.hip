@@ -38,7 +38,7 @@ size_t pack_elems(const WnStackDesc* d) {
     return L * kLayerImg + 2 * (size_t)d->Cs * L * 128;     // layer images, skip matrix [Cs][128 L], dz matrix [128 L][Cs]
 }
 
-struct BwdWs { bf16* dzs; bf16* dadg; bf16* dxb[2]; float* parts; float* wgparts; size_t bytes; };
+struct BwdWs { bf16* dzs; bf16* dadg; bf16* dxb[2]; float* parts; float* wgparts; unsigned* sync; size_t bytes; };
 BwdWs carve(const WnStackDesc* d, int B, int T, int t_off, char* ws) {
     const size_t L = d->n_layers, n = (size_t)B * T, nw = (size_t)B * (T - t_off);
     BwdWs r{};
@@ -50,6 +50,7 @@ BwdWs carve(const WnStackDesc* d, int B, int T, int t_off, char* ws) {
     r.dxb[1] = reinterpret_cast<bf16*>(take(n * 128 * 2));
     r.parts = reinterpret_cast<float*>(take(L * (size_t)dx_grid(B, T) * 128 * 128 * 4));
     r.wgparts = reinterpret_cast<float*>(take(kWgPartBytes));        // per-workgroup blocks of the time contractions
+    r.sync = reinterpret_cast<unsigned*>(take(bwd_multi_sync_words(B, T) * sizeof(unsigned)));   // dataflow words of k16_bwd_multi
     r.bytes = o;
     return r;
 }
@@ -149,7 +150,7 @@ size_t wn16_stack_bwd_workspace_bytes(const WnStackDesc* d, int B, int T, int t_
 int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x, const uint16_t* xs, const uint16_t* z,
                    const uint16_t* dout, const uint16_t* dskip, uint16_t* dx, float* const* dWf, float* const* dWg,
                    float* const* dWp, float* const* dWs, void* ws, size_t ws_bytes, int B, int T, int t_off,
-                   int compat_zero_prefix, void* stream) {
+                   int compat_zero_prefix, unsigned flags, void* stream) {
     W16_CHECK_DESC(d);
     WN_CHECK_ARG(pack && x && xs && z && dWf && dWg && dWp && ws && B > 0 && T > 0, "wn16_stack_bwd: bad argument");
     WN_CHECK_ARG(dskip, "wn16_stack_bwd: dskip is NULL (the loss reaches the stack through the skip sum)");
@@ -210,17 +211,34 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
         // receives gradient at columns t >= t_off - (reach of the layers above it) and nowhere else.  Tiles wholly below that
         // load and compute nothing; they store the zeros their readers (the dx kernel, the deferred weight-gradient launch,
         // the layer below) expect.  12.5 % of the sample-layers at config 5's window.
+        std::vector<int> Zl(L), live_g(L), live_x(L);
         int t_live = t_off;
         for (int l = L - 1; l >= 0; --l) {
+            const int dl = d->dilation[l];
+            Zl[l] = compat_zero_prefix ? zero_prefix(T, dl, 2) : 0;
+            live_g[l] = (t_live / 32) * 32;
+            t_live = t_live - dl > 0 ? t_live - dl : 0;       // the layer below (and this layer's dx): one more dilation of reach
+            live_x[l] = (t_live / 32) * 32;
+        }
+        // on request, layers L - 2 .. 1 in ONE launch (k16_bwd_multi: per-tile dataflow words instead of eighty launch
+        // boundaries; the top layer (no dout) and layer 0 (no layer below, caller's dx) keep their own launches).  Opt-in:
+        // bit-identical and, measured, no faster than the per-layer launches
+        const bool multi = (flags & WN_EXEC_BF16_MULTI_LAYER_BWD) && L >= 4 && bwd_multi_ok(B, T);
+        for (int l = L - 1; l >= 0; --l) {
+            if (multi && l == L - 2) {
+                if ((rc = bwd_multi(xb, xsb, zb, img, w.dzs, w.dadg, w.dxb[0], w.dxb[1], w.parts, part_stride, w.sync,
+                                    d->dilation, Zl.data(), live_g.data(), live_x.data(), L - 2, 1, B, T, t_off, s)))
+                    return rc;
+                for (int k = L - 3; k >= 0; --k) dWp_eff[k] = dWp[k];
+                gout = w.dxb[1];                            // dx of layer 1
+                l = 1;
+                continue;
+            }
             const bf16* in = l == 0 ? xb : xsb + (size_t)(l - 1) * n * 128;
             const int dl = d->dilation[l];
-            const int Z = compat_zero_prefix ? zero_prefix(T, dl, 2) : 0;
             bf16* dadg = w.dadg + (size_t)l * n * 256;
-            const int live = (t_live / 32) * 32;
-            t_live = t_live - dl > 0 ? t_live - dl : 0;       // the layer below (and this layer's dx): one more dilation of reach
-            const int live_dx = (t_live / 32) * 32;
             if ((rc = gate_bwd_layer(in, img + (size_t)l * kLayerImg, gout, dsk ? w.dzs + (size_t)l * nw * 128 : nullptr,
-                                     t_off, dadg, B, T, dl, Z, live, s)))
+                                     t_off, dadg, B, T, dl, Zl[l], live_g[l], s)))
                 return rc;
             bf16* gin = l == 0 ? reinterpret_cast<bf16*>(dx) : w.dxb[l & 1];
             if (!gin) break;                               // l == 0 and the caller does not want dx
@@ -228,7 +246,7 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
             // projection gradient dWp_{l-1} += dx_l z_{l-1}^T is taken in the same pass
             const bf16* zprev = l > 0 ? zb + (size_t)(l - 1) * n * 128 : nullptr;
             if ((rc = dx_layer(dadg, img + (size_t)l * kLayerImg, gout, zprev, gin,
-                               l > 0 ? w.parts + (size_t)(l - 1) * part_stride : nullptr, B, T, dl, live_dx, s)))
+                               l > 0 ? w.parts + (size_t)(l - 1) * part_stride : nullptr, B, T, dl, live_x[l], s)))
                 return rc;
             if (l > 0) dWp_eff[l - 1] = dWp[l - 1];
             gout = gin;

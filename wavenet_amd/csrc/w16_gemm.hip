@@ -291,8 +291,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned mx = lds0 + buf * kBTileB + (w + 8 * i) * 1024, mw = mx + 2 * kBTileB;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(xo[i]), "s"(xb), "s"(mx) : "memory");
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(wo[i]), "s"(wb), "s"(mw) : "memory");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(xo[i]), "s"(xb), "s"(mx) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(wo[i]), "s"(wb), "s"(mw) : "memory", "m0");
         }
     };
 

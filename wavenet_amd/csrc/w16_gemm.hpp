@@ -68,6 +68,13 @@ int gate_bwd_layer(const bf16* x, const bf16* img, const bf16* dout, const bf16*
 int dx_grid(int B, int T);
 int dx_layer(const bf16* dadg, const bf16* img, const bf16* dout, const bf16* zprev, bf16* dx, float* dwp_part, int B,
              int T, int d, int t_live, hipStream_t s);
+// stack layers l_hi .. l_lo (>= 1) of the layer backward in ONE launch (k16_bwd_multi): same results as gate_bwd_layer +
+// dx_layer per layer, bit for bit; sync: bwd_multi_sync_words(B, T) words of device memory
+size_t bwd_multi_sync_words(int B, int T);
+int bwd_multi_ok(int B, int T);
+int bwd_multi(const bf16* x0, const bf16* xs, const bf16* z, const bf16* img, const bf16* dzs, bf16* dadg, bf16* dxb0,
+              bf16* dxb1, float* parts, long long part_stride, unsigned* sync, const int* d, const int* Z,
+              const int* live_gate, const int* live_dx, int l_hi, int l_lo, int B, int T, int dz_t0, hipStream_t s);
 int reduce_parts(const float* part, long long layer_stride, int nwg, int n, float* const* dW_dev, int L, hipStream_t s);
 
 }  // namespace w16

@@ -370,7 +370,9 @@ class _Stack16Fn(_Fn):
         dx = torch.empty((B, T, Cr), device=x.device, dtype=torch.bfloat16) if ctx.needs_input_grad[0] else None
         check(lib.wn16_stack_bwd(desc, ptr(net._pack16), ptr(x), ptr(xs), ptr(z), ptr(dout), ptr(dskip), ptr(dx),
                                  gt["wf"], gt["wg"], gt["wp"], gt["ws"], ptr(ws), nbytes, B, T, t_off,
-                                 1 if net.compat_zero_prefix else 0, stream_ptr()), "wn16_stack_bwd")
+                                 1 if net.compat_zero_prefix else 0,
+                                 _lib.default_exec_flags() if net.exec_flags is None else int(net.exec_flags),
+                                 stream_ptr()), "wn16_stack_bwd")
         net._last16_ws = ws
         ctx.saved = None
         return dx, None, None, None, None
