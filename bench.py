@@ -560,7 +560,7 @@ def main():
         # ---- AR decode, config 4: 16k samples on one GPU, persistent per-layer state -----------
         if not args.no_decode:
             # decode with the seeded initial weights (not the ones the timed steps just trained), so that the first tokens
-            # (2,048 of them) can be held against the committed oracle trace tests/golden/cfg4_decode_trace.npz
+            # (all 16,000 since round 5) can be held against the committed oracle trace tests/golden/cfg4_decode_trace.npz
             n = args.decode_samples
             u = np.random.RandomState(7).random_sample(n)
             gold = None

@@ -66,8 +66,10 @@ def test_mulaw_fixture():
 
 
 def test_cfg4_decode_fixture_first_steps_and_weights():
-    """The 256-step config-4 trace (4 x 10 layers, window 4094): its weights are the product's seeded CPU initialisation,
-    equal to the oracle's; the oracle reproduces its first tokens; every stored uniform keeps the stated margin."""
+    """The config-4 trace (4 x 10 layers, window 4094, all 16,000 samples BASELINE configs[3] names): its weights are the
+    product's seeded CPU initialisation, equal to the oracle's; the oracle reproduces its first tokens; every stored
+    uniform keeps the stated margin; the number of margin-replaced draws is what the margin predicts (a draw lands within
+    2e-5 of one of 255 inner CDF boundaries with probability ~ 255 x 2 x 2e-5 = 1.0 %) and must not grow."""
     from wavenet_amd import Params, WaveNet
     z = np.load(os.path.join(G, "cfg4_decode_trace.npz"))
     p = R.make_params(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 10,
@@ -79,6 +81,10 @@ def test_cfg4_decode_fixture_first_steps_and_weights():
     toks = R.generate(p, w, 3, z["uniforms"], fast=True, fast_head_act="elu", trace=tr)
     np.testing.assert_array_equal(toks, z["tokens"][:3].astype(np.int32))
     np.testing.assert_allclose(tr[0], z["probs_every8"][0], atol=1e-6)
-    assert z["tokens"].shape == (2048,) and z["uniforms"].shape == (2048,) and z["probs_every8"].shape == (256, 256)
+    assert z["tokens"].shape == (16000,) and z["uniforms"].shape == (16000,)
+    assert z["probs_every8"].shape == (256, 256) and z["probs_every128"].shape == (125, 256)
+    np.testing.assert_array_equal(z["probs_every8"][::16], z["probs_every128"][:16])       # the two thinnings agree where they meet
+    assert int(z["replaced"]) <= 0.0102 * 16000 + 3 * np.sqrt(0.0102 * 16000)              # expectation + 3 sigma of the margin rule
+    assert int(z["tokens"].astype(np.int64).sum()) == 1991402
     cdf = np.cumsum(tr[2].astype(np.float64)); cdf /= cdf[-1]
     assert np.abs(cdf - z["uniforms"][2]).min() >= float(z["margin"])
