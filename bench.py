@@ -336,18 +336,27 @@ def main():
     if barrier:
         barrier()
     torch.cuda.synchronize()
+    # EXACTLY K steps between two barrier + synchronize brackets (the wall mean, MAX over ranks: `ms_per_step_wall_mean`), and a
+    # HIP event on the launch stream after every step ("hipEvents, median"): `ms_per_step` is the MEDIAN of the K
+    # per-step event intervals (MAX over ranks), `value` follows from it.  (The C ABI is called on torch's current stream, so
+    # torch's events are events on that stream.)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         loss = step_fn()
+        evs[i + 1].record()
     if barrier:
         barrier()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    wall_dt = (time.perf_counter() - t0) / args.steps
+    step_ms = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+    dt = 1e-3 * (step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2]))
     local_dt = dt
     if world > 1 or force_dist:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([dt, wall_dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt, wall_dt = float(tt[0].item()), float(tt[1].item())
     # ---- the same K steps launched op by op under the in-library HIP-event profiler: per-entry-point kernel time
     # (events on the launch stream around every C-ABI call; a replayed graph has no host code to record them)
     with _lib.profile() as prof:
@@ -363,7 +372,11 @@ def main():
     out = {
         "metric": "audio samples/sec: train fwd+bwd, 4x10-layer dilated stack (cfg2)", "value": value,
         "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_steps": spinup,
-        "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt * 1e3, "ms_per_step_wall_mean": wall_dt * 1e3,
+        "ms_per_step_min_max": [step_ms[0], step_ms[-1]],
+        "timing": "ms_per_step = median of the K per-step HIP-event intervals on the launch stream (MAX over ranks); "
+                  "ms_per_step_wall_mean = wall clock over the K steps between barrier + synchronize brackets / K",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "arith": arith_record(_lib.get_gemm_precision()),
         "gemm_mode": GEMM_MODE_TEXT[_lib.get_gemm_precision()],
@@ -597,8 +610,11 @@ def main():
     if world > 1 or force_dist:
         # what every rank actually ran, so that a scaling record can be trusted at first sight
         forms = [None] * world
+        # first_tokens: the head of this rank's first clip -- clip rank * B_PER_GPU of the GLOBAL batch (clip b uses
+        # phi_b = 2 pi b / B with the global b), so that a record shows at first sight that the ranks trained on different clips
         dist.all_gather_object(forms, {"rank": rank, "device": torch.cuda.current_device(), "launch": out["launch"],
-                                       "ms_per_step_local": local_dt * 1e3})
+                                       "ms_per_step_local": local_dt * 1e3, "global_clips": [rank * B_PER_GPU, (rank + 1) * B_PER_GPU],
+                                       "first_tokens": x[0, :16].cpu().tolist()})
         out["dist"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": forms,
                        "collective": "one all-reduce(SUM) of the flat fp32 gradient arena per step (%d floats)"
                                      % net._grad_arena.numel()}

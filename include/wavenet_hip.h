@@ -9,7 +9,8 @@
  *
  * Conventions (all entry points)
  *   - return 0 on success; <0 on failure (WN_EARG bad argument, WN_ESHAPE unsupported shape,
- *     WN_EHIP a HIP runtime error).  wn_last_error() gives a thread-local message.
+ *     WN_EHIP a HIP runtime error, WN_ETIMEOUT a device-side wait that gave up).  wn_last_error() gives a thread-local
+ *     message.
  *   - every tensor pointer is a DEVICE pointer owned by the caller; nothing is retained after the
  *     call returns except by decoder handles, which copy what they need at create / load time.
  *   - no allocation, no synchronisation: work is enqueued on `stream` (a hipStream_t; NULL = the
@@ -40,6 +41,7 @@ extern "C" {
 #define WN_EARG   -1
 #define WN_ESHAPE -2
 #define WN_EHIP   -3
+#define WN_ETIMEOUT -4   /* ABI 4: a device-side wait between co-resident workgroups gave up (wn_decoder_status) */
 
 #define WN_ACT_NONE 0
 #define WN_ACT_RELU 1   /* wavenet.py:588 */
@@ -256,8 +258,11 @@ typedef struct WnDecoderDesc {
     const float* const* head_W; const float* const* head_b;                     /* n_head      */
     int head_act;                     /* WN_ACT_ELU for FasterWaveNet, WN_ACT_RELU for WaveNet  */
     unsigned flags;                   /* WN_EXEC_FORCE_GENERIC: never the specialised 32/256-channel decode kernel;
-                                         WN_DECODER_ONE_WORKGROUP: wn_decoder_run of that kernel on one workgroup instead of
-                                         three (chain | skip rows | head: same results, bit for bit) */
+                                         WN_DECODER_ONE_WORKGROUP: wn_decoder_run of that kernel on ONE workgroup instead of
+                                         nine (the chain | eight workgroups of skip rows and their share of the logits):
+                                         same products, another summation order for the skip rows and the logits --
+                                         probabilities agree to ~1e-7, sampled tokens can differ at a near-tie of the
+                                         cumulative distribution; each form is deterministic */
 } WnDecoderDesc;
 
 int wn_decoder_create(void** handle, const WnDecoderDesc* desc, void* stream);
@@ -279,6 +284,13 @@ int wn_decoder_step(void* handle, int32_t token, float* prob, int apply_softmax,
  * receives the n emitted tokens; prob_trace (n*Q) is optional.                                  */
 int wn_decoder_run(void* handle, int32_t first_token, const double* uniforms, int n,
                    int32_t* out_tokens, float* prob_trace, void* stream);
+/* ABI 4.  wn_decoder_run's default form runs on nine workgroups that hand values to each other through device memory and
+ * therefore must all be resident.  The library uses the one-workgroup kernel by itself on a device with fewer than nine
+ * CUs; what it cannot know in advance -- other work holding the CUs for seconds -- ends in a wait that GIVES UP after
+ * ~1-2 s: no trap, no hang, the launch runs to its end, the HIP context survives, but the tokens of that run are void.
+ * wn_decoder_status synchronises `stream` and returns WN_OK, or WN_ETIMEOUT when the last wn_decoder_run on this handle
+ * gave up a wait (re-create the handle with WN_DECODER_ONE_WORKGROUP and decode again). */
+int wn_decoder_status(void* handle, void* stream);
 /* categorical draw with numpy's algorithm for n independent rows (generate.py:39) */
 int wn_sample_categorical(const float* prob, const double* uniforms, int32_t* out, int n, int Q,
                           void* stream);
@@ -301,7 +313,12 @@ int wn_sqnorm(const float* grad, const float* param, int64_t n, float grad_mult,
 /* Chainer Adam with the reference's hooks folded in, in hook order:
  *   g = grad*grad_mult + wd*param;   g *= min(1, clip/sqrt(*sqnorm))  (sqnorm != NULL, clip > 0)
  *   m += (1-b1)(g-m); v += (1-b2)(g^2-v); param -= lr_t * m / (sqrt(v)+eps).
- * lr_t = alpha*sqrt(1-b2^t)/(1-b1^t) is computed by the host.                                   */
+ * lr_t = alpha*sqrt(1-b2^t)/(1-b1^t) is computed by the host.
+ * ABI 4: when sqnorm is given (clip > 0) and *sqnorm is not finite, the WHOLE update is skipped -- param, m and v keep
+ * their values (every update rule below does the same).  A void gradient (a backward whose multi-layer launch gave up
+ * a wait and flagged it with a NaN, an overflow) then costs one step instead of the optimiser state; under data
+ * parallelism the all-reduce carries the NaN to every rank and every rank skips the same step.  The host can read the
+ * word back whenever it likes (wavenet_amd: WaveNet.last_update_applied()).                        */
 int wn_adam_step(float* param, const float* grad, float* m, float* v, int64_t n,
                  float lr_t, float beta1, float beta2, float eps, float weight_decay,
                  const float* sqnorm, float clip, float grad_mult, void* stream);

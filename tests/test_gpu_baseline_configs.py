@@ -281,3 +281,42 @@ def test_multi_layer_backward_soak_two_runs_of_300_replayed_steps_agree_bit_for_
     assert np.isfinite(ws[0]).all() and losses[0][1] < losses[0][0]
     assert losses[0] == losses[1]
     np.testing.assert_array_equal(ws[0], ws[1])
+
+
+def test_bench_eight_ranks_rehearsed_on_one_gpu():
+    """VERDICT r4 next #5a: BASELINE configs[2] (8 GPUs, global batch 64) has never run for want of an 8-GPU node; what one
+    GPU can rehearse is the 8-rank LAUNCH: `python bench.py --gpus 8` starts eight child ranks itself (before any GPU call),
+    WAVENET_BENCH_SHARE_GPU=1 puts them all on cuda:0 over gloo, every rank captures the two-graph data-parallel step on its own
+    shard of the GLOBAL batch (make_batch(rank, 8): clip b carries phi_b = 2 pi b / 64), the gradient arena is all-reduced
+    over eight ranks between the graphs, timing is barrier-bracketed with MAX over ranks.  Checked: one JSON line, world size
+    8, eight rank records, global batch 64, and every rank's first clip is the clip make_batch gives that rank (all eight
+    different).  It measures no scaling -- it removes "first time eight ranks ever ran" from the day a node appears."""
+    import json
+    import subprocess
+    import sys
+    import bench
+    from wavenet_amd import data
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WAVENET_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-decode", "--no-wide"], env=env, capture_output=True, text=True,
+                       timeout=1500, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["dist"]["world_size"] == 8 and len(out["dist"]["ranks"]) == 8
+    assert out["config"]["global_batch"] == 64 and out["config"]["parallelism"] == "dp8" and out["scaling"] == "weak"
+    assert np.isfinite(out["loss"]) and out["value"] > 0
+    heads = []
+    for rk in sorted(out["dist"]["ranks"], key=lambda d: d["rank"]):
+        assert "fwd+bwd graph" in rk["launch"], rk
+        b0 = rk["rank"] * bench.B_PER_GPU
+        assert rk["global_clips"] == [b0, b0 + bench.B_PER_GPU]
+        wav = data.synthetic_waveform(1, bench.T + 1, 16000, b0=b0, Btot=8 * bench.B_PER_GPU)  # that rank's first clip
+        want = data.mulaw_encode(wav)[0, :16].tolist()
+        assert rk["first_tokens"] == want, (rk["rank"], rk["first_tokens"], want)
+        heads.append(tuple(rk["first_tokens"]))
+    assert len(set(heads)) == 8                                                            # eight different shards

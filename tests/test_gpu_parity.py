@@ -424,6 +424,37 @@ def test_adam_step_matches_chainer_rule():
         np.testing.assert_allclose(to_np(net._arena), P, atol=2e-6)
 
 
+@pytest.mark.parametrize("poison", ["nan", "inf"])
+def test_a_step_with_a_non_finite_gradient_norm_is_skipped_and_the_next_one_is_not(poison):
+    """a void backward must be recoverable.  The multi-layer backward launches flag a dataflow wait that
+    gave up with a NaN in a weight gradient; before ABI 4 that NaN went straight into Adam's m / v and the weights, for good
+    (and through the all-reduce onto every rank).  Now the optimiser kernels read the global gradient norm on the device and
+    skip the WHOLE update when it is not finite: weights, m, v bit-for-bit unchanged, `last_update_applied()` False; the next
+    finite step applies as if nothing had happened (same result as a model that never saw the poisoned step, except Adam's
+    step counter, which the host advances)."""
+    p, w, net = build(CFG1, gradient_clipping=1.0)
+    net.update_laerning_rate(0.001)
+    rs = np.random.RandomState(1)
+    g0 = (rs.standard_normal(net._arena.numel()) * 0.01).astype(np.float32)
+    net._grad_arena.copy_(dev(g0))
+    net.optimizer.update(1.0)
+    assert net.last_update_applied()
+    P1, m1, v1 = to_np(net._arena).copy(), to_np(net.optimizer.m).copy(), to_np(net.optimizer.v).copy()
+    assert np.abs(m1).max() > 0
+    bad = g0.copy()
+    bad[12345 % bad.size] = np.nan if poison == "nan" else np.inf
+    net._grad_arena.copy_(dev(bad))
+    net.optimizer.update(1.0)
+    assert not net.last_update_applied()
+    np.testing.assert_array_equal(to_np(net._arena), P1)
+    np.testing.assert_array_equal(to_np(net.optimizer.m), m1)
+    np.testing.assert_array_equal(to_np(net.optimizer.v), v1)
+    net._grad_arena.copy_(dev(g0))
+    net.optimizer.update(1.0)
+    assert net.last_update_applied()
+    assert np.isfinite(to_np(net._arena)).all() and np.abs(to_np(net._arena) - P1).max() > 0
+
+
 def test_eve_step_matches_the_reference_class():
     """optimizer = "eve": wn_eve_step + the host's loss-feedback scalars vs the literal restatement of wavenet.py:10-79."""
     p, w, net = build(CFG1, gradient_clipping=0.0)

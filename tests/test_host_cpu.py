@@ -234,6 +234,26 @@ def test_hdf5_checkpoint_round_trip_and_load_prefers_the_reference_file(tmp_path
         b.load_hdf5(str(tmp_path / "missing.model"))
 
 
+def test_load_takes_the_newer_of_the_two_weight_files(tmp_path):
+    """a reference-written `wavenet.model` dropped next to an OLDER `wavenet.model.npz` must win (load() used
+    to prefer the .npz whenever it existed); the other way round the .npz wins."""
+    _need_hdf5()
+    from wavenet_amd import Params, WaveNet
+    old, new = WaveNet(Params(_TINY), seed=5), WaveNet(Params(_TINY), seed=6)
+    for newer in ("h5", "npz"):
+        d = tmp_path / newer
+        d.mkdir()
+        (old if newer == "h5" else new).save_hdf5(str(d / "wavenet.model"))            # placeholder, overwritten below
+        np.savez(str(d / "wavenet.model.npz"), **(old if newer == "h5" else new).state_dict())
+        (new if newer == "h5" else old).save_hdf5(str(d / "wavenet.model"))
+        t0 = os.path.getmtime(str(d / "wavenet.model.npz"))
+        os.utime(str(d / "wavenet.model"), (t0 + (10 if newer == "h5" else -10),) * 2)
+        net = WaveNet(Params(_TINY), seed=7)
+        net.load(str(d))
+        for k, v in new.state_dict().items():
+            assert np.array_equal(net.state_dict()[k], v), (newer, k)
+
+
 def test_hdf5_files_written_here_are_read_by_h5py(tmp_path):
     """The other direction, when the image's second interpreter (the one that has h5py) exists: h5py must see float32
     datasets at Chainer's paths with the values written."""

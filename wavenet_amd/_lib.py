@@ -85,6 +85,7 @@ _SIGS = {
     "wn_decoder_load_state": (_i, [_p, _p, _i, _pp, _pp, _p]),
     "wn_decoder_step": (_i, [_p, C.c_int32, _p, _i, _p]),
     "wn_decoder_run": (_i, [_p, C.c_int32, _p, _i, _p, _p, _p]),
+    "wn_decoder_status": (_i, [_p, _p]),
     "wn_sample_categorical": (_i, [_p, _p, _p, _i, _i, _p]),
     "wn_sqnorm": (_i, [_p, _p, _i64, _f, _f, _p, _p]),
     "wn_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _f, _f, _p]),
@@ -197,7 +198,7 @@ GEMM_PRECISIONS = ("fp32", "bf16x3", "bf16", "fp16x2")
 WN_EXEC_FORCE_GENERIC, WN_EXEC_NO_FUSED_WIDE, WN_EXEC_NO_FWD_GROUPS, WN_EXEC_NO_PIPELINED_GEMM = 1, 2, 4, 8
 WN_EXEC_NO_MULTI_LAYER_BWD = 16
 WN_EXEC_BF16_MULTI_LAYER_BWD = 32     # bf16 storage: the layer backward of layers L-2 .. 1 in one launch (opt-in; no faster, bit-identical)
-WN_DECODER_ONE_WORKGROUP = 64          # WnDecoderDesc.flags: wn_decoder_run on one workgroup instead of three
+WN_DECODER_ONE_WORKGROUP = 64          # WnDecoderDesc.flags: wn_decoder_run on one workgroup instead of nine (other summation order: ~1e-7)
 
 
 def default_exec_flags() -> int:

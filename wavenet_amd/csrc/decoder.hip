@@ -40,7 +40,8 @@ struct Decoder {
     size_t lds_bytes = 0;
     float* fastP = nullptr;       // packed weights of the specialised kernel (decoder_fast.hip), or NULL
     int head_bias_off = -1;
-    bool three_wgs = true;        // wn_decoder_run on three workgroups (decoder_fast.hip); WN_DECODER_ONE_WORKGROUP clears it
+    bool three_wgs = true;        // wn_decoder_run on nine workgroups (decoder_fast.hip); WN_DECODER_ONE_WORKGROUP clears it
+    bool ran_multi = false;       // a nine-workgroup run has been launched (its error entry is meaningful)
 };
 
 // the shape decoder_fast.hip is written for (BASELINE.json config 4 with the reference's default biases)
@@ -516,6 +517,7 @@ int wn_decoder_run(void* handle, int32_t first_token, const double* uniforms, in
                                     (int)first_token, uniforms, out_tokens, prob_trace, D->meta.Q, 1, 1,
                                     D->meta.head_act, D->three_wgs, as_stream(stream));
         if (rc) return rc;
+        D->ran_multi = D->three_wgs && n > 1;
         D->step += n;
         return WN_OK;
     }
@@ -524,6 +526,24 @@ int wn_decoder_run(void* handle, int32_t first_token, const double* uniforms, in
                        out_tokens, prob_trace, D->meta.Q, 1, 1);
     WN_LAUNCH_CHECK();
     D->step += n;
+    return WN_OK;
+}
+
+int wn_decoder_status(void* handle, void* stream) {
+    Decoder* D = (Decoder*)handle;
+    WN_CHECK_ARG(D, "wn_decoder_status: NULL handle");
+    if (!D->fastP || !D->ran_multi) {                   // nothing that could have given up has run
+        WN_HIP(hipStreamSynchronize(as_stream(stream)));
+        return WN_OK;
+    }
+    int gave_up = 0;
+    const int rc = decode_fast_status(D->fastP, D->meta.nlayers, as_stream(stream), &gave_up);
+    if (rc) return rc;
+    if (gave_up) {
+        wn::set_error("wn_decoder_run: a wait between the nine workgroups gave up (they were not all resident); the tokens of "
+                      "that run are void -- re-create the decoder with WN_DECODER_ONE_WORKGROUP");
+        return WN_ETIMEOUT;
+    }
     return WN_OK;
 }
 

@@ -234,12 +234,24 @@ typedef unsigned long long u64;
 __device__ __forceinline__ void xput(u64* p, float v, unsigned seq) {
     __hip_atomic_store(p, ((u64)seq << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float xget(const u64* p, unsigned seq) {            // spin (bounded) until the entry is this step's
+// Cross-workgroup waits never trap and never hang: an entry that does not arrive within ~1-2 s is given up -- the waiting
+// thread marks the launch void in the error entry (x_err: read by wn_decoder_status) and from then on waits for nothing
+// (`dead`), so every workgroup still runs to the end of the launch and the HIP context survives; the tokens of such a run
+// are garbage and the host is told so.  (It happens when the nine workgroups are not all resident: a device with fewer
+// free CUs than workgroups, other work holding them for seconds.)
+__device__ __forceinline__ float xget(const u64* p, unsigned seq, u64* err, bool& dead) {
     int spins = 0;
-    u64 w;
+    u64 w = 0;
+    if (dead) return 0.f;
     while ((unsigned)((w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != seq) {
         __builtin_amdgcn_s_sleep(XSLEEP);
-        if (++spins > (1 << 21)) __builtin_trap();       // (a global poll is ~0.5 us: a second or two, then abort -- never a hang)
+        ++spins;
+        // after a while also look at the error entry: when another workgroup has given up, this entry may never come
+        if (spins > (1 << 21) || ((spins & 0xfff) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            __hip_atomic_store(err, (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dead = true;
+            return 0.f;
+        }
     }
     return __uint_as_float((unsigned)w);
 }
@@ -580,7 +592,8 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast(
 static constexpr int kXZ = 0;                                   // X layout (u64 entries): z [L][64] | partial logits [8][256]
 static constexpr int kD10MaxL = 40;
 static constexpr int kD10Skip = 8;                              // skip workgroups
-__device__ __forceinline__ int x_pl(int nlayers) { return nlayers * 64; }
+__device__ __host__ __forceinline__ int x_pl(int nlayers) { return nlayers * 64; }
+__device__ __host__ __forceinline__ int x_err(int nlayers) { return nlayers * 64 + 8 * 256 + 8; }   // != 0: a wait gave up, the run is void
 
 __global__ __launch_bounds__(kFT, 1) void k_decode_fast3(
     const float* __restrict__ P, const float* __restrict__ Ph, const float* __restrict__ hbias,
@@ -605,6 +618,7 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast3(
             w[l] = l < nlayers ? *reinterpret_cast<const float4*>(P + (long long)l * kLayerFloats + kGateFloats + kProjFloats +
                                                                   ((row & 1) * 8 + sl) * 512 + 4 * (row >> 1))
                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        bool dead = false;                                            // a wait of this thread gave up: wait for nothing any more
         for (int it = 0; it < nsteps; ++it) {
             const unsigned seq = (unsigned)(it + 1);
             float acc = 0.f;
@@ -614,7 +628,7 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast3(
                     // a poll is a round trip to memory: the four waves fetch EIGHT layers per round trip (wave w the layers
                     // l0 + 2 w and l0 + 2 w + 1, one per half wave) into a shared table; the chain needs ~0.55 us per layer
                     const int lp = l0 + 2 * wv + (lane >> 5);
-                    if (lp < nlayers) zs[lp * 32 + (lane & 31)] = xget(X + kXZ + lp * 64 + (lane & 31), seq);
+                    if (lp < nlayers) zs[lp * 32 + (lane & 31)] = xget(X + kXZ + lp * 64 + (lane & 31), seq, X + x_err(nlayers), dead);
                     lds_barrier();
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
@@ -658,6 +672,7 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast3(
     const float hb = hbias ? hbias[tid] : 0.f;
     __syncthreads();
     FastLds S{xold, xcur, zall, aold, ready, ready + 1};
+    bool dead0 = false;                                   // this thread's wait for the logit shares gave up: wait for nothing any more
 
     for (int it = 0; it < nsteps; ++it) {
         const unsigned n = (unsigned)(n0 + it);
@@ -740,9 +755,15 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast3(
                 for (int k = 0; k < kD10Skip; ++k) wd[k] = __hip_atomic_load(e + k * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
                 for (int k = 0; k < kD10Skip; ++k) ok = ok && (unsigned)(wd[k] >> 32) == seq;
-                if (ok) break;
+                if (ok || dead0) break;
                 __builtin_amdgcn_s_sleep(1);
-                if (++spins > (1 << 21)) __builtin_trap();
+                ++spins;
+                if (spins > (1 << 21) || ((spins & 0xfff) == 0 &&
+                                          __hip_atomic_load(X + x_err(nlayers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    // given up (see xget): the launch is void, say so, and wait for nothing from here on
+                    __hip_atomic_store(X + x_err(nlayers), (u64)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    dead0 = true;
+                }
             }
             v = hb;
 #pragma unroll
@@ -864,6 +885,15 @@ int decode_fast_launch(const float* P, int nlayers, const float* hbias, const fl
         attr = true;
     }
     if (three_wgs && nsteps > 1 && nsteps < (1 << 30) && nlayers <= kD10MaxL) {
+        // nine workgroups that wait for each other: the device the stream belongs to must be able to hold them at once (asked
+        // per device, per call: cheap, and a process may drive several devices).  What the count cannot see -- other work
+        // holding the CUs for seconds -- ends in a given-up wait that wn_decoder_status reports (no trap, no hang).
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < kD10Skip + 1)
+            three_wgs = false;
+    }
+    if (three_wgs && nsteps > 1 && nsteps < (1 << 30) && nlayers <= kD10MaxL) {
         // the exchange entries live behind the packed weights (decode_fast_pack_floats); cleared by a kernel, in stream order
         u64* X = reinterpret_cast<u64*>(const_cast<float*>(P) + (size_t)nlayers * kLayerFloats + 256 * 256);
         const int nx = nlayers * 64 + 8 * 256 + 16;
@@ -881,6 +911,16 @@ int decode_fast_launch(const float* P, int nlayers, const float* hbias, const fl
                        P + (size_t)nlayers * kLayerFloats, hbias, E, layers, nlayers, arena, tok_ring, n0, nsteps,
                        first_token, uniforms, out_tokens, prob_out, prob_stride, apply_softmax, do_sample, head_act);
     WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+// 0 = the last nine-workgroup run's exchange completed; 1 = a wait gave up (its tokens are void).  Synchronises the stream.
+int decode_fast_status(const float* P, int nlayers, hipStream_t s, int* gave_up) {
+    const u64* X = reinterpret_cast<const u64*>(P + (size_t)nlayers * kLayerFloats + 256 * 256);
+    u64 w = 0;
+    WN_HIP(hipMemcpyAsync(&w, X + x_err(nlayers), sizeof(w), hipMemcpyDeviceToHost, s));
+    WN_HIP(hipStreamSynchronize(s));
+    *gave_up = w != 0 ? 1 : 0;
     return WN_OK;
 }
 

@@ -14,4 +14,5 @@ int decode_fast_launch(const float* P, int nlayers, const float* hbias, const fl
                        float* arena, int* tok_ring, long long n0, int nsteps, int first_token,
                        const double* uniforms, int32_t* out_tokens, float* prob_out, int prob_stride,
                        int apply_softmax, int do_sample, int head_act, bool three_wgs, hipStream_t s);
+int decode_fast_status(const float* P, int nlayers, hipStream_t s, int* gave_up);
 }  // namespace wn

@@ -770,6 +770,11 @@ __global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float
     float rate = 1.f;
     if (sqnorm && clip > 0.f) {
         float nrm = sqrtf(*sqnorm);
+        // A gradient whose global norm is not finite is no gradient: the whole update is skipped -- weights, m and v stay as
+        // they are -- instead of writing NaN into the optimiser state for good.  (Chainer would apply it; no caller can want
+        // that.  It is what makes a void backward recoverable: the multi-layer launches flag a wait that gave up with a NaN
+        // in a weight gradient, the all-reduce carries it to every rank, and every rank skips the same step.)
+        if (!(nrm < 3.0e38f)) return;
         if (nrm > 0.f && clip / nrm < 1.f) rate = clip / nrm;
     }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -802,6 +807,7 @@ __global__ void k_rule(float* __restrict__ p, const float* __restrict__ g, float
     float rate = 1.f;
     if (sqnorm && clip > 0.f) {
         float nrm = sqrtf(*sqnorm);
+        if (!(nrm < 3.0e38f)) return;      // non-finite gradient norm: the update is skipped (see k_adam)
         if (nrm > 0.f && clip / nrm < 1.f) rate = clip / nrm;
     }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;

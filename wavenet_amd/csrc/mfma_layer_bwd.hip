@@ -258,8 +258,9 @@ __device__ __forceinline__ void lb_h2_product(const H2Op& a, const H2Op& b, floa
 // any workgroup may request the next layer's (V, U).)  Every tile of the gradient stream has a word in device memory
 // holding the number of entries it has completed.  Entry e's tile X (rows 32 X ..) may
 //   * READ  V[X] and U[X + dU/32 (+1)] of entry e - 1 once those tiles have completed e - 1, i.e. show >= e, and
-//   * WRITE its own V, U -- into the buffer entry e - 1 read (two buffers, ping-pong) -- once the READERS of those rows
-//     in entry e - 1, tiles X and X - dU'/32 (-1), show >= e as well,
+//   * WRITE its own V, U -- (V, U) rotate through THREE buffer pairs: entry e writes the pair entry e - 2 read, so the
+//     write-after-read distance is two entries -- once the READERS of those rows, tiles X and X - dU'/32 (-1) of the entry
+//     that read them, show that entry done,
 // so one test, "five words >= e", covers both; tiles the previous entry did not process (below its live range, outside the
 // clip) impose nothing.  A wave publishes a tile (one sc1 store of e + 1) when the tile's stores have been counted by
 // vmcnt -- at the top of the next loop body, whose wait already guarantees it -- and requests the words of the tile it
@@ -1442,8 +1443,8 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
     return WN_OK;
 }
 
-// Entries 0 .. n-1 (stack layers layer[0] > layer[1] > ...) in ONE launch of co-resident workgroups with a grid barrier
-// between layers (k_layer_bwd_chain_multi).  Only the fp16 x 2 form reading z and sigmoid (FROM_Z), every layer with V, U
+// Entries 0 .. n-1 (stack layers layer[0] > layer[1] > ...) in ONE launch of co-resident workgroups that follow per-tile
+// dataflow words -- no grid barrier -- (k_layer_bwd_chain_multi).  Only the fp16 x 2 form reading z and sigmoid (FROM_Z), every layer with V, U
 // and dz_skip inputs.  `sync` points at mfma_chain_multi_sync_words(B, T) words of device memory (zeroed here).  *nwg receives the number of partial tiles
 // every layer writes (= the grid).
 __global__ void k_chain_zero_sync(unsigned* sync, int n) {
@@ -1472,17 +1473,29 @@ int mfma_layer_bwd_chain_multi(int n, const int* layer, const float* const* Wf, 
         if (bl > blocks) blocks = bl;
     }
     if (blocks > kCMaxBlocks) blocks = kCMaxBlocks;
-    // every workgroup must be RESIDENT (they wait for each other's tiles): one per CU by LDS footprint, so no more workgroups
-    // than the device has CUs.  (The waits are bounded -- a tile that never comes is given up after ~0.3 s and flagged in
-    // sync[0] -- so a violated assumption costs time and the result, never the GPU.)
+    // every workgroup must be RESIDENT (they wait for each other's tiles).  Asked PER DEVICE (the stream's): the occupancy of
+    // this kernel's 256 threads / kCLdsBytes of LDS x the device's CUs -- not a count cached for the first device a process
+    // happened to use.  What the query cannot see (another process on the GPU, a CU mask) is caught at run time: a wait that
+    // does not end gives up after ~0.3 s, flags sync[0] and poisons the layer's weight gradient with a NaN, and the optimiser
+    // kernels skip a step whose gradient norm is not finite (wn_adam_step, ABI 4) -- a violated assumption costs time and one
+    // step, never the GPU and never the training state.
     {
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            WN_HIP(hipGetDevice(&dev));
+        int dev = 0;
+        WN_HIP(hipGetDevice(&dev));
+        static int capacity[64];                        // per device; 0 = not asked yet (a benign race: every thread writes the same value)
+        if (dev < 0 || dev >= 64) { wn::set_error("mfma_layer_bwd_chain_multi: device index %d", dev); return WN_ESHAPE; }
+        if (!capacity[dev]) {
+            int n_cu = 0, per_cu = 0;
             WN_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chain_multi<true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kCLdsBytes));
+            WN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_layer_bwd_chain_multi<true, true>, 256, kCLdsBytes));
+            capacity[dev] = n_cu * per_cu > 0 ? n_cu * per_cu : -1;
         }
-        if (blocks > n_cu) { wn::set_error("mfma_layer_bwd_chain_multi: %d workgroups on %d CUs", blocks, n_cu); return WN_ESHAPE; }
+        if (blocks > capacity[dev]) {
+            wn::set_error("mfma_layer_bwd_chain_multi: %d workgroups, %d resident on device %d", blocks, capacity[dev], dev);
+            return WN_ESHAPE;
+        }
     }
     {   // the rotation of the deal (see `partition` in chain_body): entry i + 1 starts where entry i's surplus tiles ended
         const bool xcd = (blocks & 7) == 0 && (B & 7) == 0;
@@ -1506,12 +1519,6 @@ int mfma_layer_bwd_chain_multi(int n, const int* layer, const float* const* Wf, 
     const int nsync = (int)mfma_chain_multi_sync_words(B, T);
     hipLaunchKernelGGL(k_chain_zero_sync, dim3(cdiv(nsync, 256)), dim3(256), 0, s, sync, nsync);
     WN_LAUNCH_CHECK();
-    static bool attr_set = false;
-    if (!attr_set) {
-        WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chain_multi<true, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kCLdsBytes));
-        attr_set = true;
-    }
     hipLaunchKernelGGL((k_layer_bwd_chain_multi<true, true>), dim3(blocks), dim3(256), kCLdsBytes, s, a);
     WN_LAUNCH_CHECK();
     return WN_OK;

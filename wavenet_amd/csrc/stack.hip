@@ -242,7 +242,8 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
         int vu_t0 = 0;                               // first written row of Vin / Uin
         wn::ProfScope prof__("wn_layer_bwd", stream);        // one bracket: 40 layer kernels + the tile reduction
         // fp16 x 2, z + sigmoid saved, loss on the skip sum: every layer that has V, U and dz_skip inputs (all but the top
-        // one) runs in ONE launch with grid barriers between layers (k_layer_bwd_chain_multi); the per-layer loop below
+        // one) runs in ONE launch of co-resident workgroups following per-tile dataflow words (k_layer_bwd_chain_multi: no grid
+        // barrier); the per-layer loop below
         // then only collects their parameters
         const bool multi = gemm_mode() == WN_GEMM_FP16X2 && f == nullptr && dskip && d->Cs % 32 == 0 && L >= 3 &&
                            L - 1 <= mfma_chain_multi_max_layers() && !exec_flag(WN_EXEC_NO_MULTI_LAYER_BWD);
@@ -275,7 +276,7 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
                                             m_d.data(), m_Z.data(), m_live.data(), m_vu_t0.data(), m_dU.data(), x, xs, z, g,
                                             ws /* dz of layer l at ws + l n 32 */, Vb, Ub, parts, mfma_chain_part_floats(),
                                             sync, B, T, t_off, &grid, as_stream(stream));
-            if (rc == WN_ESHAPE) {                  // fewer CUs than workgroups: one launch per layer after all
+            if (rc == WN_ESHAPE) {                  // not every workgroup would be resident on this device: one launch per layer after all
                 wn::set_error("");
                 for (size_t i = 0; i < m_layer.size(); ++i) {
                     const int l = m_layer[i];

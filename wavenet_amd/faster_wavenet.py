@@ -211,6 +211,9 @@ class FasterWaveNet(WaveNet):
             first = int(out[0].item())
             check(lib.wn_decoder_run(self._decoder(), first, ptr(u[1:]), n_samples - 1, ptr(out[1:]),
                                      ptr(probs[1:]) if return_probs else None, stream_ptr()), "wn_decoder_run")
+            # the nine-workgroup run reports a wait that gave up (workgroups not all resident) instead of trapping: its
+            # tokens would be void.  One 8-byte read-back; generate() hands tokens to the host anyway.
+            check(lib.wn_decoder_status(self._decoder(), stream_ptr()), "wn_decoder_status")
             # the decoder advanced n_samples - 1 steps on the device (its rings are current: step-by-step decoding may go
             # on from here), but the host-side window history -- what _forward_one_step(..., full_window=True) returns
             # the older columns from -- still holds the prefill state: drop it rather than answer with a stale window

@@ -76,9 +76,23 @@ def _load() -> C.CDLL:
             "H5Pset_chunk": (C.c_int, [_hid, C.c_int, C.POINTER(_hsize)]), "H5Pset_deflate": (C.c_int, [_hid, C.c_uint]),
             "H5Eset_auto2": (C.c_int, [_hid, C.c_void_p, C.c_void_p]),
         }
-        for name, (res, args) in sig.items():
-            fn = getattr(lib, name)
-            fn.restype, fn.argtypes = res, args
+        # H5Lvisit is a plain symbol in 1.10 only; from 1.12 on it is a versioned macro and the library exports H5Lvisit2
+        # (and H5Lvisit1).  The callback ignores its info argument, so one prototype serves all three.
+        visit = None
+        for vname in ("H5Lvisit2", "H5Lvisit1", "H5Lvisit"):
+            if hasattr(lib, vname):
+                visit = getattr(lib, vname)
+                break
+        if visit is None:
+            continue
+        try:
+            for name, (res, args) in sig.items():
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+        except AttributeError:
+            continue
+        visit.restype, visit.argtypes = C.c_int, [_hid, C.c_int, C.c_int, _LINK_CB, C.c_void_p]
+        lib._wn_lvisit = visit
         lib.H5Eset_auto2(0, None, None)                    # errors come back as return codes, not as a printed stack
         _lib = lib
         return lib
@@ -111,11 +125,9 @@ def read_datasets(path: str) -> Dict[str, np.ndarray]:
         raise OSError("cannot open %s as HDF5" % path)
     names: list = []
     cb = _LINK_CB(lambda g, name, info, data: names.append(name) or 0)
-    lib.H5Lvisit.restype = C.c_int
-    lib.H5Lvisit.argtypes = [_hid, C.c_int, C.c_int, _LINK_CB, C.c_void_p]
     out: Dict[str, np.ndarray] = {}
     try:
-        if lib.H5Lvisit(f, 0, 0, cb, None) < 0:             # H5_INDEX_NAME, H5_ITER_INC
+        if lib._wn_lvisit(f, 0, 0, cb, None) < 0:           # H5_INDEX_NAME, H5_ITER_INC
             raise OSError("walking the links of %s failed" % path)
         for name in names:
             o = lib.H5Oopen(f, name, 0)

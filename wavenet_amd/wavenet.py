@@ -804,6 +804,18 @@ class WaveNet(object):
             self.optimizer.update(gmult)
         self._weights_changed()
 
+    def last_update_applied(self) -> bool:
+        """False when the most recent optimiser step was SKIPPED on the device because the global gradient norm was not
+        finite (wn_adam_step, ABI 4: the weights and the optimiser state are untouched by such a step).  Reads one word back
+        (a host synchronisation): for the training loop's occasional health check, not for every step.  A caller that sees
+        False after a step of the multi-layer backward can set ``exec_flags |= WN_EXEC_NO_MULTI_LAYER_BWD`` and go on --
+        the only thing in the library that produces a NaN on purpose is a dataflow wait of that launch that gave up
+        (workgroups not co-resident: another process on the GPU, a CU mask)."""
+        nrm = getattr(self.optimizer, "_norm", None)
+        if nrm is None or not self.params.gradient_clipping or self.params.gradient_clipping <= 0:
+            return True                                                  # no clipping hook, no norm: nothing is ever skipped
+        return bool(torch.isfinite(nrm[0]).item())
+
     # -- device --------------------------------------------------------------------------------
     def to_gpu(self, device=None):
         if not torch.cuda.is_available():
@@ -1006,14 +1018,21 @@ class WaveNet(object):
         self.load_state_dict({k: v for k, v in sd.items() if k in self.state_dict()})
 
     def load(self, model_dir="./"):
-        fn = os.path.join(model_dir, "wavenet.model")              # the reference's own HDF5 file, if h5py can read it
-        if os.path.isfile(fn) and not os.path.isfile(fn + ".npz"):
-            print("loading", fn, "...")
-            self.load_hdf5(fn)
-        fn = os.path.join(model_dir, "wavenet.model.npz")
-        if os.path.isfile(fn):                                     # silently skipped when absent, like the reference
-            print("loading", fn, "...")
-            with np.load(fn) as z:
+        """wavenet.py:627-639.  Two weight files may sit in the directory: the reference's own HDF5 ``wavenet.model`` and this
+        package's ``wavenet.model.npz``; the NEWER one (modification time) is loaded, and it is said which when both exist --
+        a reference-written checkpoint dropped next to an older .npz must not be ignored silently."""
+        h5 = os.path.join(model_dir, "wavenet.model")
+        nz = os.path.join(model_dir, "wavenet.model.npz")
+        have_h5, have_nz = os.path.isfile(h5), os.path.isfile(nz)
+        use_h5 = have_h5 and (not have_nz or os.path.getmtime(h5) > os.path.getmtime(nz))
+        if have_h5 and have_nz:
+            print("both %s and %s exist: loading the newer one (%s)" % (h5, nz, h5 if use_h5 else nz))
+        if use_h5:
+            print("loading", h5, "...")
+            self.load_hdf5(h5)
+        elif have_nz:                                              # silently skipped when absent, like the reference
+            print("loading", nz, "...")
+            with np.load(nz) as z:
                 self.load_state_dict({k: z[k] for k in z.files})
         fn = os.path.join(model_dir, "wavenet.opt.npz")
         if os.path.isfile(fn):
