@@ -70,6 +70,12 @@ def newest_profile(pattern):
     return best[1] if best else None
 
 
+# `dtype` of the JSON line: what the path computes in, said so that the line needs no footnote ("keep
+# fp16x2 as `value` but rename `dtype` to say so").  Storage and accumulation are fp32 in every mode.
+DTYPE_TEXT = {"fp32": "f32", "bf16x3": "f32 (products: 3 x bf16 split, 6 MFMA terms; fp32-exact layer kernels)",
+              "bf16": "f32 storage / bf16 products", "fp16x2": "f32 storage+accumulate / fp16x2 split products (2^-21)"}
+
+
 def arith_record(mode):
     """What multiplies in the timed step, and how far that arithmetic is from the float64 truth next to the exact-fp32
     mode (measured by tests/test_gpu_arith_error.py on the GPU; its committed output is quoted, not recomputed: the oracle
@@ -77,7 +83,13 @@ def arith_record(mode):
     rec = {"mode": mode, "storage": "f32", "accumulate": "f32", "multiply": ARITH_SHORT[mode],
            "like_for_like_with_reference": mode == "fp32",
            "note": "value / ms_per_step are measured in `mode`; ms_per_step_by_mode holds the same captured step in every "
-                   "shipped mode (fp32 = exact fp32 products, the reference's arithmetic)"}
+                   "shipped mode (fp32 = exact fp32 products, the reference's arithmetic)",
+           "why_not_an_fp32_accurate_headline": "measured round 5 (gpurun_out/bymode.log, DESIGN.md): the skip-path contractions "
+                   "alone cost + 0.372 ms with six-term (fp32-accurate) products instead of three (1.133 vs 0.761 ms) -- "
+                   "+ 12.3 % of the 3.026 ms step before the fused layer kernels are touched (they would need twice the MFMAs "
+                   "and ~twice the split instructions; on exact fp32 MFMA they cost another + 0.82 ms) -- so an accurate mode "
+                   "cannot come within 12 % of fp16x2; the distance of BOTH from the float64 truth is the same "
+                   "(error_vs_float64_truth)"}
     f = newest_profile("arith_error_vs_fp64.json")
     if f:
         doc = json.load(open(f))
@@ -377,7 +389,7 @@ def main():
         "timing": "ms_per_step = median of the K per-step HIP-event intervals on the launch stream (MAX over ranks); "
                   "ms_per_step_wall_mean = wall clock over the K steps between barrier + synchronize brackets / K",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": DTYPE_TEXT[_lib.get_gemm_precision()], "data": "synthetic",
         "arith": arith_record(_lib.get_gemm_precision()),
         "gemm_mode": GEMM_MODE_TEXT[_lib.get_gemm_precision()],
         "dtype_note": "dtype names STORAGE and ACCUMULATION (fp32 tensors in HBM, fp32 MFMA accumulators); what the matrix "

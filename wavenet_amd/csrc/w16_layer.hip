@@ -688,9 +688,6 @@ __device__ __forceinline__ bool dx_phase(char* lds, const DxP& P, MSync& ms, boo
     auto dep_wait = [&](int tile, unsigned v) {
         if constexpr (MULTI) {
             unsigned spins = 0;
-#ifdef W16_MULTI_NOWAIT
-            return;                                      // timing build: results are void
-#endif
 #ifdef WN16_MSTAMPS
             const unsigned long long w0 = __builtin_amdgcn_s_memtime();
 #endif
