@@ -612,6 +612,25 @@ def main():
                 out["ar_generate"]["golden_tokens_compared"] = ng
                 out["ar_generate"]["golden_tokens_match"] = bool(np.array_equal(first, gold["tokens"].astype(np.int32)))
                 out["ar_generate"]["golden_checksum"] = [int(first.sum()), int(gold["tokens"].astype(np.int64).sum())]
+            # the same decode for 28 independent utterances in ONE launch (wn_decoder_run_batch: nine workgroups each, 252 of
+            # the 256 CUs): what one GPU generates when it is not limited to one strict sample-to-sample chain.  Utterance 0
+            # uses the golden uniforms again and must reproduce the single-utterance tokens.
+            try:
+                nb = int(_lib.lib().wn_decoder_batch_max())
+                ub = np.random.RandomState(8).random_sample((nb, n))
+                ub[0] = u
+                net.generate_batch(64, ub[:, :64])                       # warm-up (creates the handles)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                tb = net.generate_batch(n, ub)
+                torch.cuda.synchronize()
+                bdt = time.perf_counter() - t0
+                out["ar_generate_batch"] = {"utterances": nb, "samples_each": n, "seconds": bdt,
+                                            "samples_per_s_aggregate": nb * n / bdt, "samples_per_s_per_utterance": n / bdt,
+                                            "utterance0_equals_single_run": bool(torch.equal(tb[0], toks)),
+                                            "workload": "cfg4 x %d independent utterances in one launch (9 workgroups each)" % nb}
+            except Exception as e:                                       # a side record: never the reason a bench run fails
+                out["ar_generate_batch"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if not args.no_wide:
             out["wide_channel"] = wide_channel_step(rank, world)
         if not args.no_cpu_baseline:

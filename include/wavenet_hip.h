@@ -284,6 +284,18 @@ int wn_decoder_step(void* handle, int32_t token, float* prob, int apply_softmax,
  * receives the n emitted tokens; prob_trace (n*Q) is optional.                                  */
 int wn_decoder_run(void* handle, int32_t first_token, const double* uniforms, int n,
                    int32_t* out_tokens, float* prob_trace, void* stream);
+/* ABI 4.  n_handles independent utterances in ONE launch, nine workgroups each (generate.py:9-60 is batch 1 with a strict
+ * sample-to-sample dependency, wavenet.py:286,290,354: a single utterance can use 9 of the GPU's 256 CUs -- the rest can only
+ * run OTHER utterances; SURVEY 8(e) "replicas only", on one GPU).  Every handle is a decoder of its own (wn_decoder_create +
+ * wn_decoder_load_state: its rings, its packed weights), all of the same model shape, none created with
+ * WN_DECODER_ONE_WORKGROUP; uniforms[u] (n doubles), out_tokens[u] (n) and the optional prob_traces[u] (n * Q; the array
+ * itself may be NULL) are device pointers held in HOST arrays, first_tokens is a host array.  At most wn_decoder_batch_max()
+ * (28) utterances, and 9 * n_handles workgroups must fit the device's CUs (WN_ESHAPE otherwise); n >= 2.  The groups share
+ * nothing: an utterance's tokens are those of its own wn_decoder_run with the same uniforms, bit for bit.
+ * wn_decoder_status(handle) reports per utterance as after wn_decoder_run. */
+int wn_decoder_batch_max(void);
+int wn_decoder_run_batch(void* const* handles, int n_handles, const int32_t* first_tokens, const double* const* uniforms, int n,
+                         int32_t* const* out_tokens, float* const* prob_traces, void* stream);
 /* ABI 4.  wn_decoder_run's default form runs on nine workgroups that hand values to each other through device memory and
  * therefore must all be resident.  The library uses the one-workgroup kernel by itself on a device with fewer than nine
  * CUs; what it cannot know in advance -- other work holding the CUs for seconds -- ends in a wait that GIVES UP after

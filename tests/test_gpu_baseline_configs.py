@@ -320,3 +320,26 @@ def test_bench_eight_ranks_rehearsed_on_one_gpu():
         assert rk["first_tokens"] == want, (rk["rank"], rk["first_tokens"], want)
         heads.append(tuple(rk["first_tokens"]))
     assert len(set(heads)) == 8                                                            # eight different shards
+
+
+def test_cfg4_batched_decode_equals_the_single_utterance_runs_bit_for_bit():
+    """VERDICT r4 next #9 / SURVEY 8(e) "AR decode: replicas only" on ONE GPU: wn_decoder_run_batch runs N independent
+    utterances (nine workgroups each, own decoder state) in one launch.  The groups share nothing, so row u of
+    generate_batch(n, uniforms) must equal generate(n, uniforms[u]) token for token -- checked for a full device (28
+    utterances = 252 workgroups), for an odd count (5), and against the committed oracle trace for the utterance that uses
+    the fixture's own uniforms (first 1,500 samples)."""
+    z = np.load(os.path.join(G, "cfg4_decode_trace.npz"))
+    net = FasterWaveNet(Params(R.make_params(**CFG2)), seed=1234)
+    net.to_gpu()
+    n = 1500
+    rs = np.random.RandomState(11)
+    for N in (5, 28):
+        u = rs.random_sample((N, n))
+        u[0] = z["uniforms"][:n]
+        got = to_np(net.generate_batch(n, u))
+        assert got.shape == (N, n)
+        np.testing.assert_array_equal(got[0], z["tokens"][:n].astype(np.int32))           # the oracle's trace
+        for i in (1, N // 2, N - 1):
+            want = to_np(net.generate(n, u[i]))
+            np.testing.assert_array_equal(got[i], want, err_msg="utterance %d of %d" % (i, N))
+        assert len({tuple(r[:64]) for r in got}) == N                                      # and they ARE different utterances

@@ -529,6 +529,42 @@ int wn_decoder_run(void* handle, int32_t first_token, const double* uniforms, in
     return WN_OK;
 }
 
+int wn_decoder_batch_max(void) { return kDecMaxBatch; }
+
+int wn_decoder_run_batch(void* const* handles, int n_handles, const int32_t* first_tokens, const double* const* uniforms, int n,
+                         int32_t* const* out_tokens, float* const* prob_traces, void* stream) {
+    WN_CHECK_ARG(handles && first_tokens && uniforms && out_tokens && n_handles >= 1 && n > 0, "wn_decoder_run_batch: bad argument");
+    WN_CHECK_SHAPE(n_handles <= kDecMaxBatch, "wn_decoder_run_batch: at most %d utterances per launch", kDecMaxBatch);
+    const float* P[kDecMaxBatch]; const float* hb[kDecMaxBatch]; const float* E[kDecMaxBatch]; const DecLayer* ly[kDecMaxBatch];
+    float* ar[kDecMaxBatch]; int* tr[kDecMaxBatch]; long long n0[kDecMaxBatch]; int ft[kDecMaxBatch];
+    Decoder* D0 = (Decoder*)handles[0];
+    for (int u = 0; u < n_handles; ++u) {
+        Decoder* D = (Decoder*)handles[u];
+        WN_CHECK_ARG(D && uniforms[u] && out_tokens[u], "wn_decoder_run_batch: NULL handle / uniforms / out_tokens of utterance %d", u);
+        for (int v = 0; v < u; ++v) WN_CHECK_ARG(handles[v] != handles[u], "wn_decoder_run_batch: handle %d given twice", u);
+        WN_CHECK_SHAPE(D->fastP && D->three_wgs, "wn_decoder_run_batch: needs the specialised decoder (config 4's shape) "
+                                                 "without WN_DECODER_ONE_WORKGROUP");
+        WN_CHECK_SHAPE(D->meta.nlayers == D0->meta.nlayers && D->meta.head_act == D0->meta.head_act,
+                       "wn_decoder_run_batch: the utterances' models differ");
+        WN_CHECK_ARG(first_tokens[u] >= 0 && first_tokens[u] < D->meta.Q, "wn_decoder_run_batch: token outside [0,Q)");
+        WN_CHECK_ARG(D->step + n < (1ll << 31), "wn_decoder_run_batch: step counter overflow");
+        P[u] = D->fastP; hb[u] = D->head_bias_off >= 0 ? D->arena + D->head_bias_off : nullptr;
+        E[u] = D->arena + D->causal[0].w; ly[u] = D->d_layers; ar[u] = D->arena; tr[u] = D->tok_ring; n0[u] = D->step;
+        ft[u] = (int)first_tokens[u];
+    }
+    WN_CHECK_SHAPE(decode_fast_batch_ok(D0->meta.nlayers, n_handles, n),
+                   "wn_decoder_run_batch: %d utterances x 9 workgroups must all be resident on the device, and n >= 2", n_handles);
+    const int rc = decode_fast_launch_batch(n_handles, P, D0->meta.nlayers, hb, E, ly, ar, tr, n0, n, ft, uniforms, out_tokens,
+                                            prob_traces, D0->meta.Q, D0->meta.head_act, as_stream(stream));
+    if (rc) return rc;
+    for (int u = 0; u < n_handles; ++u) {
+        Decoder* D = (Decoder*)handles[u];
+        D->ran_multi = true;
+        D->step += n;
+    }
+    return WN_OK;
+}
+
 int wn_decoder_status(void* handle, void* stream) {
     Decoder* D = (Decoder*)handle;
     WN_CHECK_ARG(D, "wn_decoder_status: NULL handle");

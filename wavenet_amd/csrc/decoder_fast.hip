@@ -595,8 +595,10 @@ static constexpr int kD10Skip = 8;                              // skip workgrou
 __device__ __host__ __forceinline__ int x_pl(int nlayers) { return nlayers * 64; }
 __device__ __host__ __forceinline__ int x_err(int nlayers) { return nlayers * 64 + 8 * 256 + 8; }   // != 0: a wait gave up, the run is void
 
-__global__ __launch_bounds__(kFT, 1) void k_decode_fast3(
-    const float* __restrict__ P, const float* __restrict__ Ph, const float* __restrict__ hbias,
+// `wg`: this workgroup's role in its utterance's group of nine (0 = chain, 1..8 = skip rows): blockIdx.x for one utterance,
+// blockIdx.x % 9 in the batched launch (k_decode_fast3_batch)
+__device__ __forceinline__ void decode_fast3_body(
+    const int wg, const float* __restrict__ P, const float* __restrict__ Ph, const float* __restrict__ hbias,
     const float* __restrict__ E, const DecLayer* __restrict__ layers, int nlayers, float* __restrict__ arena,
     int* __restrict__ tok_ring, long long n0, int nsteps, int first_token, const double* __restrict__ uniforms,
     int32_t* __restrict__ out_tokens, float* __restrict__ prob_out, int prob_stride, int apply_softmax,
@@ -604,14 +606,14 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast3(
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    if (blockIdx.x >= 1 && blockIdx.x <= kD10Skip) {
+    if (wg >= 1 && wg <= kD10Skip) {
         // ---- 32 skip rows: thread (r = tid / 8, s = tid % 8) holds Ws_l[row][4 s .. 4 s + 3] of every layer ----
         float* zs = sm;                                               // [L][32]
         float* hs = sm + kD10MaxL * 32;                               // [32]
-        const int row = 32 * (blockIdx.x - 1) + (tid >> 3), sl = tid & 7;
+        const int row = 32 * (wg - 1) + (tid >> 3), sl = tid & 7;
         float4 wh[8];                                                 // head row `tid`, the 32 columns of this workgroup's skip rows
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) wh[jj] = *reinterpret_cast<const float4*>(Ph + (8 * (blockIdx.x - 1) + jj) * 1024 + 4 * tid);
+        for (int jj = 0; jj < 8; ++jj) wh[jj] = *reinterpret_cast<const float4*>(Ph + (8 * (wg - 1) + jj) * 1024 + 4 * tid);
         float4 w[kD10MaxL];
 #pragma unroll
         for (int l = 0; l < kD10MaxL; ++l)
@@ -646,7 +648,7 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast3(
             float pl = 0.f;
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) pl += dot4(wh[jj], *reinterpret_cast<const float4*>(hs + 4 * jj));
-            xput(X + x_pl(nlayers) + (blockIdx.x - 1) * 256 + tid, pl, seq);
+            xput(X + x_pl(nlayers) + (wg - 1) * 256 + tid, pl, seq);
             lds_barrier();                                            // zs / hs are rewritten by the next step
         }
         return;
@@ -850,6 +852,34 @@ __global__ __launch_bounds__(kFT, 1) void k_decode_fast3(
 static u64* g_dbg_decX = nullptr;        // diagnostic build only: where wn_debug_dec3_stamps finds the last launch's stamps
 static int g_dbg_decL = 0;
 #endif
+__global__ __launch_bounds__(kFT, 1) void k_decode_fast3(
+    const float* __restrict__ P, const float* __restrict__ Ph, const float* __restrict__ hbias,
+    const float* __restrict__ E, const DecLayer* __restrict__ layers, int nlayers, float* __restrict__ arena,
+    int* __restrict__ tok_ring, long long n0, int nsteps, int first_token, const double* __restrict__ uniforms,
+    int32_t* __restrict__ out_tokens, float* __restrict__ prob_out, int prob_stride, int apply_softmax,
+    int do_sample, int head_act, u64* __restrict__ X) {
+    decode_fast3_body((int)blockIdx.x, P, Ph, hbias, E, layers, nlayers, arena, tok_ring, n0, nsteps, first_token, uniforms,
+                      out_tokens, prob_out, prob_stride, apply_softmax, do_sample, head_act, X);
+}
+
+// N independent utterances in ONE launch: nine workgroups each (the single-GPU form of "replicas only", SURVEY 8(e): batch 1
+// has a strict sample-to-sample dependency, so the other 247 CUs can only run OTHER utterances).  Every utterance has its own
+// decoder state (rings, token ring, exchange entries, packed weights: a handle each), its own uniforms and outputs; the groups
+// share nothing and never wait for each other, so an utterance's tokens are those of its own wn_decoder_run, bit for bit.
+struct DecBatchItem {
+    const float* P; const float* hbias; const float* E; const DecLayer* layers; float* arena; int* tok_ring;
+    long long n0; const double* uniforms; int32_t* out_tokens; float* prob_out; u64* X; int first_token; int pad;
+};
+struct DecBatchArgs { DecBatchItem it[kDecMaxBatch]; };
+__global__ __launch_bounds__(kFT, 1) void k_decode_fast3_batch(const DecBatchArgs a, int nlayers, int nsteps, int prob_stride,
+                                                               int head_act) {
+    const int u = blockIdx.x / (kD10Skip + 1);
+    const DecBatchItem& q = a.it[u];
+    decode_fast3_body((int)blockIdx.x - u * (kD10Skip + 1), q.P, q.P + (size_t)nlayers * kLayerFloats, q.hbias, q.E, q.layers,
+                      nlayers, q.arena, q.tok_ring, q.n0, nsteps, q.first_token, q.uniforms, q.out_tokens, q.prob_out,
+                      prob_stride, 1, 1, head_act, q.X);
+}
+
 __global__ void k_decode_zero_x(u64* X, int n) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) X[i] = 0ull;
 }
@@ -910,6 +940,44 @@ int decode_fast_launch(const float* P, int nlayers, const float* hbias, const fl
     hipLaunchKernelGGL(k_decode_fast, dim3(1), dim3(kFT), decode_fast_lds_bytes(), s, P,
                        P + (size_t)nlayers * kLayerFloats, hbias, E, layers, nlayers, arena, tok_ring, n0, nsteps,
                        first_token, uniforms, out_tokens, prob_out, prob_stride, apply_softmax, do_sample, head_act);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int decode_fast_batch_ok(int nlayers, int n_utt, int nsteps) {
+    if (n_utt < 1 || n_utt > kDecMaxBatch || nsteps < 2 || nsteps >= (1 << 30) || nlayers > kD10MaxL) return 0;
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return 0;
+    return n_utt * (kD10Skip + 1) <= n_cu ? 1 : 0;             // every workgroup resident (one per CU by LDS footprint)
+}
+
+int decode_fast_launch_batch(int n_utt, const float* const* P, int nlayers, const float* const* hbias, const float* const* E,
+                             const DecLayer* const* layers, float* const* arena, int* const* tok_ring, const long long* n0,
+                             int nsteps, const int* first_token, const double* const* uniforms, int32_t* const* out_tokens,
+                             float* const* prob_out, int prob_stride, int head_act, hipStream_t s) {
+    if (!decode_fast_batch_ok(nlayers, n_utt, nsteps)) {
+        wn::set_error("decode batch: %d utterances x 9 workgroups do not fit the device (or fewer than 2 steps)", n_utt);
+        return WN_ESHAPE;
+    }
+    static bool attr = false;
+    if (!attr) {
+        WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_decode_fast3_batch),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)decode_fast_lds_bytes()));
+        attr = true;
+    }
+    DecBatchArgs a{};
+    const int nx = nlayers * 64 + 8 * 256 + 16;
+    for (int u = 0; u < n_utt; ++u) {
+        DecBatchItem& q = a.it[u];
+        q.P = P[u]; q.hbias = hbias[u]; q.E = E[u]; q.layers = layers[u]; q.arena = arena[u]; q.tok_ring = tok_ring[u];
+        q.n0 = n0[u]; q.uniforms = uniforms[u]; q.out_tokens = out_tokens[u]; q.prob_out = prob_out ? prob_out[u] : nullptr;
+        q.first_token = first_token[u];
+        q.X = reinterpret_cast<u64*>(const_cast<float*>(P[u]) + (size_t)nlayers * kLayerFloats + 256 * 256);
+        hipLaunchKernelGGL(k_decode_zero_x, dim3(cdiv(nx, 256)), dim3(256), 0, s, q.X, nx);
+    }
+    hipLaunchKernelGGL(k_decode_fast3_batch, dim3(n_utt * (kD10Skip + 1)), dim3(kFT), decode_fast_lds_bytes(), s, a, nlayers,
+                       nsteps, prob_stride, head_act);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

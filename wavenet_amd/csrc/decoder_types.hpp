@@ -14,5 +14,11 @@ int decode_fast_launch(const float* P, int nlayers, const float* hbias, const fl
                        float* arena, int* tok_ring, long long n0, int nsteps, int first_token,
                        const double* uniforms, int32_t* out_tokens, float* prob_out, int prob_stride,
                        int apply_softmax, int do_sample, int head_act, bool three_wgs, hipStream_t s);
+static constexpr int kDecMaxBatch = 28;                    // utterances per batched launch: 28 x 9 workgroups on 256 CUs
+int decode_fast_batch_ok(int nlayers, int n_utt, int nsteps);
+int decode_fast_launch_batch(int n_utt, const float* const* P, int nlayers, const float* const* hbias, const float* const* E,
+                             const DecLayer* const* layers, float* const* arena, int* const* tok_ring, const long long* n0,
+                             int nsteps, const int* first_token, const double* const* uniforms, int32_t* const* out_tokens,
+                             float* const* prob_out, int prob_stride, int head_act, hipStream_t s);
 int decode_fast_status(const float* P, int nlayers, hipStream_t s, int* gave_up);
 }  // namespace wn

@@ -42,6 +42,8 @@ class FasterWaveNet(WaveNet):
         self._dec = None
         self._dec_keep = None
         self._dec_stale = True
+        self._batch_decs = []              # decoder handles of generate_batch (one per utterance), created on demand
+        self._batch_stale = []
         self.prev_causal_outputs = None
         self.prev_residual_outputs = None
         self.keep_window = False           # keep the logits of the whole window on the device (full_window=True needs it)
@@ -53,12 +55,15 @@ class FasterWaveNet(WaveNet):
         try:
             if self._dec is not None:
                 _lib.lib().wn_decoder_destroy(self._dec)
+            for h in getattr(self, "_batch_decs", []):
+                _lib.lib().wn_decoder_destroy(h)
         except Exception:
             pass
 
     def _weights_changed(self):
         super()._weights_changed()
         self._dec_stale = True
+        self._batch_stale = [True] * len(getattr(self, "_batch_decs", []))
 
     # -- decoder handle -------------------------------------------------------------------------
     def _desc(self):
@@ -219,3 +224,70 @@ class FasterWaveNet(WaveNet):
             # the older columns from -- still holds the prefill state: drop it rather than answer with a stale window
             self._hist = None
         return (out, probs) if return_probs else out
+
+    # -- N utterances at once (new capability: the reference generates one utterance per process) ------------------------
+    def generate_batch(self, n_samples: int, uniforms, initial_tokens=None):
+        """``uniforms``: (N, n_samples) float64 -- N independent utterances from the same initial window, utterance u drawing
+        with ``uniforms[u]``; returns (N, n_samples) int32 tokens on the device.  A single utterance is a strict
+        sample-to-sample chain (generate.py:9-60, batch 1: wavenet.py:286,290,354) and occupies nine of the GPU's CUs; the
+        batched launch (``wn_decoder_run_batch``) runs up to ``wn_decoder_batch_max()`` = 28 such chains side by side, each with
+        a decoder state of its own.  Row u equals ``generate(n_samples, uniforms[u])`` bit for bit.  Step 1 -- the full forward
+        over the initial window -- is the same for every utterance and runs once."""
+        p = self.params
+        Q = p.quantization_steps
+        iw = self.input_width
+        u_np = np.ascontiguousarray(np.asarray(uniforms, dtype=np.float64))
+        if u_np.ndim != 2 or u_np.shape[1] < n_samples:
+            raise Exception("uniforms must be (N, >= n_samples)")
+        N = u_np.shape[0]
+        lib = _lib.lib()
+        if N < 1 or N > lib.wn_decoder_batch_max():
+            raise Exception("1 .. %d utterances per batch" % lib.wn_decoder_batch_max())
+        if initial_tokens is None:
+            initial_tokens = np.full((iw,), 127 if Q > 127 else Q // 2, dtype=np.int32)   # generate.py:21
+        tok = torch.as_tensor(np.asarray(initial_tokens, dtype=np.int32).reshape(1, -1)).to(self.device)
+        u = torch.as_tensor(u_np).to(self.device)
+        # one prefill, N decoder states seeded from it
+        self.prev_causal_outputs = None
+        storage, self.storage = self.storage, "fp32"
+        try:
+            with torch.no_grad():
+                causal_output = self.forward_causal_block(tok)
+                _, sum_skip = self.forward_residual_block(causal_output)
+                p0 = self.forward_softmax_block(sum_skip, apply_softmax=True)
+        finally:
+            self.storage = storage
+        tokens = tok.to(torch.int32).contiguous()
+        while len(self._batch_decs) < N:
+            d, keep = self._desc()
+            h = C.c_void_p()
+            check(lib.wn_decoder_create(C.byref(h), C.byref(d), stream_ptr()), "wn_decoder_create")
+            self._batch_decs.append(h)
+            self._batch_stale.append(False)
+        for i in range(N):
+            if self._batch_stale[i]:
+                d, keep = self._desc()
+                check(lib.wn_decoder_update_weights(self._batch_decs[i], C.byref(d), stream_ptr()), "wn_decoder_update_weights")
+                self._batch_stale[i] = False
+            check(lib.wn_decoder_load_state(
+                self._batch_decs[i], ptr(tokens), tokens.shape[1], ptr_array([t.contiguous() for t in self._last_causal_outputs]),
+                ptr_array(self._last_layer_inputs), stream_ptr()), "wn_decoder_load_state")
+        first_prob = p0[0, :, 0, -1].contiguous().view(1, Q).expand(N, Q).contiguous()
+        out = torch.empty((N, n_samples), device=self.device, dtype=torch.int32)
+        first = torch.empty((N,), device=self.device, dtype=torch.int32)
+        check(lib.wn_sample_categorical(ptr(first_prob), ptr(u[:, 0].contiguous()), ptr(first), N, Q, stream_ptr()),
+              "wn_sample_categorical")
+        out[:, 0] = first
+        if n_samples > 1:
+            if n_samples < 3:
+                raise Exception("generate_batch: at least 3 samples (the batched launch runs two steps or more)")
+            firsts = (C.c_int32 * N)(*[int(v) for v in first.cpu().tolist()])
+            handles = (C.c_void_p * N)(*[h.value for h in self._batch_decs[:N]])
+            rest = [u[i, 1:].contiguous() for i in range(N)]
+            outs = [torch.empty((n_samples - 1,), device=self.device, dtype=torch.int32) for _ in range(N)]
+            check(lib.wn_decoder_run_batch(handles, N, firsts, ptr_array(rest), n_samples - 1, ptr_array(outs), None,
+                                           stream_ptr()), "wn_decoder_run_batch")
+            for i in range(N):
+                check(lib.wn_decoder_status(self._batch_decs[i], stream_ptr()), "wn_decoder_status")
+                out[i, 1:] = outs[i]
+        return out
