@@ -197,6 +197,7 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
     }
     const int nwg = dx_grid(B, T);
     const long long part_stride = (long long)nwg * 128 * 128;
+    std::vector<int> Zl(L), live_g(L), live_x(L), zero_g(L);    // per layer: zero prefix, live ranges (GateP / DxP in w16_layer.hip)
     const bf16* gout = reinterpret_cast<const bf16*>(dout);
     std::vector<float*> dWp_eff(L, nullptr);
     if (gout) {
@@ -211,12 +212,12 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
         // receives gradient at columns t >= t_off - (reach of the layers above it) and nowhere else.  Tiles wholly below that
         // load and compute nothing; they store the zeros their readers (the dx kernel, the deferred weight-gradient launch,
         // the layer below) expect.  12.5 % of the sample-layers at config 5's window.
-        std::vector<int> Zl(L), live_g(L), live_x(L);
         int t_live = t_off;
         for (int l = L - 1; l >= 0; --l) {
             const int dl = d->dilation[l];
             Zl[l] = compat_zero_prefix ? zero_prefix(T, dl, 2) : 0;
             live_g[l] = (t_live / 32) * 32;
+            zero_g[l] = (t_live / 64) * 64;                   // the deferred weight-gradient launch reads [da | dg] from here on (64-row chunks)
             t_live = t_live - dl > 0 ? t_live - dl : 0;       // the layer below (and this layer's dx): one more dilation of reach
             live_x[l] = (t_live / 32) * 32;
         }
@@ -227,7 +228,8 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
         for (int l = L - 1; l >= 0; --l) {
             if (multi && l == L - 2) {
                 if ((rc = bwd_multi(xb, xsb, zb, img, w.dzs, w.dadg, w.dxb[0], w.dxb[1], w.parts, part_stride, w.sync,
-                                    d->dilation, Zl.data(), live_g.data(), live_x.data(), L - 2, 1, B, T, t_off, s)))
+                                    d->dilation, Zl.data(), live_g.data(), live_x.data(), zero_g.data(), L - 2, 1, B, T, t_off,
+                                    s)))
                     return rc;
                 for (int k = L - 3; k >= 0; --k) dWp_eff[k] = dWp[k];
                 gout = w.dxb[1];                            // dx of layer 1
@@ -238,7 +240,7 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
             const int dl = d->dilation[l];
             bf16* dadg = w.dadg + (size_t)l * n * 256;
             if ((rc = gate_bwd_layer(in, img + (size_t)l * kLayerImg, gout, dsk ? w.dzs + (size_t)l * nw * 128 : nullptr,
-                                     t_off, dadg, B, T, dl, Zl[l], live_g[l], s)))
+                                     t_off, dadg, B, T, dl, Zl[l], live_g[l], zero_g[l], s)))
                 return rc;
             bf16* gin = l == 0 ? reinterpret_cast<bf16*>(dx) : w.dxb[l & 1];
             if (!gin) break;                               // l == 0 and the caller does not want dx
@@ -246,7 +248,8 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
             // projection gradient dWp_{l-1} += dx_l z_{l-1}^T is taken in the same pass
             const bf16* zprev = l > 0 ? zb + (size_t)(l - 1) * n * 128 : nullptr;
             if ((rc = dx_layer(dadg, img + (size_t)l * kLayerImg, gout, zprev, gin,
-                               l > 0 ? w.parts + (size_t)(l - 1) * part_stride : nullptr, B, T, dl, live_x[l], s)))
+                               l > 0 ? w.parts + (size_t)(l - 1) * part_stride : nullptr, B, T, dl, live_x[l], live_g[l],
+                               l == 0 ? 1 : 0 /* the embedding backward reads every row of layer 0's dx */, s)))
                 return rc;
             if (l > 0) dWp_eff[l - 1] = dWp[l - 1];
             gout = gin;
@@ -261,6 +264,7 @@ int wn16_stack_bwd(const WnStackDesc* d, const uint16_t* pack, const uint16_t* x
             WG16Prob& p = a.prob[l];
             const bf16* in = l == 0 ? xb : xsb + (size_t)(l - 1) * n * 128;
             p.A = w.dadg + (size_t)l * n * 256;
+            p.r_lo = zero_g[l];                               // [da | dg] is zero (and unwritten) below: not read
             for (int nh = 0; nh < 2; ++nh) {
                 p.Bh[nh] = in; p.shift[nh] = nh == 0 ? -d->dilation[l] : 0;
                 p.out[0][nh] = dWf[l] + nh;               // W[o][c][k]: (o * 128 + c) * 2 + k

@@ -425,27 +425,35 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // neighbouring problems share (dWs: the two dskip halves of a layer pair, one dskip half for all layer pairs) come from
     // HBM once per XCD and from its L2 for the rest.  (In grid order an XCD held every slab of every fifth problem or so:
     // 42 distinct operand slabs per XCD for 30 workgroups, 2.86 GB fetched for 1.1 GB of operands.)
-    int slab = blockIdx.x, p = blockIdx.y;
+    // The launch is a LIST of (slab, problem) pairs, slab-major -- level s holds the problems that have more than s slabs -- and
+    // only as long as the pairs that exist (a.n_items <= 256: every workgroup resident, at most 32 per XCD).
+    int slab = 0, p = 0;
     {
-        const int total = gridDim.x * gridDim.y;
-        if ((total & 7) == 0) {
-            const int id = blockIdx.x + gridDim.x * blockIdx.y;
-            const int item = (id & 7) * (total >> 3) + (id >> 3);
-            slab = item / (int)gridDim.y;
-            p = item - slab * (int)gridDim.y;
-        }
+        const int total = gridDim.x;
+        int item = blockIdx.x;
+        if ((total & 7) == 0) item = (item & 7) * (total >> 3) + (item >> 3);
+        if (item >= a.n_items) return;                       // (the list is padded to a multiple of 8)
+        while (item >= (int)a.level_cnt[slab]) { item -= (int)a.level_cnt[slab]; ++slab; }
+        for (int q = 0; q < a.n_prob; ++q)
+            if ((int)a.prob[q].nslab > slab) {
+                if (item == 0) { p = q; break; }
+                --item;
+            }
     }
     const WG16Prob& pr = a.prob[p];
-    // this workgroup's slab of 64-row chunks
-    const int cpb = (a.R + kWT - 1) / kWT;
+    // this workgroup's slab of 64-row chunks.  A problem's rows start at r_lo (a multiple of 64): below it A is zero -- the
+    // columns of a layer no gradient reaches -- and nothing is read; problems get slabs in proportion to their rows
+    // (launch_wgrad16), so the workgroups of a launch stream about the same number of chunks.
+    const int rlo = pr.r_lo;
+    const int cpb = (a.R - rlo + kWT - 1) / kWT;
     const int nch = a.nB * cpb;
-    const int c_begin = (int)((long long)nch * slab / gridDim.x);
-    const int c_end = (int)((long long)nch * (slab + 1) / gridDim.x);
+    const int c_begin = (int)((long long)nch * slab / pr.nslab);
+    const int c_end = (int)((long long)nch * (slab + 1) / pr.nslab);
     auto tile = [&](int buf, int which) { return lds + (buf * 4 + which) * kWTileB; };   // which: A0 A1 B0 B1
 
     auto issue = [&](int c, int buf) {
         const int b = c / cpb;
-        const int r0 = (c - b * cpb) * kWT;
+        const int r0 = rlo + (c - b * cpb) * kWT;
         const bf16* ab = pr.A + ((long long)b * a.a_rpb + a.a_r0) * a.lda;
         const int ahi = a.R - 1;
 #pragma unroll
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     // rows that do not exist (the ragged end of a clip, a dilated tap reaching before its start) contribute nothing
     auto fixup = [&](int c, int buf) {
         const int b = c / cpb;
-        const int r0 = (c - b * cpb) * kWT;
+        const int r0 = rlo + (c - b * cpb) * kWT;
         bool fix = r0 + kWT > a.R;
         int sh[2];
 #pragma unroll
@@ -546,7 +554,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
     if (a.part) {
         // this workgroup's block as it sits in the accumulators: [wave][mi][ni][r][lane], 256-byte rows, coalesced
-        float* pp = a.part + ((size_t)slab * gridDim.y + p) * 65536 + (size_t)w * 8192 + lane;
+        float* pp = a.part + (size_t)(pr.slab0 + slab) * 65536 + (size_t)w * 8192 + lane;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -571,22 +579,24 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
 // dW += the slabs' blocks of a problem, slab 0 first: one thread per element of the 256 x 256 block, no atomics.  A slab
 // whose chunk range is empty has left its block unwritten: the ranges are recomputed here.
-__global__ void k16_wgrad_reduce(WG16 a, int slabs) {
+__global__ void k16_wgrad_reduce(WG16 a) {
     const int p = blockIdx.y;
     const int e = blockIdx.x * 256 + threadIdx.x;            // [wave][mi][ni][r][lane]
     const int lane = e & 63, r = (e >> 6) & 15, ni = (e >> 10) & 3, mi = (e >> 12) & 1, w = e >> 13;
     const int wm = w & 3, wn = w >> 2, j = lane & 31, h = lane >> 5;
-    float* ob = a.prob[p].out[wm >> 1][wn];
+    const WG16Prob& pr = a.prob[p];
+    float* ob = pr.out[wm >> 1][wn];
     if (!ob) return;
-    const int cpb = (a.R + kWT - 1) / kWT;
+    const int cpb = (a.R - pr.r_lo + kWT - 1) / kWT;
     const int nch = a.nB * cpb;
     // (the slab ranges in 32-bit arithmetic: launch_wgrad16 guarantees nch * (slabs + 1) < 2^31 -- the 64-bit divisions this
     // loop used to do per thread and slab were most of its 41 us)
     float sum = 0.f;
     unsigned cb = 0;
+    const int slabs = pr.nslab;
     for (int sl = 0; sl < slabs; ++sl) {
         const unsigned ce = (unsigned)nch * (unsigned)(sl + 1) / (unsigned)slabs;
-        if (cb < ce) sum += a.part[((size_t)sl * gridDim.y + p) * 65536 + e];
+        if (cb < ce) sum += a.part[(size_t)(pr.slab0 + sl) * 65536 + e];
         cb = ce;
     }
     const int m = 64 * (wm & 1) + 32 * mi + acc_row(r, h);
@@ -594,14 +604,42 @@ __global__ void k16_wgrad_reduce(WG16 a, int slabs) {
     ob[(long long)m * a.os_m + (long long)n * a.os_n] += sum;
 }
 
-int launch_wgrad16(const WG16& a, int nprob, hipStream_t s) {
+int launch_wgrad16(const WG16& a_in, int nprob, hipStream_t s) {
     if (nprob < 1 || nprob > kMaxProb16) { wn::set_error("w16 wgrad: %d problems", nprob); return WN_EARG; }
-    const int cpb = (a.R + kWT - 1) / kWT;
-    const int nch = a.nB * cpb;
-    int slabs = 256 / nprob;                             // every workgroup resident at once: slabs stream in step
-    if (slabs < 1) slabs = 1;
-    if (slabs > nch) slabs = nch;
-    if ((long long)nch * (slabs + 1) >= (1ll << 31)) { wn::set_error("w16 wgrad: %d chunks x %d slabs overflows", nch, slabs); return WN_ESHAPE; }
+    WG16 a = a_in;
+    // every workgroup resident at once (256 in all: slabs stream in step), dealt to the problems in proportion to their rows
+    long long tot = 0;
+    int nchp[kMaxProb16];
+    for (int p = 0; p < nprob; ++p) {
+        int rlo = a.prob[p].r_lo;
+        rlo = rlo < 0 ? 0 : (rlo / kWT) * kWT;
+        if (rlo >= a.R) rlo = ((a.R - 1) / kWT) * kWT;
+        a.prob[p].r_lo = rlo;
+        nchp[p] = a.nB * ((a.R - rlo + kWT - 1) / kWT);
+        tot += nchp[p];
+    }
+    int slabs = 0, used = 0;
+    for (int p = 0; p < nprob; ++p) {
+        int ns = (int)((256ll * nchp[p]) / (tot > 0 ? tot : 1));
+        if (ns < 1) ns = 1;
+        if (ns > nchp[p]) ns = nchp[p];
+        if (ns > 64) ns = 64;
+        if ((long long)nchp[p] * (ns + 1) >= (1ll << 31)) { wn::set_error("w16 wgrad: %d chunks x %d slabs overflows", nchp[p], ns); return WN_ESHAPE; }
+        a.prob[p].nslab = (unsigned short)ns;
+        a.prob[p].slab0 = (unsigned short)used;
+        used += ns;
+        if (ns > slabs) slabs = ns;
+    }
+    if (used > 256) { wn::set_error("w16 wgrad: %d workgroups", used); return WN_ESHAPE; }
+    static_assert(sizeof(WG16) <= 4096, "WG16 travels as a kernel argument");
+    a.n_items = used;
+    a.n_prob = nprob;
+    for (int sl = 0; sl < 64; ++sl) {
+        int cnt = 0;
+        for (int p = 0; p < nprob; ++p) cnt += a.prob[p].nslab > sl ? 1 : 0;
+        a.level_cnt[sl] = (unsigned short)cnt;
+    }
+    const int grid = (used + 7) & ~7;
 #define WGL(RB)                                                                                                   \
     do {                                                                                                          \
         static bool attr = false;                                                                                 \
@@ -610,13 +648,13 @@ int launch_wgrad16(const WG16& a, int nprob, hipStream_t s) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, kWgLds));                      \
             attr = true;                                                                                          \
         }                                                                                                         \
-        hipLaunchKernelGGL((k16_wgrad<RB>), dim3(slabs, nprob), dim3(512), kWgLds, s, a);                         \
+        hipLaunchKernelGGL((k16_wgrad<RB>), dim3(grid), dim3(512), kWgLds, s, a);                                 \
     } while (0)
     if (a.relu_b) WGL(true); else WGL(false);
 #undef WGL
     WN_LAUNCH_CHECK();
     if (a.part) {
-        hipLaunchKernelGGL(k16_wgrad_reduce, dim3(256, nprob), dim3(256), 0, s, a, slabs);
+        hipLaunchKernelGGL(k16_wgrad_reduce, dim3(256, nprob), dim3(256), 0, s, a);
         WN_LAUNCH_CHECK();
     }
     return WN_OK;

@@ -34,6 +34,9 @@ struct WG16Prob {
     const bf16* Bh[2];               // two 128-channel operands [rows][ldb]
     int shift[2];                    // row shift of each B half (dilated taps); rows outside the clip read as 0
     float* out[2][2];                // [m half][n half]: element (m, n) at out + m * os_m + n * os_n; NULL = skip
+    int r_lo;                        // rows below r_lo (a multiple of 64) are not read: A is zero there (dead columns of a layer)
+    unsigned short nslab;            // filled by launch_wgrad16: workgroups (time slabs) of this problem, ~ its share of the rows
+    unsigned short slab0;            // filled by launch_wgrad16: index of its first partial block
 };
 // dW[m][n] += sum over clips b and rows r < R of A[b * a_rpb + a_r0 + r][m] * B[b * b_rpb + b_r0 + r + shift][n]
 struct WG16 {
@@ -42,6 +45,8 @@ struct WG16 {
     int nB, R, a_rpb, a_r0, b_rpb, b_r0;
     int os_m, os_n;
     int relu_b;
+    int n_items, n_prob;             // filled by launch_wgrad16: (slab, problem) pairs of the launch, problems
+    unsigned short level_cnt[64];    // filled by launch_wgrad16: problems that have more than s slabs (at most 64 slabs per problem)
     float* part;                     // kWgPartBytes of scratch: every workgroup leaves its 256 x 256 block there and a second
                                      // kernel adds the slabs of a problem in a fixed order (bit-reproducible); NULL: each
                                      // workgroup adds its block to dW with float atomics (order of the slabs not defined)
@@ -62,19 +67,21 @@ int embed_fwd16(const int32_t* idx, const float* W, const float* bias, bf16* out
 
 // w16_layer.hip
 int fwd_layer(const bf16* x, const bf16* img, bf16* out, bf16* z, int B, int T, int d, int Z, hipStream_t s);
-// t_live (multiple of 32): columns below it receive no gradient -- their tiles store zeros and do nothing else
+// live ranges (multiples of 32; GateP / DxP in w16_layer.hip): columns below t_live receive no gradient; gate tiles below t_zero
+// and (unless zero_dead) dx tiles below t_live are not touched at all; [da | dg](t) and dout(t) read as zero below t_gate
 int gate_bwd_layer(const bf16* x, const bf16* img, const bf16* dout, const bf16* dzs, int dz_t0, bf16* dadg, int B, int T,
-                   int d, int Z, int t_live, hipStream_t s);
+                   int d, int Z, int t_live, int t_zero, hipStream_t s);
 int dx_grid(int B, int T);
 int dx_layer(const bf16* dadg, const bf16* img, const bf16* dout, const bf16* zprev, bf16* dx, float* dwp_part, int B,
-             int T, int d, int t_live, hipStream_t s);
+             int T, int d, int t_live, int t_gate, int zero_dead, hipStream_t s);
 // stack layers l_hi .. l_lo (>= 1) of the layer backward in ONE launch (k16_bwd_multi): same results as gate_bwd_layer +
 // dx_layer per layer, bit for bit; sync: bwd_multi_sync_words(B, T) words of device memory
 size_t bwd_multi_sync_words(int B, int T);
 int bwd_multi_ok(int B, int T);
 int bwd_multi(const bf16* x0, const bf16* xs, const bf16* z, const bf16* img, const bf16* dzs, bf16* dadg, bf16* dxb0,
               bf16* dxb1, float* parts, long long part_stride, unsigned* sync, const int* d, const int* Z,
-              const int* live_gate, const int* live_dx, int l_hi, int l_lo, int B, int T, int dz_t0, hipStream_t s);
+              const int* live_gate, const int* live_dx, const int* zero_gate, int l_hi, int l_lo, int B, int T, int dz_t0,
+              hipStream_t s);
 int reduce_parts(const float* part, long long layer_stride, int nwg, int n, float* const* dW_dev, int L, hipStream_t s);
 
 }  // namespace w16

@@ -288,13 +288,21 @@ __device__ __forceinline__ unsigned dep_word(const MSync& ms, int lane) {
     return v;
 }
 
+// Live ranges (all multiples of 32; the host computes them, w16_api.hip).  The loss reaches the stack through skip[t_off:]
+// only, so layer l receives gradient at columns t >= t_off - (reach of the layers above) and nowhere else:
+//   gate phase: columns below t_live carry no gradient.  Tiles wholly below t_zero (<= t_live, a multiple of 64: the deferred
+//               weight-gradient launch reads [da | dg] in 64-row chunks starting there) are NOT TOUCHED -- nothing loaded,
+//               nothing stored; the dead tile between t_zero and t_live, if any, stores zeros.
+//   dx phase:   dx is exactly zero below t_live (= the gate bound of the layer below); such tiles are not touched unless
+//               zero_dead (layer 0: the embedding backward reads every row).  [da | dg](t) and dout(t) are zero below t_gate
+//               (this layer's gate bound: rows nobody wrote) -- they are not read there, their LDS tiles are zero-filled.
 struct GateP {
     const bf16* x; const bf16* convA; const bf16* dzA; const bf16* dout; const bf16* dzs; int dz_t0; bf16* dadg;
-    int B, T, d, Z, tiles_per_b, ntiles, t_live;
+    int B, T, d, Z, tiles_per_b, ntiles, t_live, t_zero;
 };
 struct DxP {
     const bf16* dadg; const bf16* dxA; const bf16* dout; const bf16* zprev; bf16* dx; float* dwp_part;
-    int B, T, d, tiles_per_b, ntiles, t_live;
+    int B, T, d, tiles_per_b, ntiles, t_live, t_gate, zero_dead;
 };
 
 // what every request of a wave needs: its piece of a 32-row tile is rows 4 w .. 4 w + 3, the lane's 16 bytes at a fixed offset
@@ -384,22 +392,23 @@ __device__ __forceinline__ void dx_issue(char* lds, const DxP& P, const WaveC& c
     const int b = tile / P.tiles_per_b;
     const int t0 = (tile - b * P.tiles_per_b) * kLT;
     if (t0 + kLT <= P.t_live) return;                    // a dead tile
+    const bool tlive = t0 + kLT > P.t_gate;            // the tile's own rows of [da | dg] and dout exist (else: zeros, dx_phase fills them in)
     if (t0 + kLT + d <= T) {                           // interior tile: uniform bases + fixed lane offsets (as in gate_issue)
         const bf16* a0 = P.dadg + ((long long)b * T + t0) * 256;
         const bf16* a1 = a0 + (long long)d * 256;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            dma16_sx<MULTI>(a0 + 128 * half, c.off256, c.lds0 + M::at(buf, half) * kLTileB + w * 1024);
+            if (tlive) dma16_sx<MULTI>(a0 + 128 * half, c.off256, c.lds0 + M::at(buf, half) * kLTileB + w * 1024);
             dma16_sx<MULTI>(a1 + 128 * half, c.off256, c.lds0 + M::at(buf, 2 + half) * kLTileB + w * 1024);
         }
-        if (HAS_DO) dma16_sx<MULTI>(P.dout + ((long long)b * T + t0) * 128, c.off128, c.lds0 + M::at(buf, 4) * kLTileB + w * 1024);
+        if (HAS_DO && tlive) dma16_sx<MULTI>(P.dout + ((long long)b * T + t0) * 128, c.off128, c.lds0 + M::at(buf, 4) * kLTileB + w * 1024);
         if (HAS_Z) dma16_s(P.zprev + ((long long)b * T + t0) * 128, c.off128, c.lds0 + M::at(buf, 5) * kLTileB + w * 1024);
         return;
     }
     const bf16* ab = P.dadg + (long long)b * T * 256;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        dma_pieces<MULTI, MULTI>(lds + M::at(buf, half) * kLTileB, lane, w, 1, 1, [&](int r) {
+        if (tlive) dma_pieces<MULTI, MULTI>(lds + M::at(buf, half) * kLTileB, lane, w, 1, 1, [&](int r) {
             const int t = t0 + r < T ? t0 + r : T - 1;
             return ab + (long long)t * 256 + 128 * half;
         });
@@ -409,7 +418,7 @@ __device__ __forceinline__ void dx_issue(char* lds, const DxP& P, const WaveC& c
             return ab + (long long)t * 256 + 128 * half;
         });
     }
-    if (HAS_DO) {
+    if (HAS_DO && tlive) {
         const bf16* db = P.dout + (long long)b * T * 128;
         dma_pieces<MULTI, MULTI>(lds + M::at(buf, 4) * kLTileB, lane, w, 1, 1, [&](int r) {
             const int t = t0 + r < T ? t0 + r : T - 1;
@@ -528,8 +537,12 @@ __device__ __forceinline__ bool gate_phase(char* lds, const GateP& P, MSync& ms,
             if (n >= 3 && it == n - 1) tail_issued = tail.issue();
         }
         STAMP_K(1, 3);
-        if (t0 + kLT <= t_live) {                          // dead tile (workgroup-uniform): [da | dg] = 0, two stores per wave as below
-            const int r = 4 * w + (lane >> 4);
+        if (t0 + kLT <= t_live) {                          // dead tile (workgroup-uniform)
+            if (t0 + kLT <= P.t_zero) {                    // ... that nobody reads: not touched
+                full_prev = false;                         // (no stores: the next body's wait covers its requests in full)
+                continue;
+            }
+            const int r = 4 * w + (lane >> 4);             // [da | dg] = 0, two stores per wave as below
             const int cc = (lane & 15) ^ key(r);
             bf16* o = dadg + ((long long)b * T + t0 + r) * 256 + cc * 8;
             const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -637,9 +650,9 @@ template <bool HAS_DO, bool HAS_DZ>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k16_gate_bwd(
     const bf16* __restrict__ x, const bf16* __restrict__ convA, const bf16* __restrict__ dzA,
     const bf16* __restrict__ dout, const bf16* __restrict__ dzs, int dz_t0, bf16* __restrict__ dadg, int B, int T, int d,
-    int Z, int tiles_per_b, int ntiles, int t_live) {
+    int Z, int tiles_per_b, int ntiles, int t_live, int t_zero) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-    const GateP P{x, convA, dzA, dout, dzs, dz_t0, dadg, B, T, d, Z, tiles_per_b, ntiles, t_live};
+    const GateP P{x, convA, dzA, dout, dzs, dz_t0, dadg, B, T, d, Z, tiles_per_b, ntiles, t_live, t_zero};
     MSync ms{};
     NoTail nt;
     gate_phase<HAS_DO, HAS_DZ, false>(lds, P, ms, false, nt);
@@ -756,21 +769,36 @@ __device__ __forceinline__ bool dx_phase(char* lds, const DxP& P, MSync& ms, boo
             if (n >= 3 && it == n - 1) tail_issued = tail.issue();
         }
         STAMP_K(2, 3);
-        if (t0 + kLT <= t_live) {                          // dead tile (workgroup-uniform): dx = 0, one store per wave as below
-            const int r = 4 * w + (lane >> 4);
+        if (t0 + kLT <= t_live) {                          // dead tile (workgroup-uniform)
+            if (!P.zero_dead) {                            // ... that nobody reads: not touched
+                full_prev = false;
+                continue;
+            }
+            const int r = 4 * w + (lane >> 4);             // dx = 0, one store per wave as below
             const int cc = (lane & 15) ^ key(r);
             const u32x4 zero4 = {0u, 0u, 0u, 0u};
             st16_wt(dx + ((long long)b * T + t0 + r) * 128 + cc * 8, zero4);
             full_prev = true;
             continue;
         }
-        if (t0 + kLT + d > T) {                          // dab[t + d] beyond the clip end contributes nothing
-            for (int r = w; r < kLT; r += 8)
-                if (t0 + r + d >= T) {
-                    *reinterpret_cast<unsigned*>(tile_at(buf, 2) + r * 256 + lane * 4) = 0u;
-                    *reinterpret_cast<unsigned*>(tile_at(buf, 3) + r * 256 + lane * 4) = 0u;
+        {
+            // rows that are zero by construction and were never written (or never requested): dab[t + d] beyond the clip end
+            // and below this layer's gate bound; the tile's own [da | dg] and dout when it lies below the gate bound
+            const bool hi_fix = t0 + kLT + d > T, lo_fix = t0 + d < P.t_gate, own_dead = t0 + kLT <= P.t_gate;
+            if (hi_fix || lo_fix || own_dead) {
+                for (int r = w; r < kLT; r += 8) {
+                    if (t0 + r + d >= T || t0 + r + d < P.t_gate) {
+                        *reinterpret_cast<unsigned*>(tile_at(buf, 2) + r * 256 + lane * 4) = 0u;
+                        *reinterpret_cast<unsigned*>(tile_at(buf, 3) + r * 256 + lane * 4) = 0u;
+                    }
+                    if (own_dead) {
+                        *reinterpret_cast<unsigned*>(tile_at(buf, 0) + r * 256 + lane * 4) = 0u;
+                        *reinterpret_cast<unsigned*>(tile_at(buf, 1) + r * 256 + lane * 4) = 0u;
+                        if (HAS_DO) *reinterpret_cast<unsigned*>(tile_at(buf, 4) + r * 256 + lane * 4) = 0u;
+                    }
                 }
-            barrier();
+                barrier();
+            }
         }
         f32x16 acc;
 #pragma unroll
@@ -864,9 +892,9 @@ template <bool HAS_DO, bool HAS_Z>
 __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void k16_dx(const bf16* __restrict__ dadg, const bf16* __restrict__ dxA,
                                                   const bf16* __restrict__ dout, const bf16* __restrict__ zprev,
                                                   bf16* __restrict__ dx, float* __restrict__ dwp_part, int B, int T, int d,
-                                                  int tiles_per_b, int ntiles, int t_live) {
+                                                  int tiles_per_b, int ntiles, int t_live, int t_gate, int zero_dead) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
-    const DxP P{dadg, dxA, dout, zprev, dx, dwp_part, B, T, d, tiles_per_b, ntiles, t_live};
+    const DxP P{dadg, dxA, dout, zprev, dx, dwp_part, B, T, d, tiles_per_b, ntiles, t_live, t_gate, zero_dead};
     MSync ms{};
     NoTail nt;
     dx_phase<HAS_DO, HAS_Z, false>(lds, P, ms, false, nt);
@@ -894,7 +922,7 @@ struct BwdMultiArgs {
     const bf16* x0; const bf16* xs; const bf16* z; const bf16* img; const bf16* dzs;
     bf16* dadg; bf16* dxb[2]; float* parts; long long part_stride; unsigned* sync;
     long long n, nw;                                     // B T, B (T - dz_t0)
-    int d[kMaxProb16], Z[kMaxProb16], live_gate[kMaxProb16], live_dx[kMaxProb16];   // by stack layer
+    int d[kMaxProb16], Z[kMaxProb16], live_gate[kMaxProb16], live_dx[kMaxProb16], zero_gate[kMaxProb16];   // by stack layer
     int l_hi, l_lo, B, T, dz_t0, tiles_per_b, ntiles;
 };
 
@@ -939,7 +967,7 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const bf16* img = uniform_ptr(a.img + (long long)l * kLayerImg);
         return GateP{in, img + kOffConvA8, img + kOffDzA8, uniform_ptr(a.dxb[(l + 1) & 1]),
                      uniform_ptr(a.dzs + (long long)l * a.nw * 128), a.dz_t0, uniform_ptr(a.dadg + (long long)l * a.n * 256),
-                     a.B, a.T, a.d[l], a.Z[l], a.tiles_per_b, a.ntiles, a.live_gate[l]};
+                     a.B, a.T, a.d[l], a.Z[l], a.tiles_per_b, a.ntiles, a.live_gate[l], a.zero_gate[l]};
     };
     bool pre = false;
     for (int l = a.l_hi; l >= a.l_lo; --l) {
@@ -947,7 +975,8 @@ __global__ __launch_bounds__(512, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         const GateP g = gate_args(l);
         const DxP x{g.dadg, uniform_ptr(a.img + (long long)l * kLayerImg) + kOffDxA, g.dout,
                     uniform_ptr(a.z + (long long)(l - 1) * a.n * 128), uniform_ptr(a.dxb[l & 1]),
-                    a.parts + (long long)(l - 1) * a.part_stride, a.B, a.T, a.d[l], a.tiles_per_b, a.ntiles, a.live_dx[l]};
+                    a.parts + (long long)(l - 1) * a.part_stride, a.B, a.T, a.d[l], a.tiles_per_b, a.ntiles, a.live_dx[l],
+                    a.live_gate[l], 0};
         DxTail dt{lds, &x, &c, &ms, first};
 #ifdef WN16_MSTAMPS
         const int ph = 2 * (a.l_hi - l);
@@ -1017,7 +1046,7 @@ int fwd_layer(const bf16* x, const bf16* img, bf16* out, bf16* z, int B, int T, 
 }
 
 int gate_bwd_layer(const bf16* x, const bf16* img, const bf16* dout, const bf16* dzs, int dz_t0, bf16* dadg, int B, int T,
-                   int d, int Z, int t_live, hipStream_t s) {
+                   int d, int Z, int t_live, int t_zero, hipStream_t s) {
     const int tiles_per_b = (T + kLT - 1) / kLT;
     const int ntiles = B * tiles_per_b;
     const int grid = grid_for(ntiles, 1);
@@ -1030,7 +1059,7 @@ int gate_bwd_layer(const bf16* x, const bf16* img, const bf16* dout, const bf16*
             attr = true;                                                                                               \
         }                                                                                                              \
         hipLaunchKernelGGL((k16_gate_bwd<DO, DZ>), dim3(grid), dim3(512), kGateLds, s, x, img + kOffConvA8,           \
-                           img + kOffDzA8, dout, dzs, dz_t0, dadg, B, T, d, Z, tiles_per_b, ntiles, t_live);          \
+                           img + kOffDzA8, dout, dzs, dz_t0, dadg, B, T, d, Z, tiles_per_b, ntiles, t_live, t_zero);  \
     } while (0)
     if (dout && dzs) GB_LAUNCH(true, true);
     else if (dout) GB_LAUNCH(true, false);
@@ -1045,7 +1074,7 @@ int dx_grid(int B, int T) { return grid_for(B * ((T + kLT - 1) / kLT), 1); }
 
 // dx = dout + conv^T(dadg); zprev (the z of the layer BELOW, may be NULL) -> that layer's dWp partial tiles
 int dx_layer(const bf16* dadg, const bf16* img, const bf16* dout, const bf16* zprev, bf16* dx, float* dwp_part, int B,
-             int T, int d, int t_live, hipStream_t s) {
+             int T, int d, int t_live, int t_gate, int zero_dead, hipStream_t s) {
     const int tiles_per_b = (T + kLT - 1) / kLT;
     const int ntiles = B * tiles_per_b;
     const int grid = dx_grid(B, T);
@@ -1058,7 +1087,7 @@ int dx_layer(const bf16* dadg, const bf16* img, const bf16* dout, const bf16* zp
             attr = true;                                                                                               \
         }                                                                                                              \
         hipLaunchKernelGGL((k16_dx<DO, ZZ>), dim3(grid), dim3(512), kDxLds, s, dadg, img + kOffDxA, dout,                \
-                           zprev, dx, dwp_part, B, T, d, tiles_per_b, ntiles, t_live);                                \
+                           zprev, dx, dwp_part, B, T, d, tiles_per_b, ntiles, t_live, t_gate, zero_dead);             \
     } while (0)
     if (dout && zprev) DX_LAUNCH(true, true);
     else if (dout) DX_LAUNCH(true, false);
@@ -1096,7 +1125,8 @@ int bwd_multi_ok(int B, int T) {
 
 int bwd_multi(const bf16* x0, const bf16* xs, const bf16* z, const bf16* img, const bf16* dzs, bf16* dadg, bf16* dxb0,
               bf16* dxb1, float* parts, long long part_stride, unsigned* sync, const int* d, const int* Z,
-              const int* live_gate, const int* live_dx, int l_hi, int l_lo, int B, int T, int dz_t0, hipStream_t s) {
+              const int* live_gate, const int* live_dx, const int* zero_gate, int l_hi, int l_lo, int B, int T, int dz_t0,
+              hipStream_t s) {
     if (l_hi >= kMaxProb16 || l_lo < 1 || l_hi < l_lo) { wn::set_error("w16 bwd_multi: layers %d..%d", l_hi, l_lo); return WN_EARG; }
     BwdMultiArgs a{};
     a.x0 = x0; a.xs = xs; a.z = z; a.img = img; a.dzs = dzs; a.dadg = dadg; a.dxb[0] = dxb0; a.dxb[1] = dxb1;
@@ -1104,7 +1134,9 @@ int bwd_multi(const bf16* x0, const bf16* xs, const bf16* z, const bf16* img, co
     a.tiles_per_b = (T + kLT - 1) / kLT;
     a.ntiles = B * a.tiles_per_b;
     a.n = (long long)B * T; a.nw = (long long)B * (T - dz_t0);
-    for (int l = l_lo; l <= l_hi; ++l) { a.d[l] = d[l]; a.Z[l] = Z[l]; a.live_gate[l] = live_gate[l]; a.live_dx[l] = live_dx[l]; }
+    for (int l = l_lo; l <= l_hi; ++l) {
+        a.d[l] = d[l]; a.Z[l] = Z[l]; a.live_gate[l] = live_gate[l]; a.live_dx[l] = live_dx[l]; a.zero_gate[l] = zero_gate[l];
+    }
     a.l_hi = l_hi; a.l_lo = l_lo; a.B = B; a.T = T; a.dz_t0 = dz_t0;
     const int grid = grid_for(a.ntiles, 1);
     if (!bwd_multi_resident(grid)) { wn::set_error("w16 bwd_multi: %d workgroups are not all resident", grid); return WN_ESHAPE; }
