@@ -38,11 +38,12 @@ GEMM_MODE_TEXT = {
     "bf16x3": "skip-path and head contractions on bf16x3 split products (three bf16 parts per operand, six "
               "v_mfma_f32_32x32x16_bf16 per product, error <= 3*2^-27 relative per product); the fused 32-channel layer "
               "kernels (dilated convs, gate, residual projection, their backward) on exact fp32-input MFMA",
-    "fp16x2": "EVERY contraction of the step except the head convolutions -- the fused layer forward, the chained layer "
-              "backward, the skip sum, dz, dWs -- on fp16x2 split products: operands scaled by a power of two (per tile "
-              "from the wave's own maximum in the layer kernels, from a measured absmax on the skip path) and split into "
-              "two fp16 parts, three v_mfma_f32_32x32x16_f16 per product (error <= 2^-21 relative per product + 2^-24 of "
-              "the tile maximum), fp32 accumulation; head convolutions on bf16x3 (six terms).  Not the reference's fp32 "
+    "fp16x2": "EVERY contraction of the step except the head's backward -- the fused layer forward, the chained layer "
+              "backward, the skip sum, dz, dWs, the head forward (fused with the loss: wn_head_xent) -- on fp16x2 split "
+              "products: operands scaled by a power of two (per tile / per chunk from the wave's own maximum in the layer "
+              "kernels and the head, from a measured absmax on the skip path) and split into two fp16 parts, three "
+              "v_mfma_f32_32x32x16_f16 per product (error <= 2^-21 relative per product + 2^-24 of the tile maximum), fp32 "
+              "accumulation; the head's dx / dW contractions on bf16x3 (six terms).  Not the reference's fp32 "
               "products: held to the same parity bars (logits 1e-4, every gradient 1e-4 relative, tokens bit-exact)",
     "bf16": "operands rounded to bf16 once, fp32 accumulation (config 5's arithmetic; not fp32-accurate)",
 }
@@ -53,7 +54,7 @@ ARITH_SHORT = {
     "bf16x3": "f32 operands split into 3 bf16 parts, 6 v_mfma_f32_32x32x16_bf16 per product (<= 3*2^-27 per product: "
               "fp32-accurate), f32 accumulate; fused layer kernels on f32 MFMA",
     "fp16x2": "f32 operands scaled by a power of two and split into 2 fp16 parts, 3 v_mfma_f32_32x32x16_f16 per product "
-              "(<= 2^-21 per product), f32 accumulate; head convolutions on bf16x3",
+              "(<= 2^-21 per product), f32 accumulate; the head's backward contractions on bf16x3",
     "bf16": "operands rounded to bf16 once, f32 accumulate",
 }
 
@@ -118,8 +119,9 @@ def train_step(net, x, tgt, iw):
     # cannot see -- same loss and gradients -- but buys nothing at this size, so the bench computes every column like the
     # reference does.)
     _, s = net.forward_residual_block(c, t_off=iw)
-    logits = net.forward_softmax_block(s, apply_softmax=False)
-    loss = net.cross_entropy(logits, tgt)
+    # forward_softmax_block(s, apply_softmax=False) + cross_entropy (train.py:75-76) through WaveNet.head_cross_entropy: the last
+    # head convolution and the loss in ONE launch where the library covers it (config 2 does), the same two calls where not
+    loss = net.head_cross_entropy(s, tgt)
     net.backprop(loss)
     return loss
 

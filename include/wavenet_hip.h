@@ -229,6 +229,16 @@ int wn_softmax_fwd(const float* logits, float* prob, int N, int Q, void* stream)
 #define WN_XENT_LOSS_WORDS 2056
 int wn_softmax_xent(const float* logits, const int32_t* target, float* loss, float* dlogits, int N, int Q,
                     int64_t n_norm, void* stream);
+/* ABI 4.  The LAST head convolution and the loss in ONE launch (wavenet.py:584-593 with apply_softmax = False followed by
+ * wavenet.py:597-617): logits = W act(x) + b are formed and consumed on the chip -- they never reach memory --, dlogits (N, Cout)
+ * receives d loss / d logits for an upstream gradient of 1 (what wn_softmax_xent writes), loss as for wn_softmax_xent
+ * (WN_XENT_LOSS_WORDS floats, n_norm with the same meaning).  Covered: WN_GEMM_FP16X2, Cout = 256, Cin a multiple of 32
+ * (wn_head_xent_supported; WN_ESHAPE otherwise: run wn_pointwise_fwd + wn_softmax_xent).  The input has no known range: every
+ * 32-channel chunk of a wave's 32 columns is scaled by the power of two that fits the wave's own maximum before the fp16 split
+ * (error <= 2^-21 per product as elsewhere under FP16X2).  Backward: wn_pointwise_bwd(x, W, dlogits, ...) as after the two calls. */
+int wn_head_xent_supported(int Cin, int Cout, const WnExec* ex);
+int wn_head_xent(const float* x, const float* W, const float* bias, const int32_t* target, float* loss, float* dlogits,
+                 int N, int Cin, int Cout, int act, int64_t n_norm, const WnExec* ex, void* stream);
 
 /* x[i] *= *scale_dev (a device scalar), and nothing at all when *scale_dev == 1: the backward of the loss node
  * (chainer's softmax_cross_entropy backward multiplies by the upstream gradient, which is 1 for `loss.backward()`).  */

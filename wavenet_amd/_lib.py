@@ -77,6 +77,8 @@ _SIGS = {
     "wn_exec_workspace_bytes": (C.c_size_t, [C.POINTER(WnStackDesc), _i, _i, _i, _ip, _i, _i, _i]),
     "wn_softmax_fwd": (_i, [_p, _p, _i, _i, _p]),
     "wn_softmax_xent": (_i, [_p, _p, _p, _p, _i, _i, _i64, _p]),
+    "wn_head_xent_supported": (_i, [_i, _i, C.POINTER(WnExec)]),
+    "wn_head_xent": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, C.POINTER(WnExec), _p]),
     "wn_nchw_to_btc": (_i, [_p, _p, _i, _i, _i, _p]),
     "wn_btc_to_nchw": (_i, [_p, _p, _i, _i, _i, _p]),
     "wn_decoder_create": (_i, [_pp, C.POINTER(WnDecoderDesc), _p]),

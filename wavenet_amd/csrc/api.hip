@@ -280,6 +280,28 @@ int wn_softmax_xent(const float* logits, const int32_t* target, float* loss, flo
     return generic_softmax_xent(logits, target, loss, dlogits, N, Q, n_norm, as_stream(stream));
 }
 
+int wn_head_xent_supported(int Cin, int Cout, const WnExec* ex) {
+    wn::ExecScope exec__(ex);
+    return (!force_generic() && gemm_mode() == WN_GEMM_FP16X2 && Cout == 256 && Cin > 0 && Cin % 32 == 0 && mfma_pointwise_supported(Cin, Cout)) ? 1 : 0;
+}
+
+int wn_head_xent(const float* x, const float* W, const float* bias, const int32_t* target, float* loss, float* dlogits,
+                 int N, int Cin, int Cout, int act, int64_t n_norm, const WnExec* ex, void* stream) {
+    wn::ExecScope exec__(ex);
+    WN_CHECK_ARG(!ex || (ex->precision >= WN_GEMM_FP32 && ex->precision <= WN_GEMM_FP16X2), "%s: WnExec.precision must be 0 .. 3", __func__);
+    wn::ProfScope prof__("wn_head_xent", stream);
+    NN(x); NN(W); NN(target); NN(loss); NN(dlogits); POS(N); POS(Cin); POS(Cout);
+    WN_CHECK_ARG(act >= WN_ACT_NONE && act <= WN_ACT_ELU, "wn_head_xent: bad act %d", act);
+    WN_CHECK_SHAPE(wn_head_xent_supported(Cin, Cout, ex), "wn_head_xent: needs WN_GEMM_FP16X2, 256 outputs and a multiple of 32 "
+                                                          "inputs (run wn_pointwise_fwd + wn_softmax_xent instead)");
+    hipStream_t s = as_stream(stream);
+    const long long nn = n_norm > 0 ? n_norm : (n_norm == 0 ? N : -1);
+    int ncnt = 0, rc;
+    if (nn < 0 && (rc = generic_xent_count(target, N, Cout, loss, &ncnt, s))) return rc;
+    if ((rc = mfma_head_xent(x, W, bias, target, loss, dlogits, N, Cin, Cout, act, nn, ncnt, s))) return rc;
+    return generic_xent_final(loss, (int)((N + 127) / 128), nn, ncnt, s);
+}
+
 int wn_nchw_to_btc(const float* src, float* dst, int B, int C, int T, void* stream) {
     wn::ProfScope prof__("wn_nchw_to_btc", stream);
     NN(src); NN(dst); POS(B); POS(C); POS(T);

@@ -568,7 +568,7 @@ __global__ void k_softmax(const float* __restrict__ logits, float* __restrict__ 
 }
 
 // loss[0] = (sum of the per-block sums, in block order) / n_norm: no float atomics, the loss is bit-reproducible
-static constexpr int kXentPart = 8, kXentCnt = 64, kXentBlocks = 2048 - kXentCnt;
+// (kXentPart, kXentCnt, kXentBlocks: wn_kernels.hpp)
 // n_norm < 0: the number of rows that count (labels in [0, Q)) is taken on the device: k_xent_count leaves one INTEGER per
 // workgroup in the last kXentCnt words of the loss buffer and every reader adds them (one load per lane and a wave
 // reduction; integer sums do not depend on the order).  No memset, no atomics: with one zeroed word + an integer atomic
@@ -1127,6 +1127,20 @@ int generic_skip_bwd_dw(int L, const float* const* z, const int* cd, const float
 
 int generic_softmax(const float* logits, float* prob, long long N, int Q, hipStream_t s) {
     hipLaunchKernelGGL(k_softmax, dim3(cdiv(N, 4)), dim3(256), 0, s, logits, prob, N, Q);
+    WN_LAUNCH_CHECK();
+    return WN_OK;
+}
+
+int generic_xent_count(const int32_t* target, long long N, int Q, float* loss, int* ncnt_out, hipStream_t s) {
+    int ncnt = cdiv(N, 2048);
+    ncnt = ncnt > kXentCnt ? kXentCnt : (ncnt < 1 ? 1 : ncnt);
+    hipLaunchKernelGGL(k_xent_count, dim3(ncnt), dim3(1024), 0, s, target, N, Q, loss);
+    WN_LAUNCH_CHECK();
+    *ncnt_out = ncnt;
+    return WN_OK;
+}
+int generic_xent_final(float* loss, int nblocks, long long n_norm, int ncnt, hipStream_t s) {
+    hipLaunchKernelGGL(k_xent_final, dim3(1), dim3(256), 0, s, loss, nblocks, n_norm, ncnt);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

@@ -281,6 +281,21 @@ int mfma_pointwise_fwd(const float* x, const float* W, const float* bias, float*
     return launch_colgemm<false>(a, 1, s);
 }
 
+// The last head convolution and the loss in one launch (fp16 split, 256 outputs): dlogits = d loss / d (W act(x) + b), the
+// workgroups' loss sums in loss[kXentPart ..] (the caller finalises).  WN_ESHAPE when the shape or the arithmetic mode is not
+// covered: the caller then runs the convolution and the loss as two calls.
+int mfma_head_xent(const float* x, const float* W, const float* bias, const int32_t* target, float* loss, float* dlogits,
+                   long long N, int Cin, int Cout, int act, long long n_norm, int ncnt, hipStream_t s) {
+    if (Cout != 256 || Cin % 32 || N >= (1ll << 30) || gemm_mode() != WN_GEMM_FP16X2) return WN_ESHAPE;
+    CGArgs a{};
+    a.nsrc = 1; a.X[0] = x; a.W[0] = W; a.bias[0] = bias; a.K[0] = Cin; a.wsm[0] = Cin; a.wsk = 1;
+    a.out[0] = dlogits; a.M = Cout; a.ldo = Cout; a.N = N;
+    a.rows_out_per_b = (int)N; a.rows_src_per_b = (int)N; a.off = 0;
+    a.act = act; a.gate_x = nullptr; a.accumulate = 0;
+    a.xent_target = target; a.xent_loss = loss; a.xent_n_norm = n_norm; a.xent_ncnt = ncnt;
+    return launch_colgemm_b3(a, 6, 1, s);
+}
+
 // dx[n][c] = act'(x[n][c]) * sum_o W[o][c] dout[n][o]
 int mfma_pointwise_bwd_dx(const float* x, const float* W, const float* dout, float* dx, long long N, int Cin,
                           int Cout, int act, hipStream_t s) {

@@ -42,6 +42,13 @@ struct CGArgs {
     const unsigned* wmax_dev;        // fp16 split: bits of max |W| over the launch's weight tiles (launch_colgemm_b3 fills it)
     const float* proj_W;             // Wp[128][128], row-major
     const float* proj_bias;
+    // head + loss mode (mode 6, fp16 split, exactly 8 m-tiles = 256 outputs): the GEMM result + bias are a column's logits; the
+    // epilogue takes softmax cross-entropy against xent_target[row] and writes d loss / d logits to out[0] instead of the logits
+    // (row stride ldo), the workgroup's loss sum to xent_loss[kXentPart + workgroup] (wn_kernels.hpp)
+    const int32_t* xent_target;
+    float* xent_loss;
+    long long xent_n_norm;           // > 0: rows that count; < 0: counted on the device (xent_ncnt partial counts in xent_loss)
+    int xent_ncnt;
 };
 
 
@@ -82,6 +89,7 @@ int launch_wgrad(WGArgs& a, int M, hipStream_t s);
 int launch_wgrad_b3w(WGArgs& a, hipStream_t s);
 // one channel GEMM launch (multi-source form); picks bf16x3 or exact fp32
 int launch_colgemm_multi(CGArgs& a, hipStream_t s);
+
 // bf16x3 form of k_wgrad_mfma (same grid / arguments)
 int launch_wgrad_b3(const WGArgs& a, int mt, dim3 grid, hipStream_t s);
 

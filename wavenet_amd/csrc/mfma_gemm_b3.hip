@@ -78,7 +78,7 @@ __global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __
     const int i = threadIdx.x & 31, c4 = threadIdx.x >> 5;           // row, group of 4 consecutive k
     const float* W;
     int wsm, k0;
-    if (mode == 0 || mode == 4) {
+    if (mode == 0 || mode == 4 || mode == 6) {
         const int src = c / chunks_per_src;
         k0 = (c - src * chunks_per_src) * 32;
         W = a.W[src] + (long long)(t * 32) * a.wsm[src];
@@ -216,7 +216,12 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
     const float h2sx = H2 ? h2_scale(a.xmax_dev, kH2ScaleX) : 1.f;
     const float h2sw = H2 ? h2_scale(a.wmax_dev, kH2ScaleW) : 1.f;
     static_assert(MT == 4 || (MT == 8 && (ONE || H2)), "8 m-tiles per workgroup: one-term or fp16-split products");
-    static_assert(!H2 || MODE == 0 || MODE == 2, "the fp16 split serves the plain contractions only");
+    static_assert(!H2 || MODE == 0 || MODE == 2 || MODE == 6, "the fp16 split serves the plain contractions only");
+    static_assert(MODE != 6 || (H2 && MT == 8), "head + loss mode: fp16 split, all eight m-tiles (256 logits) in one workgroup");
+    // MODE 6 (head + loss): X -- relu(skip sum), no known range -- is scaled PER CHUNK by a power of two taken from the wave's own
+    // maximum (as the fused layer kernels do), so no range pass and no overflow fallback exist; a chunk's products leave the matrix
+    // core in their own scale and join the fp32 logits with one fma per element.
+    constexpr bool XENT = MODE == 6;
     constexpr int TB = ONE ? kTileBytes / 3 : (H2 ? kTileBytes * 2 / 3 : kTileBytes);   // bytes of one tile image
     __shared__ __attribute__((aligned(16))) char lds[2 * MT * TB];              // double-buffered tile images
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
     };
     float4 xr[4];
     auto load_x = [&](int c) {
-        const int src = (MODE == 0 || MODE >= 3) ? c / chunks_per_src : 0;
+        const int src = (MODE == 0 || MODE >= 3) ? c / chunks_per_src : 0;          // (mode 6 = mode 0 here)
         const int k0 = ((MODE == 0 || MODE >= 3) ? c - src * chunks_per_src : c) * 32;
         const int rs = rbase + a.soff[src];
         const bool rv = rs >= 0 && rs < a.rows_src_per_b;
@@ -318,6 +323,16 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
         // split this chunk's X columns (the loads were issued one iteration ago)
         ms = ms_next;
         bf16x8 xh[2], xm[2], xl[2];
+        float csx = 1.f, cix = 1.f;                       // MODE 6: this chunk's scale (a power of two) and its inverse
+        if constexpr (XENT) {
+            float mx = 0.f;
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(act_apply_t<ACT>(xr[i4].x)), fabsf(act_apply_t<ACT>(xr[i4].y))),
+                                     fmaxf(fabsf(act_apply_t<ACT>(xr[i4].z)), fabsf(act_apply_t<ACT>(xr[i4].w)))));
+            mx = lb_wave_max(mx * ms);
+            lb_pow2_scale(mx, csx, cix);
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const float v[8] = {xr[2 * ks].x, xr[2 * ks].y, xr[2 * ks].z, xr[2 * ks].w,
@@ -327,7 +342,7 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     _Float16 a0, a1;
-                    split2h(act_apply_t<ACT>(v[e]) * (ms * h2sx), a0, a1);
+                    split2h(act_apply_t<ACT>(v[e]) * (ms * (XENT ? csx : h2sx)), a0, a1);
                     fh[e] = a0; fm[e] = a1;
                 }
                 xh[ks] = __builtin_bit_cast(bf16x8, fh);
@@ -378,6 +393,11 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
             } else {
                 ldA(mt, f);
             }
+            f32x16 tacc;                                   // MODE 6: the chunk's product of this m-tile, in the chunk's scale
+            if constexpr (XENT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tacc[r] = 0.f;
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const bf16x8 ah = f[ks][0];
@@ -386,6 +406,12 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
                 if (H2) {                                  // fp16 two-way split: wm xh + wh xm + wh xh
                     const f16x8 fah = __builtin_bit_cast(f16x8, ah), fam = __builtin_bit_cast(f16x8, am);
                     const f16x8 fxh = __builtin_bit_cast(f16x8, xh[ks]), fxm = __builtin_bit_cast(f16x8, xm[ks]);
+                    if constexpr (XENT) {
+                        tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam, fxh, tacc, 0, 0, 0);
+                        tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fxm, tacc, 0, 0, 0);
+                        tacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fxh, tacc, 0, 0, 0);
+                        continue;
+                    }
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam, fxh, acc[mt], 0, 0, 0);
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fxm, acc[mt], 0, 0, 0);
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fxh, acc[mt], 0, 0, 0);
@@ -400,6 +426,10 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
                     acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xm[ks], acc[mt], 0, 0, 0);
                 }
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, xh[ks], acc[mt], 0, 0, 0);
+            }
+            if constexpr (XENT) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][r] = fmaf(tacc[r], cix, acc[mt][r]);
             }
             if (PIPE) __builtin_amdgcn_sched_barrier(0);
         }
@@ -498,11 +528,80 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] *= 1.f / (h2sw * h2sx);                 // exact: a power of two
+            for (int r = 0; r < 16; ++r) acc[mt][r] *= 1.f / (h2sw * (XENT ? 1.f : h2sx));      // exact: a power of two
     }
     __syncthreads();                                               // the image buffers become the waves' 4 KB row patches
     float* patch = reinterpret_cast<float*>(lds) + wave * 1024;
     const RowMap rm = row_map(no, nvalid, lane);
+    if constexpr (XENT) {
+        // ---- head + loss: acc[mt][r] (+ bias) = logit 32 mt + b3_ch(r, h) of column j; lanes j and j + 32 hold 128 logits each.
+        // Softmax cross-entropy against the column's label as k_softmax_xent computes it (loss row = m + log sum exp(l - m) - l_t;
+        // a label outside [0, 256) -- Chainer's ignore label -1 -- gives no loss and a zero gradient); the logits themselves
+        // never reach memory: out[0] receives d loss / d logits = (softmax - onehot) / (rows that count).
+        const float* bb = a.bias[0];
+        if (bb) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][r] += bb[mt * 32 + b3_ch(r, h)];
+        }
+        const int tg = nvalid ? a.xent_target[no] : -1;
+        const bool counts = tg >= 0 && tg < 32 * MT;
+        float m = -INFINITY, lt = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                m = fmaxf(m, acc[mt][r]);
+                lt = (mt * 32 + b3_ch(r, h) == tg) ? acc[mt][r] : lt;
+            }
+        m = fmaxf(m, __shfl_xor(m, 32));
+        lt += __shfl_xor(lt, 32);                          // the partner lane holds 0 for a label that is not among its channels
+        float ssum = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[mt][r] = __expf(acc[mt][r] - m);
+                ssum += acc[mt][r];
+            }
+        ssum += __shfl_xor(ssum, 32);
+        // the rows that count: given by the host, or counted on the device from the labels (k_xent_count's integer partials)
+        float cnt;
+        if (a.xent_n_norm < 0) {
+            int cn = lane < a.xent_ncnt ? reinterpret_cast<const int*>(a.xent_loss + kXentPart + kXentBlocks)[lane] : 0;
+            for (int o = 32; o >= 1; o >>= 1) cn += __shfl_xor(cn, o);
+            cnt = (float)(cn > 0 ? cn : 1);
+        } else {
+            cnt = (float)a.xent_n_norm;
+        }
+        const float invN = 1.f / cnt;
+        const float sc = counts ? invN / ssum : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            float4 t[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float d4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * q + e;
+                    d4[e] = acc[mt][r] * sc - ((counts && mt * 32 + b3_ch(r, h) == tg) ? invN : 0.f);
+                }
+                t[q] = make_float4(d4[0], d4[1], d4[2], d4[3]);
+            }
+            tile_store_rows(patch, lane, t, a.out[0], a.ldo, mt * 32, rm);
+        }
+        // this workgroup's loss sum: columns in lane order (lanes 0..31 carry a column each), waves in order -- a fixed tree
+        float rl = (counts && h == 0) ? m + __logf(ssum) - lt : 0.f;
+        for (int o = 32; o >= 1; o >>= 1) rl += __shfl_xor(rl, o);
+        __syncthreads();                                            // every wave is done with its patch
+        float* red = reinterpret_cast<float*>(lds);
+        if (lane == 0) red[wave] = rl;
+        __syncthreads();
+        if (tid == 0) a.xent_loss[kXentPart + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        return;
+    }
     if (MODE == 3) {
         const bool live = rbase - a.off >= a.gate_Z;               // rbase - off = t of this column
 #pragma unroll
@@ -825,7 +924,10 @@ __global__ __launch_bounds__(256, 2) void k_colgemm_h2q(CGArgs a, const __bf16* 
 }
 
 int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
-    if (mode != 0 && mode != 2 && mode != 3 && mode != 4 && mode != 5) return WN_ESHAPE;
+    if (mode != 0 && mode != 2 && mode != 3 && mode != 4 && mode != 5 && mode != 6) return WN_ESHAPE;
+    if (mode == 6 && !(half2_mode() && a.M == 256 && a.nsrc == 1 && a.xent_target && a.xent_loss && a.out[0] &&
+                       cdiv(a.N, 128) <= kXentBlocks))
+        return WN_ESHAPE;
     int mtiles, nchunks, cps;
     if (mode == 0 || mode >= 3) {
         if (a.M % 32) return WN_ESHAPE;
@@ -844,7 +946,7 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     }
     const bool one = one_term();
     // fp16 split: plain contractions whose operands the caller declared range-safe (forward activations); else six terms
-    const bool h2 = half2_mode() && (a.h2_ok || a.xmax_dev) && (mode == 0 || mode == 2);
+    const bool h2 = half2_mode() && ((a.h2_ok || a.xmax_dev) && (mode == 0 || mode == 2) || mode == 6);
     const size_t bytes = (size_t)nchunks * mtiles * (one ? kTileBytes / 3 : (h2 ? kTileBytes * 2 / 3 : kTileBytes));
     const size_t bytes2 = mode == 5 ? (size_t)16 * (kTileBytes / 3) : 0;        // Wp's image behind the gate image
     __bf16* img = reinterpret_cast<__bf16*>(exec_scratch(bytes + bytes2, "the split weight image"));
@@ -877,6 +979,16 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     }
     const bool mt8 = (one || h2) && mtiles >= 8;
     dim3 grid(cdiv(a.N, 128) * cdiv(mtiles, mt8 ? 8 : 4));
+    if (mode == 6) {
+#define X_LAUNCH(ACT_) hipLaunchKernelGGL((k_colgemm_b3<6, ACT_, 3, 8>), grid, dim3(256), 0, s, a, (const __bf16*)img, mtiles,   \
+                                          nchunks, cps, (const __bf16*)nullptr)
+        if (a.act == WN_ACT_RELU) X_LAUNCH(WN_ACT_RELU);
+        else if (a.act == WN_ACT_ELU) X_LAUNCH(WN_ACT_ELU);
+        else X_LAUNCH(WN_ACT_NONE);
+#undef X_LAUNCH
+        WN_LAUNCH_CHECK();
+        return WN_OK;
+    }
 #define CG_LAUNCH(MODE_, ACT_)                                                                                          \
     do {                                                                                                                \
         if (mt8) hipLaunchKernelGGL((k_colgemm_b3<MODE_, ACT_, 1, 8>), grid, dim3(256), 0, s, a, (const __bf16*)img,    \

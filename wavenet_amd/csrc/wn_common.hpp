@@ -98,4 +98,7 @@ __device__ __forceinline__ float act_grad(float x, int act) {
     return 1.f;
 }
 
+// layout of the WN_XENT_LOSS_WORDS floats behind `loss` (generic_kernels.hip): [0] the result, [kXentPart ..] one partial sum per
+// workgroup of the loss kernel (at most kXentBlocks), then kXentCnt integer partial counts of the rows that count
+static constexpr int kXentPart = 8, kXentCnt = 64, kXentBlocks = 2048 - kXentCnt;
 }  // namespace wn

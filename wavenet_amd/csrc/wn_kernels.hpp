@@ -32,6 +32,10 @@ int generic_skip_bwd_dw(int L, const float* const* z, const int* cd, const float
 int generic_colsum(const float* A, int nB, int nT, int tmin, int lda, int M, float* out, hipStream_t s);
 int generic_softmax(const float*, float*, long long, int, hipStream_t);
 int generic_softmax_xent(const float*, const int32_t*, float*, float*, long long, int, long long n_norm, hipStream_t);
+// the two small launches around a loss kernel that leaves its per-workgroup sums in loss[kXentPart + workgroup]: the device-side
+// count of the rows that count (n_norm < 0; *ncnt = its workgroups) and the fixed-order sum into loss[0]
+int generic_xent_count(const int32_t* target, long long N, int Q, float* loss, int* ncnt, hipStream_t s);
+int generic_xent_final(float* loss, int nblocks, long long n_norm, int ncnt, hipStream_t s);
 int generic_transpose(const float* src, float* dst, int batch, int R, int Cc, hipStream_t s);
 int generic_sample(const float*, const double*, int32_t*, int, int, hipStream_t);
 int generic_mulaw_encode_pcm16(const int16_t* pcm, const int32_t* lut, int32_t* tok, long long n, hipStream_t s);
@@ -125,6 +129,8 @@ int mfma_skip_sum_fwd(int L, const float* const* z, const float* const* Ws, cons
 int mfma_skip_bwd_dz(int L, const float* const* Ws, const int* cd, const float* dskip, float* const* dz, int B,
                      int T, int t_off, int Tw, int Cs, bool window_only, hipStream_t s);
 bool mfma_pointwise_supported(int Cin, int Cout);
+int mfma_head_xent(const float* x, const float* W, const float* bias, const int32_t* target, float* loss, float* dlogits,
+                   long long N, int Cin, int Cout, int act, long long n_norm, int ncnt, hipStream_t s);
 int mfma_pointwise_fwd(const float* x, const float* W, const float* bias, float* out, long long N, int Cin,
                        int Cout, int act, hipStream_t s);
 int mfma_pointwise_bwd_dx(const float* x, const float* W, const float* dout, float* dx, long long N, int Cin,

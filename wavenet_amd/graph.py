@@ -23,8 +23,8 @@ def default_loss(net, x, tgt, window_only: bool = False):
     the columns that window cannot see (WaveNet.forward_residual_block); same loss, same gradients."""
     c = net.forward_causal_block(x)
     _, s = net.forward_residual_block(c, t_off=x.shape[1] - tgt.shape[1], window_only=window_only)
-    logits = net.forward_softmax_block(s, apply_softmax=False)
-    return net.cross_entropy(logits, tgt)
+    # forward_softmax_block(apply_softmax=False) + cross_entropy, the last head convolution and the loss in one launch where covered
+    return net.head_cross_entropy(s, tgt)
 
 
 class TrainStepGraph(object):

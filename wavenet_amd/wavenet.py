@@ -239,6 +239,42 @@ class _XentFn(_Fn):
         return dlog, None, None
 
 
+class _HeadXentFn(_Fn):
+    """The last head convolution and the softmax cross-entropy as ONE node and one launch (wn_head_xent): the logits are formed
+    and consumed on the chip.  forward_softmax_block(apply_softmax=False) followed by cross_entropy (wavenet.py:584-617) gives
+    the same loss and the same gradients through two nodes and a (N, Q) logits tensor in memory."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, target, act, n_norm, net):
+        lead = x.shape[:-1]
+        Cin, Cout = x.shape[-1], W.shape[0]
+        x2 = x.reshape(-1, Cin).contiguous()
+        N = x2.shape[0]
+        buf = torch.empty((_lib.XENT_LOSS_WORDS,), device=x.device, dtype=torch.float32)
+        dlog = torch.empty((N, Cout), device=x.device, dtype=torch.float32)
+        check(_lib.lib().wn_head_xent(ptr(x2), ptr(W), ptr(b), ptr(target), ptr(buf), ptr(dlog), N, Cin, Cout, act,
+                                      int(n_norm), net._exec(), stream_ptr()), "wn_head_xent")
+        ctx.save_for_backward(x2)
+        ctx.W, ctx.b, ctx.act, ctx.lead, ctx.net, ctx.dlog = W, b, act, lead, net, dlog
+        return buf[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (x2,) = ctx.saved_tensors
+        dlog, ctx.dlog = ctx.dlog, None
+        if dlog is None:
+            raise RuntimeError("the fused head + cross-entropy node can be backpropagated once (its gradient buffer is scaled in place)")
+        W, b = ctx.W, ctx.b
+        Cout, Cin = W.shape[0], x2.shape[1]
+        lib = _lib.lib()
+        d = dloss.to(torch.float32).reshape(1).contiguous()
+        check(lib.wn_scale_by_dev(ptr(dlog), ptr(d), dlog.numel(), stream_ptr()), "wn_scale_by_dev")
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        check(lib.wn_pointwise_bwd(ptr(x2), ptr(W), ptr(dlog), ptr(dx), ptr(W.grad), ptr(None if b is None else b.grad),
+                                   x2.shape[0], Cin, Cout, ctx.act, ctx.net._exec(), stream_ptr()), "wn_pointwise_bwd")
+        return (None if dx is None else dx.view(*ctx.lead, Cin)), None, None, None, None, None, None
+
+
 class _StackFn(_Fn):
     """All residual layers + the deferred skip sum as ONE autograd node and ONE library call each way
     (WaveNet.forward_residual_block, wavenet.py:572-582)."""
@@ -550,6 +586,7 @@ class WaveNet(object):
         self.storage = storage
         self.gemm_precision = None          # None: the module default (wavenet_amd.set_gemm_precision) at call time
         self.exec_flags = None              # None: _lib.default_exec_flags(); else WN_EXEC_* bits for every call of this model
+        self.fuse_head_loss = os.environ.get("WAVENET_HIP_NO_FUSED_HEAD_LOSS") != "1"      # head_cross_entropy: one launch when covered
         self.fwd_t1_min_blocks = None       # None: _lib.default_fwd_t1_min_blocks() (WnExec.fwd_t1_min_blocks)
         self._scratch, self._scratch_keep = {}, []
         self._pack16 = None
@@ -964,6 +1001,39 @@ class WaveNet(object):
         rows = _to_btc(raw)                                        # row b*T'+t, as after the reference's transpose
         B, Tw, Q = rows.shape
         return _XentFn.apply(rows.reshape(B * Tw, Q).contiguous(), tgt.to(torch.int32).reshape(-1).contiguous(), n_norm)
+
+    def head_cross_entropy(self, sum_skip, target_signal_data):
+        """``cross_entropy(forward_softmax_block(sum_skip, apply_softmax=False), target)`` (wavenet.py:584-617), with the LAST head
+        convolution and the loss as one launch when the library covers it (fp32 storage, fp16x2 arithmetic, 256 quantisation
+        steps: ``wn_head_xent``) -- the (B, Q, 1, T') logits then never reach memory (200 MB less traffic per step at config 2).
+        Same loss, same gradients (the products are the skip path's fp16x2 split instead of the head's six-term split: 1e-6);
+        anything the fused launch does not cover runs the two calls.  New capability: the reference has no such method; the
+        captured training step (``TrainStepGraph`` / ``graph.default_loss``) uses it."""
+        x = self.to_variable(sum_skip)
+        _need_gpu(x)
+        tensor_target = isinstance(target_signal_data, torch.Tensor)
+        if tensor_target and target_signal_data.requires_grad:
+            raise Exception("target_signal_data cannot be Variable")
+        lay = self.softmax_conv_layers[-1]
+        fused = (self.storage != "bf16" and self.fuse_head_loss and
+                 _lib.lib().wn_head_xent_supported(lay.W.shape[1], lay.W.shape[0], self._exec()) == 1)
+        if not fused:
+            return self.cross_entropy(self.forward_softmax_block(x, apply_softmax=False), target_signal_data)
+        act = ACT[self.head_activation]
+        out = _to_btc(x)
+        for l2 in self.softmax_conv_layers[:-1]:
+            out = _PointwiseFn.apply(out, l2.W, l2.b, act, self)
+        n_norm = -1
+        if not tensor_target:
+            lab = np.asarray(target_signal_data)
+            Q = lay.W.shape[0]
+            if lab.size and (lab.min() < -1 or lab.max() >= Q):
+                raise Exception("cross_entropy: labels must lie in [0, %d) or be -1 (ignored)" % Q)
+            n_norm = max(int((lab != -1).sum()), 1)
+        tgt = self.to_variable(np.asarray(target_signal_data) if not tensor_target else target_signal_data)
+        if out.shape[1] != tgt.shape[1]:
+            raise Exception("raw_network_output.width != target.width")
+        return _HeadXentFn.apply(out, lay.W, lay.b, tgt.to(torch.int32).reshape(-1).contiguous(), act, n_norm, self)
 
     # -- the deferred skip projection -----------------------------------------------------------
     def _skip_sum(self, zs: Sequence[torch.Tensor], skip: torch.Tensor, B, T, t_off, Tw):
