@@ -301,11 +301,13 @@ int wn_decoder_run(void* handle, int32_t first_token, const double* uniforms, in
  * WN_DECODER_ONE_WORKGROUP; uniforms[u] (n doubles), out_tokens[u] (n) and the optional prob_traces[u] (n * Q; the array
  * itself may be NULL) are device pointers held in HOST arrays, first_tokens is a host array.  At most wn_decoder_batch_max()
  * (28) utterances, and 9 * n_handles workgroups must fit the device's CUs (WN_ESHAPE otherwise); n >= 2.  The groups share
- * nothing: an utterance's tokens are those of its own wn_decoder_run with the same uniforms, bit for bit.
+ * nothing: an utterance's tokens are those of its own wn_decoder_run with the same uniforms, bit for bit.  same_weights != 0 is
+ * the caller's word that every handle was created from (and updated with) the SAME weights: all utterances then read handle 0's
+ * packed weights (one copy through the L2s instead of n_handles; each keeps its own state) -- same tokens, higher rate.
  * wn_decoder_status(handle) reports per utterance as after wn_decoder_run. */
 int wn_decoder_batch_max(void);
 int wn_decoder_run_batch(void* const* handles, int n_handles, const int32_t* first_tokens, const double* const* uniforms, int n,
-                         int32_t* const* out_tokens, float* const* prob_traces, void* stream);
+                         int32_t* const* out_tokens, float* const* prob_traces, int same_weights, void* stream);
 /* ABI 4.  wn_decoder_run's default form runs on nine workgroups that hand values to each other through device memory and
  * therefore must all be resident.  The library uses the one-workgroup kernel by itself on a device with fewer than nine
  * CUs; what it cannot know in advance -- other work holding the CUs for seconds -- ends in a wait that GIVES UP after

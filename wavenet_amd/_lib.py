@@ -89,7 +89,7 @@ _SIGS = {
     "wn_decoder_run": (_i, [_p, C.c_int32, _p, _i, _p, _p, _p]),
     "wn_decoder_status": (_i, [_p, _p]),
     "wn_decoder_batch_max": (_i, []),
-    "wn_decoder_run_batch": (_i, [_p, _i, _p, _p, _i, _p, _p, _p]),
+    "wn_decoder_run_batch": (_i, [_p, _i, _p, _p, _i, _p, _p, _i, _p]),
     "wn_sample_categorical": (_i, [_p, _p, _p, _i, _i, _p]),
     "wn_sqnorm": (_i, [_p, _p, _i64, _f, _f, _p, _p]),
     "wn_adam_step": (_i, [_p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _p, _f, _f, _p]),

@@ -532,7 +532,7 @@ int wn_decoder_run(void* handle, int32_t first_token, const double* uniforms, in
 int wn_decoder_batch_max(void) { return kDecMaxBatch; }
 
 int wn_decoder_run_batch(void* const* handles, int n_handles, const int32_t* first_tokens, const double* const* uniforms, int n,
-                         int32_t* const* out_tokens, float* const* prob_traces, void* stream) {
+                         int32_t* const* out_tokens, float* const* prob_traces, int same_weights, void* stream) {
     WN_CHECK_ARG(handles && first_tokens && uniforms && out_tokens && n_handles >= 1 && n > 0, "wn_decoder_run_batch: bad argument");
     WN_CHECK_SHAPE(n_handles <= kDecMaxBatch, "wn_decoder_run_batch: at most %d utterances per launch", kDecMaxBatch);
     const float* P[kDecMaxBatch]; const float* hb[kDecMaxBatch]; const float* E[kDecMaxBatch]; const DecLayer* ly[kDecMaxBatch];
@@ -555,7 +555,7 @@ int wn_decoder_run_batch(void* const* handles, int n_handles, const int32_t* fir
     WN_CHECK_SHAPE(decode_fast_batch_ok(D0->meta.nlayers, n_handles, n),
                    "wn_decoder_run_batch: %d utterances x 9 workgroups must all be resident on the device, and n >= 2", n_handles);
     const int rc = decode_fast_launch_batch(n_handles, P, D0->meta.nlayers, hb, E, ly, ar, tr, n0, n, ft, uniforms, out_tokens,
-                                            prob_traces, D0->meta.Q, D0->meta.head_act, as_stream(stream));
+                                            prob_traces, D0->meta.Q, D0->meta.head_act, same_weights != 0, as_stream(stream));
     if (rc) return rc;
     for (int u = 0; u < n_handles; ++u) {
         Decoder* D = (Decoder*)handles[u];

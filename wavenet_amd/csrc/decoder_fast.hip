@@ -955,7 +955,7 @@ int decode_fast_batch_ok(int nlayers, int n_utt, int nsteps) {
 int decode_fast_launch_batch(int n_utt, const float* const* P, int nlayers, const float* const* hbias, const float* const* E,
                              const DecLayer* const* layers, float* const* arena, int* const* tok_ring, const long long* n0,
                              int nsteps, const int* first_token, const double* const* uniforms, int32_t* const* out_tokens,
-                             float* const* prob_out, int prob_stride, int head_act, hipStream_t s) {
+                             float* const* prob_out, int prob_stride, int head_act, bool same_weights, hipStream_t s) {
     if (!decode_fast_batch_ok(nlayers, n_utt, nsteps)) {
         wn::set_error("decode batch: %d utterances x 9 workgroups do not fit the device (or fewer than 2 steps)", n_utt);
         return WN_ESHAPE;
@@ -970,7 +970,11 @@ int decode_fast_launch_batch(int n_utt, const float* const* P, int nlayers, cons
     const int nx = nlayers * 64 + 8 * 256 + 16;
     for (int u = 0; u < n_utt; ++u) {
         DecBatchItem& q = a.it[u];
-        q.P = P[u]; q.hbias = hbias[u]; q.E = E[u]; q.layers = layers[u]; q.arena = arena[u]; q.tok_ring = tok_ring[u];
+        // same_weights (the caller's word that every handle was created from the same weights): every utterance reads utterance
+        // 0's packed weights, embedding table and head bias -- the 28 chain workgroups then stream ONE 0.96 MB copy per step
+        // through the XCDs' L2s instead of 28; the state (rings, token ring, exchange entries) stays per utterance
+        const int wu = same_weights ? 0 : u;
+        q.P = P[wu]; q.hbias = hbias[wu]; q.E = E[wu]; q.layers = layers[u]; q.arena = arena[u]; q.tok_ring = tok_ring[u];
         q.n0 = n0[u]; q.uniforms = uniforms[u]; q.out_tokens = out_tokens[u]; q.prob_out = prob_out ? prob_out[u] : nullptr;
         q.first_token = first_token[u];
         q.X = reinterpret_cast<u64*>(const_cast<float*>(P[u]) + (size_t)nlayers * kLayerFloats + 256 * 256);

@@ -19,6 +19,6 @@ int decode_fast_batch_ok(int nlayers, int n_utt, int nsteps);
 int decode_fast_launch_batch(int n_utt, const float* const* P, int nlayers, const float* const* hbias, const float* const* E,
                              const DecLayer* const* layers, float* const* arena, int* const* tok_ring, const long long* n0,
                              int nsteps, const int* first_token, const double* const* uniforms, int32_t* const* out_tokens,
-                             float* const* prob_out, int prob_stride, int head_act, hipStream_t s);
+                             float* const* prob_out, int prob_stride, int head_act, bool same_weights, hipStream_t s);
 int decode_fast_status(const float* P, int nlayers, hipStream_t s, int* gave_up);
 }  // namespace wn

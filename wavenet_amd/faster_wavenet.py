@@ -15,6 +15,7 @@ Differences a caller can observe, both deliberate:
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import numpy as np
@@ -285,7 +286,8 @@ class FasterWaveNet(WaveNet):
             handles = (C.c_void_p * N)(*[h.value for h in self._batch_decs[:N]])
             rest = [u[i, 1:].contiguous() for i in range(N)]
             outs = [torch.empty((n_samples - 1,), device=self.device, dtype=torch.int32) for _ in range(N)]
-            check(lib.wn_decoder_run_batch(handles, N, firsts, ptr_array(rest), n_samples - 1, ptr_array(outs), None,
+            same = 0 if os.environ.get("WAVENET_HIP_BATCH_OWN_WEIGHTS") == "1" else 1      # the handles ARE copies of this model's weights
+            check(lib.wn_decoder_run_batch(handles, N, firsts, ptr_array(rest), n_samples - 1, ptr_array(outs), None, same,
                                            stream_ptr()), "wn_decoder_run_batch")
             for i in range(N):
                 check(lib.wn_decoder_status(self._batch_decs[i], stream_ptr()), "wn_decoder_status")
