@@ -78,7 +78,7 @@ def test_cfg2_topology_train_step_loss_and_every_gradient(B, extra, t1, prec):
     net.zero_grads()
     loss.backward()
     torch.cuda.synchronize()
-    assert abs(float(loss) - loss_ref) < 1e-4
+    assert abs(float(loss.detach()) - loss_ref) < 1e-4
     np.testing.assert_allclose(to_np(logits), logits_ref, atol=1e-4)
     worst = _check_grads(net, g, 1e-4, "eager")
     assert float(net.residual_blocks[-1][-1].projection_block.W.grad.abs().sum()) == 0
