@@ -343,3 +343,43 @@ def test_cfg4_batched_decode_equals_the_single_utterance_runs_bit_for_bit():
             want = to_np(net.generate(n, u[i]))
             np.testing.assert_array_equal(got[i], want, err_msg="utterance %d of %d" % (i, N))
         assert len({tuple(r[:64]) for r in got}) == N                                      # and they ARE different utterances
+
+
+def test_batched_decode_rejects_bad_arguments_without_touching_the_device():
+    """wn_decoder_run_batch through the C ABI: a handle given twice, more utterances than wn_decoder_batch_max(), a single
+    step (the nine-workgroup form needs two or more) and a decoder created with WN_DECODER_ONE_WORKGROUP are refused with a
+    message (WN_EARG / WN_ESHAPE); wn_decoder_status of a handle that never ran the nine-workgroup form is WN_OK."""
+    import ctypes as C
+    from wavenet_amd import _lib
+    lib = _lib.lib()
+    nets = []
+    for flags in (None, _lib.WN_DECODER_ONE_WORKGROUP):
+        net = FasterWaveNet(Params(R.make_params(**CFG2)), seed=1)
+        net.to_gpu()
+        net.exec_flags = flags
+        nets.append(net)
+    h0, h1 = nets[0]._decoder(), nets[1]._decoder()
+    assert lib.wn_decoder_status(h0, None) == 0
+    nmax = lib.wn_decoder_batch_max()
+    assert nmax == 28
+    u = torch.zeros((nmax + 1, 8), device="cuda", dtype=torch.float64) + 0.5
+    out = torch.zeros((nmax + 1, 8), device="cuda", dtype=torch.int32)
+    firsts = (C.c_int32 * (nmax + 1))(*([127] * (nmax + 1)))
+    ups = (C.c_void_p * (nmax + 1))(*[u[i].data_ptr() for i in range(nmax + 1)])
+    ops = (C.c_void_p * (nmax + 1))(*[out[i].data_ptr() for i in range(nmax + 1)])
+
+    def call(handles, n):
+        hs = (C.c_void_p * len(handles))(*[h.value for h in handles])
+        rc = lib.wn_decoder_run_batch(hs, len(handles), firsts, ups, n, ops, None, 1, None)
+        return rc, lib.wn_last_error().decode()
+
+    rc, msg = call([h0, h0], 8)
+    assert rc == -1 and "twice" in msg, (rc, msg)
+    rc, msg = call([h0] * (nmax + 1), 8)
+    assert rc == -2 and "at most" in msg, (rc, msg)
+    rc, msg = call([h0], 1)
+    assert rc == -2, (rc, msg)
+    rc, msg = call([h1], 8)
+    assert rc == -2 and "ONE_WORKGROUP" in msg, (rc, msg)
+    torch.cuda.synchronize()
+    assert int(out.abs().sum()) == 0                                    # nothing ran
