@@ -427,9 +427,13 @@ __device__ __forceinline__ void chain_body(
     auto dep_request_lds = [&](int tile) {
         if constexpr (MULTI) lds_dma4_sc1(dep_ptr(tile), dep_lds);
     };
+    // (inline asm with its own wait: a plain LDS read here "may alias" the loop's LDS-DMA requests in hipcc's eyes and gets
+    // s_waitcnt vmcnt(0) in front of it -- the x rows the body has just asked for and the (V, U) stores included)
     auto dep_take = [&]() -> unsigned {
         unsigned v = 0xffffffffu;
-        if constexpr (MULTI) v = dep_lds[lane];
+        if constexpr (MULTI)
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(v) : "v"((unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned*)dep_lds + 4u * (unsigned)lane) : "memory");
         return v;
     };
 #ifdef WN_MULTI_STAMPS
@@ -441,12 +445,19 @@ __device__ __forceinline__ void chain_body(
 #ifdef WN_MULTI_STAMPS
             unsigned long long w0; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w0) :: "memory");
 #endif
-            while (!gave_up && __builtin_amdgcn_ballot_w64(v < (unsigned)li - dep_slack) != 0ull) {   // a word still shows an earlier entry
+            // a word still shows an earlier entry?  Every polled value is USED before the loop can be left, and the loop's
+            // condition is a scalar: with `while (ballot(v < ..))` the header's compare may be fed by the poll of the back edge,
+            // so hipcc puts s_waitcnt vmcnt(0) in front of it ON EVERY PASS -- also the first, whose v came from LDS -- and
+            // the x rows fetch_x has just requested (and the eight (V, U) stores) are waited for with nothing to overlap them
+            bool late = !gave_up && __builtin_amdgcn_ballot_w64(v < (unsigned)li - dep_slack) != 0ull;
+            while (late) {
                 __builtin_amdgcn_s_sleep(1);
                 v = dep_request(tile);
+                late = __builtin_amdgcn_ballot_w64(v < (unsigned)li - dep_slack) != 0ull;
                 if (++spins > (1u << 18)) {          // never hang the GPU: give up for good, flag it, the results are void
                     gave_up = true;
                     if (lane == 0) __hip_atomic_store(ma->sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    late = false;
                 }
             }
 #ifdef WN_MULTI_STAMPS
