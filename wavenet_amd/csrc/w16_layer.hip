@@ -357,25 +357,25 @@ __device__ __forceinline__ void gate_issue(char* lds, const GateP& P, const Wave
         return;
     }
     const bf16* xb = P.x + (long long)b * T * 128;
-    dma_pieces<false, MULTI>(lds + M::xcur(buf) * kLTileB, lane, w, 1, 1, [&](int r) {
+    dma_pieces<false, true>(lds + M::xcur(buf) * kLTileB, lane, w, 1, 1, [&](int r) {
         const int t = t0 + r < T ? t0 + r : T - 1;
         return xb + (long long)t * 128;
     });
-    dma_pieces<false, MULTI>(lds + M::xold(buf) * kLTileB, lane, w, 1, 1, [&](int r) {
+    dma_pieces<false, true>(lds + M::xold(buf) * kLTileB, lane, w, 1, 1, [&](int r) {
         int t = t0 + r < T ? t0 + r : T - 1;
         t = t - d >= 0 ? t - d : 0;
         return xb + (long long)t * 128;
     });
     if (HAS_DO) {
         const bf16* db = P.dout + (long long)b * T * 128;
-        dma_pieces<MULTI, MULTI>(lds + M::dot(buf) * kLTileB, lane, w, 1, 1, [&](int r) {
+        dma_pieces<MULTI, true>(lds + M::dot(buf) * kLTileB, lane, w, 1, 1, [&](int r) {
             const int t = t0 + r < T ? t0 + r : T - 1;
             return db + (long long)t * 128;
         });
     }
     if (HAS_DZ) {
         const bf16* zb = P.dzs + (long long)b * Tw * 128;       // dz_skip exists for the loss window only
-        dma_pieces<false, MULTI>(lds + M::dzt(buf) * kLTileB, lane, w, 1, 1, [&](int r) {
+        dma_pieces<false, true>(lds + M::dzt(buf) * kLTileB, lane, w, 1, 1, [&](int r) {
             int t = t0 + r < T ? t0 + r : T - 1;
             t = t - dz_t0 >= 0 ? t - dz_t0 : 0;
             return zb + (long long)t * 128;
@@ -408,11 +408,11 @@ __device__ __forceinline__ void dx_issue(char* lds, const DxP& P, const WaveC& c
     const bf16* ab = P.dadg + (long long)b * T * 256;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        if (tlive) dma_pieces<MULTI, MULTI>(lds + M::at(buf, half) * kLTileB, lane, w, 1, 1, [&](int r) {
+        if (tlive) dma_pieces<MULTI, true>(lds + M::at(buf, half) * kLTileB, lane, w, 1, 1, [&](int r) {
             const int t = t0 + r < T ? t0 + r : T - 1;
             return ab + (long long)t * 256 + 128 * half;
         });
-        dma_pieces<MULTI, MULTI>(lds + M::at(buf, 2 + half) * kLTileB, lane, w, 1, 1, [&](int r) {
+        dma_pieces<MULTI, true>(lds + M::at(buf, 2 + half) * kLTileB, lane, w, 1, 1, [&](int r) {
             int t = t0 + r + d;
             t = t < T ? t : T - 1;
             return ab + (long long)t * 256 + 128 * half;
@@ -420,14 +420,14 @@ __device__ __forceinline__ void dx_issue(char* lds, const DxP& P, const WaveC& c
     }
     if (HAS_DO && tlive) {
         const bf16* db = P.dout + (long long)b * T * 128;
-        dma_pieces<MULTI, MULTI>(lds + M::at(buf, 4) * kLTileB, lane, w, 1, 1, [&](int r) {
+        dma_pieces<MULTI, true>(lds + M::at(buf, 4) * kLTileB, lane, w, 1, 1, [&](int r) {
             const int t = t0 + r < T ? t0 + r : T - 1;
             return db + (long long)t * 128;
         });
     }
     if (HAS_Z) {
         const bf16* zb = P.zprev + (long long)b * T * 128;
-        dma_pieces<false, MULTI>(lds + M::at(buf, 5) * kLTileB, lane, w, 1, 1, [&](int r) {
+        dma_pieces<false, true>(lds + M::at(buf, 5) * kLTileB, lane, w, 1, 1, [&](int r) {
             const int t = t0 + r < T ? t0 + r : T - 1;
             return zb + (long long)t * 128;
         });
