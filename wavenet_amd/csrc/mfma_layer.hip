@@ -564,6 +564,12 @@ __global__ __launch_bounds__(64 * kGrpWaves, 5) void k_layer_fwd_h2_grp(GrpArgs 
         if (l == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (writer) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (2 + (SAVE >= 1 ? 1 : 0) + (SAVE == 1 ? 1 : 0))) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the image's inverse scale, through the SCALAR cache.  (As a plain load it was a vector-memory load hipcc waited for
+        // with s_waitcnt vmcnt(0) a dozen instructions later -- right behind the NEXT image's requests, which have a whole
+        // layer to land, and this layer's stores.)
+        float w_inv;
+        asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(w_inv) : "s"(a.img + (size_t)l * kH2ImgStride + kH2ImgBytes) : "memory");
         __syncthreads();
         // 2. x[t - d]: slab row (32 wv + j - d); rows left of the slab (halo tile only) and columns before the clip are 0
         float xo[16];
@@ -585,7 +591,6 @@ __global__ __launch_bounds__(64 * kGrpWaves, 5) void k_layer_fwd_h2_grp(GrpArgs 
         if (l + 1 < a.nl) dma_image(l + 1, (l + 1) & 1);
         // 3. the layer (k_layer_fwd_h2_t1's arithmetic)
         const char* img = imgs[l & 1];
-        const float w_inv = *reinterpret_cast<const float*>(a.img + (size_t)l * kH2ImgStride + kH2ImgBytes);
         float mx = 0.f;
 #pragma unroll
         for (int s = 0; s < 16; ++s) mx = fmaxf(mx, fmaxf(fabsf(xc[s]), fabsf(xo[s])));

@@ -707,6 +707,7 @@ __device__ __forceinline__ bool dx_phase(char* lds, const DxP& P, MSync& ms, boo
             // (every polled value is USED before the loop can be left: a load still pending at the exit would make hipcc put
             // s_waitcnt vmcnt(0) in front of the next write of that register -- the next body's dep_word -- and with it
             // drain the store every body leaves in flight on purpose)
+            asm volatile("" ::"v"(v));                   // (the first poll too: also on the path that has given up)
             bool late = !ms.gave_up && __builtin_amdgcn_ballot_w64(v < ms.done) != 0ull;
             while (late) {
                 __builtin_amdgcn_s_sleep(1);
