@@ -175,3 +175,32 @@ def test_no_vector_memory_instruction_reads_a_scalar_a_vector_instruction_has_ju
                 states += int(nop.group(1)) + 1 if nop else 1
                 k -= 1
     assert checked > 100
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("src,kernels", [
+    ("w16_gemm.hip", ("k16_wgrad",)),
+    ("w16_layer.hip", ("k16_fwd", "k16_gate_bwd", "k16_dx")),
+])
+def test_bf16_stage_loops_carry_no_wait_of_the_compilers(src, kernels):
+    """Round 5 ("waits the compiler adds"): with a builtin LDS-DMA in a loop hipcc puts `s_waitcnt vmcnt(0)` in front
+    of the next LDS read that may alias it -- in k16_wgrad that stood at the top of the stage loop, right behind the requests of
+    the stage after next (5 us per 64 KB stage instead of 1), in k16_dx in front of the dWp reads.  These kernels request through
+    inline asm and wait by their own counts; this keeps a builtin request (or a plain load consumed inside the loop) from coming
+    back: behind the kernel's first request, no block of a loop holds a vmcnt wait that is not the kernel's own."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_waits
+    text = isa_waits.assembly(os.path.join(ROOT, "wavenet_amd", "csrc", src))
+    waits = isa_waits.compiler_waits_in_loops(text)
+    seen = 0
+    for sym, ws in waits.items():
+        if not any(("%d%s" % (len(k), k)) in sym for k in kernels):
+            continue
+        seen += 1
+        s0 = next(i for i, l in enumerate(text) if l.startswith(sym + ":"))
+        first_req = next((i + 1 for i in range(s0, len(text)) if "global_load_lds" in text[i]), None)
+        assert first_req is not None, sym
+        late = [w for w in ws if w[0] > first_req]
+        assert not late, "%s: compiler-made vmcnt wait(s) inside a loop behind the first request: %s" % (sym, late)
+    assert seen >= len(kernels)
