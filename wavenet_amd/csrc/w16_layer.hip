@@ -141,11 +141,13 @@ __global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
             return;
         }
-        dma_pieces(xcur(buf), lane, 2 * w, 1, 2, [&](int r) {
+        // (inline asm as the interior tiles' requests: one builtin LDS-DMA anywhere in the loop and every LDS wait hipcc emits
+        // in it is lgkmcnt(0) -- fragments in flight for the next k-step are waited for with the ones being consumed)
+        dma_pieces<false, true>(xcur(buf), lane, 2 * w, 1, 2, [&](int r) {
             const int t = t0 + r < T ? t0 + r : T - 1;
             return xb + (long long)t * 128;
         });
-        dma_pieces(xold(buf), lane, 2 * w, 1, 2, [&](int r) {
+        dma_pieces<false, true>(xold(buf), lane, 2 * w, 1, 2, [&](int r) {
             int t = t0 + r < T ? t0 + r : T - 1;
             t = t - d >= 0 ? t - d : 0;
             return xb + (long long)t * 128;
