@@ -179,7 +179,7 @@ def test_no_vector_memory_instruction_reads_a_scalar_a_vector_instruction_has_ju
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 @pytest.mark.parametrize("src,kernels", [
-    ("w16_gemm.hip", ("k16_wgrad",)),
+    ("w16_gemm.hip", ("k16_wgrad", "k16_cgemm256")),
     ("w16_layer.hip", ("k16_fwd", "k16_gate_bwd", "k16_dx")),
 ])
 def test_bf16_stage_loops_carry_no_wait_of_the_compilers(src, kernels):
