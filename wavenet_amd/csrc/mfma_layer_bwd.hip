@@ -1084,6 +1084,13 @@ __device__ __forceinline__ void chain_body(
 #endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) dza[q] = dzb[q];
+        if constexpr (!PL) {
+            // (dzb came from plain loads a body ago: hipcc waits for them with vmcnt(0) where it copies them -- keep that in front
+            // of the x requests below, which it otherwise issues first and then waits for with everything else)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(dza[q].x), "+v"(dza[q].y), "+v"(dza[q].z), "+v"(dza[q].w));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         fetch_x(tile + stride, xc, xo);
         if (tile + 2 * stride < last) {
             dep_wait(tile + 2 * stride, dep_take());
