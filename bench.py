@@ -343,7 +343,17 @@ def main():
     # slower than the steady state (measured: 4.26 ms with 3 warm-up steps, 4.16 ms with 100), so a short timed region right
     # after a 3-step warm-up measures the ramp, not the kernel.  Same code path as the timed steps.
     spinup = max(0, 60 - args.warmup)
-    for _ in range(spinup):
+    # The FIRST step (seed-1234 weights, this batch) against the oracle's loss for exactly that step, committed as
+    # tests/golden/cfg2_bench_step.npz (tests/golden/make_golden.py::cfg2_bench_step; N = 1 only: the fixture is rank 0's batch
+    # of a world of one).  Like golden_tokens_match for the decode: the bench checks the thing it times, before it times it.
+    first_loss = float(step_fn().detach())
+    golden = None
+    gfile = os.path.join(ROOT, "tests", "golden", "cfg2_bench_step.npz")
+    if world == 1 and os.path.exists(gfile):
+        gz = np.load(gfile)
+        if [int(x.sum().item()), int(tgt.sum().item())] == gz["tokens_checksum"].tolist():
+            golden = float(gz["loss"])
+    for _ in range(max(0, spinup - 1)):
         step_fn()
     for _ in range(args.warmup):
         step_fn()
@@ -402,6 +412,10 @@ def main():
                                "fwd + bwd + clip + Adam%s" % (B_PER_GPU, " + RCCL all-reduce" if world > 1 or force_dist else ""),
                    "global_batch": world * B_PER_GPU, "seq_len": T, "parallelism": "dp%d" % world},
         "loss": float(loss.detach()),
+        "first_step_loss": first_loss, "golden_loss": golden,
+        "golden_loss_match": (abs(first_loss - golden) <= 1e-4) if golden is not None else None,
+        "golden_loss_source": "tests/golden/cfg2_bench_step.npz: the oracle's loss for this batch and the seed-1234 weights "
+                              "(bar 1e-4); `loss` is the loss after the %d optimiser steps of this run" % (spinup + args.warmup + args.steps),
         "launch": ("hipGraph replay, one graph launch per step" + (" (fwd+bwd graph, RCCL all-reduce, optimiser graph)"
                    if world > 1 or force_dist else "")) if graph is not None else "op-by-op launches from Python",
         "eager_ms_per_step": eager_dt * 1e3,

@@ -115,6 +115,44 @@ def cfg4_decode_trace(n=16000, margin=2e-5):
     print("cfg4 trace: %d draws replaced, token sum %d" % (replaced, int(toks.sum())))
 
 
+def cfg2_bench_step(probes=384):
+    """The step bench.py times (BASELINE config 2, train_audio/train.py:58-80): 4 x 10 layers, 32 / 256 channels, the
+    bench's own batch -- ``bench.make_batch(0, 1, iw)``: 8 synthetic clips x 16,384 tokens, targets = the next sample, loss
+    over the last 12,290 columns -- and the product's seeded initial weights (``WaveNet(Params, seed=1234)`` ==
+    ``init_weights(p, 1234)``, asserted).  One oracle step (13.5 s, 7.4 GB with 8 threads): the loss, the logits and the
+    skip sum at ``probes`` (clip, column) positions, and of every gradient tensor its L2 norm, its largest magnitude and
+    its sum -- at the oracle's OWN ReLU mask (the GPU test that differentiates at the device's mask runs the oracle live).
+    bench.py holds its first captured step against ``loss`` before the timed region (``golden_loss_match``)."""
+    from wavenet_amd import Params, WaveNet, data
+    p = R.make_params(**CFG2)
+    w = WaveNet(Params(p), seed=1234).state_dict()
+    w0 = R.init_weights(p, 1234)
+    assert all(np.array_equal(w[k], w0[k]) for k in w0) and len(w) == len(w0)
+    iw = R.input_width(p)
+    B, T = 8, 16384
+    tok = data.mulaw_encode(data.synthetic_waveform(B, T + 1, 16000, b0=0, Btot=B))
+    assert np.array_equal(tok, D.mulaw_quantize(D.synthetic_waveform(B, T + 1, 16000)))      # product host code == oracle
+    idx, tgt = tok[:, :T].astype(np.int32), tok[:, iw + 1:T + 1].astype(np.int32)
+    keep = {}
+    loss, logits, g = R.train_step_grads(p, w, idx, tgt, keep=keep)
+    Tw = T - iw
+    rs = np.random.RandomState(11)
+    pb = rs.randint(0, B, probes).astype(np.int32)
+    pt = np.concatenate([[0, 1, Tw - 2, Tw - 1], rs.randint(0, Tw, probes - 4)]).astype(np.int32)
+    names = sorted(g)
+    np.savez_compressed(
+        os.path.join(OUT, "cfg2_bench_step.npz"), loss=np.array(loss, np.float64),
+        tokens_checksum=np.array([int(idx.astype(np.int64).sum()), int(tgt.astype(np.int64).sum())]),
+        probe_b=pb, probe_t=pt, logits_probes=logits[pb, :, 0, pt].astype(np.float32),
+        skip_probes=keep["skip"][pb, :, 0, pt].astype(np.float32),
+        logits_sum=np.array(float(logits.astype(np.float64).sum())), logits_abs_sum=np.array(float(np.abs(logits.astype(np.float64)).sum())),
+        relu_live=np.array(int((keep["skip"] > 0).sum())),
+        grad_names=np.array(names), grad_l2=np.array([float(np.sqrt((g[k].astype(np.float64) ** 2).sum())) for k in names]),
+        grad_absmax=np.array([float(np.abs(g[k]).max()) for k in names]),
+        grad_sum=np.array([float(g[k].astype(np.float64).sum()) for k in names]))
+    print("cfg2 bench step: loss %.9f" % loss)
+
+
 def mulaw_table():
     q = D.mulaw_quantize_pcm16(np.arange(-32768, 32768))
     np.savez_compressed(os.path.join(OUT, "mulaw_pcm16.npz"), table=q.astype(np.uint8))
@@ -122,7 +160,7 @@ def mulaw_table():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (kat1, cfg1_forward, cfg1_train_step, fastgen_trace, mulaw_table, cfg4_decode_trace):
+    for fn in (kat1, cfg1_forward, cfg1_train_step, fastgen_trace, mulaw_table, cfg4_decode_trace, cfg2_bench_step):
         if not only or fn.__name__ in only:
             fn()
     for f in sorted(os.listdir(OUT)):

@@ -88,3 +88,32 @@ def test_cfg4_decode_fixture_first_steps_and_weights():
     assert int(z["tokens"].astype(np.int64).sum()) == 1991402
     cdf = np.cumsum(tr[2].astype(np.float64)); cdf /= cdf[-1]
     assert np.abs(cdf - z["uniforms"][2]).min() >= float(z["margin"])
+
+
+def test_cfg2_bench_step_fixture():
+    """tests/golden/cfg2_bench_step.npz (the step bench.py times, train_audio/train.py:58-80 at BASELINE config 2's size): the
+    tokens the PRODUCT's host code makes for the bench batch are the ones the fixture was computed on, the oracle reproduces
+    the fixture's loss / logits probes / gradient norms (one full oracle step, ~20 s and 7.4 GB)."""
+    from wavenet_amd import Params, WaveNet, data
+    z = np.load(os.path.join(G, "cfg2_bench_step.npz"))
+    p = R.make_params(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 10,
+                      residual_num_blocks=4, softmax_conv_channels=[256, 256])
+    w = R.init_weights(p, 1234)
+    sd = WaveNet(Params(p), seed=1234).state_dict()
+    assert set(sd) == set(w) and all(np.array_equal(sd[k], w[k]) for k in w)
+    iw = R.input_width(p)
+    tok = data.mulaw_encode(data.synthetic_waveform(8, 16385, 16000, b0=0, Btot=8))
+    idx, tgt = tok[:, :16384].astype(np.int32), tok[:, iw + 1:16385].astype(np.int32)
+    assert [int(idx.astype(np.int64).sum()), int(tgt.astype(np.int64).sum())] == z["tokens_checksum"].tolist()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    keep = {}
+    loss, logits, g = R.train_step_grads(p, w, idx, tgt, keep=keep)
+    assert abs(loss - float(z["loss"])) < 2e-6
+    pb, pt = z["probe_b"], z["probe_t"]
+    np.testing.assert_allclose(logits[pb, :, 0, pt], z["logits_probes"], atol=2e-6)
+    np.testing.assert_allclose(keep["skip"][pb, :, 0, pt], z["skip_probes"], atol=2e-6)
+    assert int((keep["skip"] > 0).sum()) == int(z["relu_live"])
+    names = [str(k) for k in z["grad_names"]]
+    assert sorted(g) == names
+    for k, l2 in zip(names, z["grad_l2"]):
+        assert abs(np.sqrt((g[k].astype(np.float64) ** 2).sum()) - l2) <= 1e-5 * l2 + 1e-12, k

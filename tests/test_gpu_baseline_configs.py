@@ -37,15 +37,17 @@ def _check_grads(net, g, rel, tag):
 
 
 @pytest.mark.parametrize("prec", ["fp16x2", "bf16x3", "fp32"])
-@pytest.mark.parametrize("B,extra,t1", [(2, 200, 0), (1, 333, 1), (2, 12290, 0)])
+@pytest.mark.parametrize("B,extra,t1", [(2, 200, 0), (1, 333, 1), (2, 12290, 0), (8, 12290, 0)])
 def test_cfg2_topology_train_step_loss_and_every_gradient(B, extra, t1, prec):
     """The stack the bench times (4 x 10 layers, d = 1..512, 1280-deep skip contraction, the 40-layer partial-tile
     reduction, the chained backward's live ranges over four blocks) at T = input_width + extra: loss within 1e-4, every
     gradient tensor within 1e-4 of its largest entry, against the oracle's autograd -- eager and graph replay -- in EVERY
     shipped arithmetic mode (fp16x2: the default; bf16x3 / fp32: the exact-fp32 layer kernels with six-term bf16 or fp32
     skip-path contractions).  The third case is the bench's own window: T = 16,384, t_off = 4,094, loss over 12,290
-    columns (B = 2: 1,024 tiles per layer, four per wave in the chained backward, the XCD-aware tile order).  t1 = 1
-    forces the one-tile-per-wave forward kernels, which bench-sized launches take by themselves
+    columns (B = 2: 1,024 tiles per layer, four per wave in the chained backward, the XCD-aware tile order).  The fourth
+    case IS the timed workload: B = 8 x T = 16,384 on bench.py's own batch (``bench.make_batch(0, 1, iw)``; 4,096 tiles per
+    layer, one workgroup per CU in the multi-layer backward) -- the oracle step on it costs ~15-25 s and 7.4 GB of host
+    memory.  t1 = 1 forces the one-tile-per-wave forward kernels, which bench-sized launches take by themselves
     (WnExec.fwd_t1_min_blocks)."""
     p, w, net = build(CFG2)
     net.gemm_precision = prec
@@ -53,10 +55,17 @@ def test_cfg2_topology_train_step_loss_and_every_gradient(B, extra, t1, prec):
     iw = R.input_width(p)
     assert iw == 4094 and len(net._flat_layers) == 40
     T = iw + extra
-    rs = np.random.RandomState(17 + extra)
-    idx = rs.randint(0, 256, (B, T)).astype(np.int32)
-    tgt = rs.randint(0, 256, (B, extra)).astype(np.int32)
-    x, t = dev(idx), dev(tgt)
+    if B == 8:
+        from bench import make_batch
+        x, t = make_batch(0, 1, iw)
+        idx, tgt = to_np(x), to_np(t)
+        assert idx.shape == (8, 16384) and tgt.shape == (8, 12290)
+        torch.set_num_threads(min(16, os.cpu_count() or 1))     # the oracle's intra-op pool: more threads than that only hurt
+    else:
+        rs = np.random.RandomState(17 + extra)
+        idx = rs.randint(0, 256, (B, T)).astype(np.int32)
+        tgt = rs.randint(0, 256, (B, extra)).astype(np.int32)
+        x, t = dev(idx), dev(tgt)
     # op by op
     c = net.forward_causal_block(x)
     _, s = net.forward_residual_block(c, t_off=T - extra)
@@ -146,9 +155,10 @@ def test_cfg4_decoder_on_nine_workgroups_equals_the_one_workgroup_kernel():
 
 
 def test_cfg2_full_batch_gradients_fp16x2_against_exact_fp32_on_the_device():
-    """At the bench's full size (B = 8 x T = 16,384: 4,096 tiles per layer, one workgroup per CU in the chained backward)
-    the oracle is out of reach (memory), but the exact-fp32-MFMA mode -- held to the oracle at T = 16,384, B = 2 above --
-    is not.  Forward: skip sum and logits of the default fp16x2 mode within 1e-4 of it, loss within 1e-5.  Backward: both
+    """An extra at the bench's full size (B = 8 x T = 16,384: 4,096 tiles per layer, one workgroup per CU in the chained
+    backward; the oracle itself is held against this size in test_cfg2_topology_train_step_loss_and_every_gradient's
+    fourth case and in test_cfg2_bench_step_against_the_committed_oracle_fixture): the default arithmetic against the
+    exact-fp32-MFMA mode on the device, where BOTH differentiate the same recorded forward.  Forward: skip sum and logits of the default fp16x2 mode within 1e-4 of it, loss within 1e-5.  Backward: both
     modes differentiate the SAME recorded forward (the exact-fp32 one: same saved activations, same ReLU mask -- see the
     test above for why the mask must be shared), every gradient tensor of fp16x2 within 1e-4 of fp32 relative to the
     tensor's largest entry."""
@@ -185,6 +195,48 @@ def test_cfg2_full_batch_gradients_fp16x2_against_exact_fp32_on_the_device():
         scale = max(float(np.abs(a).max()), 1e-9)
         assert np.abs(a - b).max() <= 1e-4 * scale, (ln.name, kind, float(np.abs(a - b).max()), scale)
     assert np.abs(grads["fp32"] - grads["fp16x2"]).max() > 0            # and the two really are different arithmetic
+
+
+@pytest.mark.parametrize("prec", ["fp16x2", "bf16x3", "fp32"])
+def test_cfg2_bench_step_against_the_committed_oracle_fixture(prec):
+    """tests/golden/cfg2_bench_step.npz (make_golden.py::cfg2_bench_step): the oracle's loss, logits / skip-sum probes and
+    per-tensor gradient norms for the step bench.py times -- its batch, the seed-1234 weights -- at the oracle's own ReLU
+    mask.  The captured graph's first step (what bench.py reports as ``golden_loss_match``): loss within 1e-4; op by op:
+    logits and skip sum at 384 probed (clip, column) positions within 1e-4; every gradient tensor's L2 norm within 1e-3
+    relative + its sum within 1e-3 of (norm x sqrt(n)) -- looser than the live-oracle test because a skip value within
+    rounding distance of 0 flips its ReLU (see there), which the norms absorb and an element-wise bar would not."""
+    from bench import make_batch
+    z = np.load(os.path.join(G, "cfg2_bench_step.npz"))
+    net = WaveNet(Params(R.make_params(**CFG2)), seed=1234)
+    net.gemm_precision = prec
+    net.to_gpu()
+    iw = net.input_width
+    x, t = make_batch(0, 1, iw)
+    assert [int(x.sum().item()), int(t.sum().item())] == z["tokens_checksum"].tolist()
+    c = net.forward_causal_block(x)
+    _, s = net.forward_residual_block(c, t_off=iw)
+    logits = net.forward_softmax_block(s, apply_softmax=False)
+    loss = net.cross_entropy(logits, t)
+    net.zero_grads()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - float(z["loss"])) < 1e-4
+    pb, pt = torch.as_tensor(z["probe_b"]).long().cuda(), torch.as_tensor(z["probe_t"]).long().cuda()
+    np.testing.assert_allclose(to_np(logits[pb, :, 0, pt]), z["logits_probes"], atol=1e-4)
+    np.testing.assert_allclose(to_np(s[pb, :, 0, pt]), z["skip_probes"], atol=1e-4)
+    assert abs(float(logits.double().sum()) - float(z["logits_sum"])) <= 1e-5 * float(z["logits_abs_sum"])
+    assert abs(int((s > 0).sum().item()) - int(z["relu_live"])) <= 64
+    names = [str(k) for k in z["grad_names"]]
+    got = {"%s/%s" % (ln.name, kind): to_np(net._grad_arena[off:off + n]).astype(np.float64) for ln, kind, off, n, _ in net._spans}
+    assert sorted(got) == names
+    for k, l2, am, sm in zip(names, z["grad_l2"], z["grad_absmax"], z["grad_sum"]):
+        g = got[k]
+        assert abs(np.sqrt((g ** 2).sum()) - l2) <= 1e-3 * l2 + 1e-12, (k, np.sqrt((g ** 2).sum()), l2)
+        assert abs(np.abs(g).max() - am) <= 1e-2 * am + 1e-12, (k, np.abs(g).max(), am)
+        assert abs(g.sum() - sm) <= 1e-3 * l2 * np.sqrt(g.size) + 1e-12, (k, g.sum(), sm)
+    del c, s, logits, loss
+    gr = TrainStepGraph(net, x, t)
+    assert abs(float(gr.step()) - float(z["loss"])) < 1e-4
 
 
 def test_bench_two_ranks_on_one_gpu_runs_the_n_gt_1_branch():
