@@ -447,6 +447,14 @@ def main():
         out["samples_per_s_by_mode"] = {k: (samples / (v * 1e-3) if v else None) for k, v in by_mode.items()}
         out["exact_fp32_ms_per_step"] = by_mode.get("fp32")
         out["exact_fp32_samples_per_s"] = out["samples_per_s_by_mode"].get("fp32")
+        # the like-for-like figures inside `config`, so that a reader of the parsed line alone sees them next to `value`:
+        # bf16x3 = fp32-accurate products (<= 3 * 2^-27), fp32 = the reference's own arithmetic; `value` is in arith_mode
+        out["config"].update({"arith_mode": default_mode,
+                              "like_for_like_samples_per_s": out["samples_per_s_by_mode"].get("bf16x3"),
+                              "like_for_like_ms_per_step": by_mode.get("bf16x3"),
+                              "exact_fp32_samples_per_s": out["samples_per_s_by_mode"].get("fp32"),
+                              "exact_fp32_ms_per_step": by_mode.get("fp32"),
+                              "golden_loss_match": out.get("golden_loss_match")})
     if rank == 0 and world == 1 and not force_dist:
         # ---- fused residual-stack forward (the north star's roofline target) -------------------
         with torch.no_grad():

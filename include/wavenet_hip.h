@@ -35,6 +35,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the functions declared between this push and the pop at the end of the
+ * header are its ONLY dynamic symbols (tests/test_host_cpu.py holds `nm -D` to this list). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define WN_ABI_VERSION 4
 #define WN_OK      0
@@ -422,6 +427,9 @@ int wn_prof_enable(int on);                    /* 1: clear + start recording, 0:
 /* "name calls total_ms min_ms max_ms" per line into buf; returns the bytes needed (synchronises). */
 int wn_prof_report(char* buf, int buflen);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -724,8 +724,9 @@ def test_pipelined_skip_weight_gradient_is_the_older_kernel_bit_for_bit(B, T, tw
 
 def test_fast_step_full_window_output_is_the_references_shape_and_values():
     """faster_wavenet.py:105-113 returns the softmax of the WHOLE rolled window, (1, Q, 1, W), every cached column under
-    the ELU head; ``keep_window`` + ``full_window=True`` reproduces that from a device-side ring of logits: all W columns
-    of eight consecutive steps against the oracle's literal restatement, and the newest-column face is unchanged."""
+    the ELU head; the default face reproduces that from a device-side ring of logits (``keep_window``, on by default): all W
+    columns of eight consecutive steps against the oracle's literal restatement; ``full_window=False`` is the newest-column
+    face, and asking for the window of a model whose prefill kept none raises."""
     over = dict(quantization_steps=256, causal_conv_channels=[16], residual_conv_channels=[16] * 4,
                 residual_num_blocks=2, softmax_conv_channels=[32, 256])
     p, w, net = build(over, cls=FasterWaveNet)
@@ -733,45 +734,48 @@ def test_fast_step_full_window_output_is_the_references_shape_and_values():
     iw = net.input_width
     rs = np.random.RandomState(11)
     buf = rs.randint(0, 256, (iw,)).astype(np.int32)
+    assert net.keep_window is True
+    net.keep_window = False
     with pytest.raises(Exception, match="keep_window"):
         net._forward_one_step(data.onehot_pixel_image(buf.reshape(1, -1), 256), full_window=True)
     net.keep_window = True
     for step in range(9):
         x = data.onehot_pixel_image(buf[-iw:].reshape(1, -1), 256)
         want = ref._forward_one_step(x, apply_softmax=True)
-        got = net._forward_one_step(x, apply_softmax=True, as_numpy=True, full_window=step > 0 and step != 5)
-        if step > 0 and step != 5:
+        got = net._forward_one_step(x, apply_softmax=True, as_numpy=True, **({"full_window": False} if step == 5 else {}))
+        if step == 5:
+            assert got.shape == (1, 256, 1, 1)
+        if step != 5:                                   # the prefill call returns the window too (wavenet.py:556-563)
             assert got.shape == want.shape == (1, 256, 1, iw)
             np.testing.assert_allclose(got, want, atol=2e-5)
         else:                                           # the prefill call / a newest-column call in between
             np.testing.assert_allclose(got[0, :, 0, -1], want[0, :, 0, -1], atol=2e-5)
         buf = np.append(buf, [int(rs.randint(0, 256))]).astype(np.int32)
-    lg = net._forward_one_step(int(buf[-1]), apply_softmax=False, as_numpy=True, full_window=True)
+    lg = net._forward_one_step(int(buf[-1]), apply_softmax=False, as_numpy=True)
     want = ref._forward_one_step(data.onehot_pixel_image(buf[-iw:].reshape(1, -1), 256), apply_softmax=False)
     np.testing.assert_allclose(lg, want, atol=1e-4)
 
 
 def test_generate_with_keep_window_drops_the_stale_window_history():
     """generate() advances the decoder n - 1 steps on the device; the host-side ring of window logits still
-    holds the prefill state.  A later full_window=True call must not answer with that stale window: it raises until the
-    caller prefills again; the newest-column face keeps working from the decoder's (current) state and equals a fresh
+    holds the prefill state.  A later full-window call (the default face) must not answer with that stale window: it raises
+    until the caller prefills again; the newest-column face (full_window=False) keeps working from the decoder's (current) state and equals a fresh
     generate() of the same draws."""
     over = dict(quantization_steps=256, causal_conv_channels=[16], residual_conv_channels=[16] * 4,
                 residual_num_blocks=2, softmax_conv_channels=[32, 256])
     p, w, net = build(over, cls=FasterWaveNet)
-    net.keep_window = True
     u = np.random.RandomState(3).random_sample(12)
     toks = to_np(net.generate(10, u[:10]))
     with pytest.raises(Exception, match="window history was dropped"):
-        net._forward_one_step(int(toks[-1]), full_window=True)
-    pr = net._forward_one_step(int(toks[-1]), apply_softmax=True, as_numpy=True)        # step 11 from the decoder's state
+        net._forward_one_step(int(toks[-1]))
+    pr = net._forward_one_step(int(toks[-1]), apply_softmax=True, as_numpy=True, full_window=False)   # step 11 from the decoder's state
     _, probs = net.generate(11, u[:11], return_probs=True)
     np.testing.assert_allclose(pr[0, :, 0, -1], to_np(probs)[10], atol=2e-6)
     net.prev_causal_outputs = None                                                      # prefill again: full_window is back
     iw = net.input_width
     buf = np.random.RandomState(4).randint(0, 256, (iw,)).astype(np.int32)
     net._forward_one_step(data.onehot_pixel_image(buf.reshape(1, -1), 256))
-    out = net._forward_one_step(int(buf[-1]), as_numpy=True, full_window=True)
+    out = net._forward_one_step(int(buf[-1]), as_numpy=True)
     assert out.shape == (1, 256, 1, iw)
 
 

@@ -25,6 +25,11 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libwavenet_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    # ... and NOTHING else: the library is built with -fvisibility=hidden + an export map, so its dynamic symbol table is the
+    # header's list (no mangled wn:: internals, no compiler markers) -- what a third party binds is what the header says
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if ln.strip()}
+    assert exported == declared, sorted(exported ^ declared)
     assert _lib.lib().wn_abi_version() == 4 == int(re.search(r"#define WN_ABI_VERSION (\d+)", hdr).group(1))
     assert not hasattr(lib, "wn_set_gemm_precision")          # ABI v2: no process-wide arithmetic mode
     # ABI v3: no switch read from the process environment inside the library (they are WnExec.flags / fields now)

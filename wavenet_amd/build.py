@@ -16,7 +16,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libwavenet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"] + \
+# -fvisibility=hidden: only what include/wavenet_hip.h declares (inside its `#pragma GCC visibility push(default)`) is exported
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"] + \
     os.environ.get("WAVENET_HIP_EXTRA_FLAGS", "").split()        # e.g. -DWN16_STAMPS for the in-kernel timestamps
 
 
@@ -45,7 +46,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force, hdr), srcs))
     if force or not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        # the version script drops what hipcc itself adds to the dynamic table (one __hip_cuid_* marker per translation unit)
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden",
+               "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

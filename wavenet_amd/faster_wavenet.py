@@ -4,11 +4,12 @@ The reference caches every layer's full-window output and rolls all caches by on
 generated sample.  Here the state is a handle owned by libwavenet_hip.so: per-layer rings of the
 last (fw-1)*d input columns in HBM, advanced by one persistent kernel (csrc/decoder.hip).
 
-Differences a caller can observe, both deliberate:
-* ``_forward_one_step`` returns ``(1, Q, 1, 1)`` -- the newest column -- not the full ``(1, Q, 1, W)``
-  window; the reference's caller reads ``[0, :, 0, -1]`` only (train_audio/generate.py:38), which
-  indexes the same values.  ``keep_window = True`` + ``_forward_one_step(..., full_window=True)`` gives the
-  reference's shape and values (faster_wavenet.py:105-113) from a device-side ring of the window's logits.
+What a caller can observe:
+* ``_forward_one_step`` returns the reference's ``(1, Q, 1, W)`` -- every column of the rolled window under the ELU head,
+  the newest last (faster_wavenet.py:105-113) -- from a device-side ring of the window's logits (``keep_window``, on by
+  default since round 6).  The reference's caller reads ``[0, :, 0, -1]`` only (train_audio/generate.py:38);
+  ``full_window=False`` (or ``keep_window = False`` before the prefill) returns just that newest column as
+  ``(1, Q, 1, 1)`` and skips the per-call window concatenation + W-row softmax.  ``generate()`` never builds the window.
 * only the newest token of ``x_batch_data`` is read (the reference also reads nothing else of it:
   wavenet.py:286), and an integer token may be passed instead of the one-hot window.
 """
@@ -47,7 +48,7 @@ class FasterWaveNet(WaveNet):
         self._batch_stale = []
         self.prev_causal_outputs = None
         self.prev_residual_outputs = None
-        self.keep_window = False           # keep the logits of the whole window on the device (full_window=True needs it)
+        self.keep_window = True            # keep the logits of the whole window on the device: _forward_one_step's reference shape
         self._hist = None                  # (W, Q) ring of ELU-head logits, oldest column at _hist_pos
         self._hist_pos = 0
         super().__init__(params, compat_zero_prefix=compat_zero_prefix, seed=seed, storage=storage)
@@ -140,11 +141,14 @@ class FasterWaveNet(WaveNet):
         self.prev_residual_outputs = _RingState("residual")
         return self.to_numpy(out) if as_numpy else out
 
-    def _forward_one_step(self, x_batch_data, apply_softmax=True, as_numpy=False, full_window=False):
+    def _forward_one_step(self, x_batch_data, apply_softmax=True, as_numpy=False, full_window=None):
         """One incremental step (faster_wavenet.py:50-63); falls back to the full forward when the
-        state was reset by ``prev_causal_outputs = None``.  ``full_window=True`` (needs ``keep_window = True`` set before
-        the prefill) returns the reference's ``(1, Q, 1, W)``: every column of the rolled window under the ELU head, the
-        newest last -- a compatibility face (one concatenation + one softmax over W rows per call), not the fast path."""
+        state was reset by ``prev_causal_outputs = None``.  Returns the reference's ``(1, Q, 1, W)`` -- every column of the
+        rolled window under the ELU head, the newest last (faster_wavenet.py:105-113; one concatenation + one softmax over W
+        rows per call) -- unless ``full_window=False`` (or ``keep_window`` was False at the prefill): then the newest
+        column only, ``(1, Q, 1, 1)``; ``[0, :, 0, -1]`` reads the same values from either."""
+        if full_window is None:
+            full_window = bool(self.keep_window)
         if full_window and not self.keep_window:
             raise Exception("full_window=True needs keep_window = True before the first (prefill) call")
         if getattr(self, "prev_causal_outputs", None) is None:
@@ -162,8 +166,9 @@ class FasterWaveNet(WaveNet):
         prob = torch.empty((1, 1, Q), device=self.device, dtype=torch.float32)
         if self._hist is None:
             if full_window:
-                raise Exception("full_window=True: the window history was dropped (generate() advanced the decoder on the "
-                                "device); set prev_causal_outputs = None and prefill again")
+                raise Exception("the window history was dropped (generate() advanced the decoder on the device, or keep_window "
+                                "was False at the prefill): pass full_window=False for the newest column, or set "
+                                "prev_causal_outputs = None and prefill again")
             check(lib.wn_decoder_step(self._decoder(), token, ptr(prob), 1 if apply_softmax else 0, stream_ptr()),
                   "wn_decoder_step")
             out = _as_view(prob)
@@ -205,7 +210,11 @@ class FasterWaveNet(WaveNet):
             raise Exception("need one uniform per emitted sample")
         lib = _lib.lib()
         self.prev_causal_outputs = None
-        p0 = self.forward_one_step(tok, apply_softmax=True)          # (1,Q,1,W)
+        keep, self.keep_window = self.keep_window, False             # the run below never builds the window (and drops it)
+        try:
+            p0 = self.forward_one_step(tok, apply_softmax=True)      # (1,Q,1,W)
+        finally:
+            self.keep_window = keep
         first_prob = p0[0, :, 0, -1].contiguous().view(1, Q)
         out = torch.empty((n_samples,), device=self.device, dtype=torch.int32)
         check(lib.wn_sample_categorical(ptr(first_prob), ptr(u), ptr(out), 1, Q, stream_ptr()),
