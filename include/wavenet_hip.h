@@ -41,7 +41,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define WN_ABI_VERSION 4
+#define WN_ABI_VERSION 5
 #define WN_OK      0
 #define WN_EARG   -1
 #define WN_ESHAPE -2
@@ -101,7 +101,11 @@ enum { WN_GEMM_FP32 = 0, WN_GEMM_BF16X3 = 1, WN_GEMM_BF16 = 2, WN_GEMM_FP16X2 = 
                                             (k16_bwd_multi: the same dataflow words, k16_gate_bwd / k16_dx tile code unchanged)
                                             instead of two launches per layer.  Same results, bit for bit.  OPT-IN: measured
                                             equal to the per-layer launches within 1 %, and it needs every
-                                            workgroup resident -- the library falls back by itself when they would not be */
+                                            workgroup resident -- the library falls back by itself when the static occupancy
+                                            query says they would not be.  CUs held by OTHER work at launch time are not
+                                            covered by that query: a dataflow wait that then gives up (2^18 polls) poisons
+                                            the layer's dWp with a NaN, so the gradient norm is not finite and wn_adam_step
+                                            skips the step (WaveNet.last_update_applied() == False) -- never a silent update */
 typedef struct WnExec {
     int precision;
     unsigned flags;
@@ -238,10 +242,11 @@ int wn_softmax_xent(const float* logits, const int32_t* target, float* loss, flo
  * wavenet.py:597-617): logits = W act(x) + b are formed and consumed on the chip -- they never reach memory --, dlogits (N, Cout)
  * receives d loss / d logits for an upstream gradient of 1 (what wn_softmax_xent writes), loss as for wn_softmax_xent
  * (WN_XENT_LOSS_WORDS floats, n_norm with the same meaning).  Covered: WN_GEMM_FP16X2, Cout = 256, Cin a multiple of 32
- * (wn_head_xent_supported; WN_ESHAPE otherwise: run wn_pointwise_fwd + wn_softmax_xent).  The input has no known range: every
+ * and N <= 253,952 rows -- one 128-row workgroup per partial-sum slot of `loss` -- (wn_head_xent_supported, which takes N since
+ * ABI 5; WN_ESHAPE otherwise: run wn_pointwise_fwd + wn_softmax_xent, which has no row limit).  The input has no known range: every
  * 32-channel chunk of a wave's 32 columns is scaled by the power of two that fits the wave's own maximum before the fp16 split
  * (error <= 2^-21 per product as elsewhere under FP16X2).  Backward: wn_pointwise_bwd(x, W, dlogits, ...) as after the two calls. */
-int wn_head_xent_supported(int Cin, int Cout, const WnExec* ex);
+int wn_head_xent_supported(int64_t N, int Cin, int Cout, const WnExec* ex);
 int wn_head_xent(const float* x, const float* W, const float* bias, const int32_t* target, float* loss, float* dlogits,
                  int N, int Cin, int Cout, int act, int64_t n_norm, const WnExec* ex, void* stream);
 

@@ -435,3 +435,45 @@ def test_batched_decode_rejects_bad_arguments_without_touching_the_device():
     assert rc == -2 and "ONE_WORKGROUP" in msg, (rc, msg)
     torch.cuda.synchronize()
     assert int(out.abs().sum()) == 0                                    # nothing ran
+
+
+def test_generate_batch_falls_back_to_single_runs_where_the_batched_launch_does_not_reach():
+    """generate_batch decides BEFORE any work whether wn_decoder_run_batch covers the request and otherwise
+    runs generate() per utterance -- n_samples == 2 (the launch needs two steps or more), a model the specialised decoder
+    does not take (16 channels), WN_DECODER_ONE_WORKGROUP -- instead of raising after the prefill; and through the C ABI a
+    batch whose handles were packed from DIFFERENT weights is refused when same_weights = 1 (it would decode every utterance
+    with handle 0's weights)."""
+    import ctypes as C
+    from wavenet_amd import _lib
+    lib = _lib.lib()
+    rs = np.random.RandomState(2)
+    net = FasterWaveNet(Params(R.make_params(**CFG2)), seed=1234)
+    net.to_gpu()
+    u = rs.random_sample((3, 2))
+    got = to_np(net.generate_batch(2, u))
+    assert got.shape == (3, 2) and len(net._batch_decs) == 0                               # no handle was created for nothing
+    for i in range(3):
+        np.testing.assert_array_equal(got[i], to_np(net.generate(2, u[i])))
+    net.exec_flags = _lib.WN_DECODER_ONE_WORKGROUP
+    u = rs.random_sample((2, 40))
+    got = to_np(net.generate_batch(40, u))
+    np.testing.assert_array_equal(got[1], to_np(net.generate(40, u[1])))
+    p, w, small = build(dict(quantization_steps=256, causal_conv_channels=[16], residual_conv_channels=[16] * 4,
+                             residual_num_blocks=2, softmax_conv_channels=[32, 256]), cls=FasterWaveNet)
+    got = to_np(small.generate_batch(20, u[:, :20]))
+    for i in range(2):
+        np.testing.assert_array_equal(got[i], R.generate(p, w, 20, u[i, :20], fast=True))
+    # same_weights = 1 with handles of two different models
+    a = FasterWaveNet(Params(R.make_params(**CFG2)), seed=1)
+    b = FasterWaveNet(Params(R.make_params(**CFG2)), seed=2)
+    a.to_gpu(); b.to_gpu()
+    hs = (C.c_void_p * 2)(a._decoder().value, b._decoder().value)
+    ud = torch.zeros((2, 8), device="cuda", dtype=torch.float64) + 0.5
+    out = torch.zeros((2, 8), device="cuda", dtype=torch.int32)
+    firsts = (C.c_int32 * 2)(127, 127)
+    ups = (C.c_void_p * 2)(ud[0].data_ptr(), ud[1].data_ptr())
+    ops = (C.c_void_p * 2)(out[0].data_ptr(), out[1].data_ptr())
+    rc = lib.wn_decoder_run_batch(hs, 2, firsts, ups, 8, ops, None, 1, None)
+    assert rc == -1 and "other weights" in lib.wn_last_error().decode()
+    assert lib.wn_decoder_run_batch(hs, 2, firsts, ups, 8, ops, None, 0, None) == 0           # own weights each: fine
+    torch.cuda.synchronize()

@@ -1690,8 +1690,9 @@ def test_head_and_loss_in_one_launch_against_the_oracle_and_the_two_calls(N, Cin
         tgt[rs.rand(N) < 0.3] = -1
     a = {"relu": 1, "elu": 2, "none": 0}[act]
     lib = _lib.lib()
-    assert lib.wn_head_xent_supported(Cin, Q, EX("fp16x2")) == 1
-    assert lib.wn_head_xent_supported(Cin, Q, EX("bf16x3")) == 0 and lib.wn_head_xent_supported(Cin, 128, EX("fp16x2")) == 0
+    assert lib.wn_head_xent_supported(N, Cin, Q, EX("fp16x2")) == 1
+    assert lib.wn_head_xent_supported(N, Cin, Q, EX("bf16x3")) == 0 and lib.wn_head_xent_supported(N, Cin, 128, EX("fp16x2")) == 0
+    assert lib.wn_head_xent_supported(253952, Cin, Q, EX("fp16x2")) == 1 and lib.wn_head_xent_supported(253953, Cin, Q, EX("fp16x2")) == 0
     xd, Wd, bd, td = dev(x), dev(W), dev(b), dev(tgt)
     loss = torch.zeros((_lib.XENT_LOSS_WORDS,), device="cuda")
     dlog = torch.full((N, Q), 7.0, device="cuda")
@@ -1764,3 +1765,36 @@ def test_fused_head_loss_step_equals_the_two_node_step():
         scale = max(float(np.abs(b).max()), 1e-12)
         assert float(np.abs(a - b).max()) <= 1e-5 * scale, (ln.name, kind, float(np.abs(a - b).max()), scale)
     assert np.abs(grads[True][1]).max() > 0
+
+
+def test_head_cross_entropy_beyond_the_fused_launchs_row_limit_takes_the_two_calls():
+    """ADVICE r5 (medium): wn_head_xent holds one 128-row workgroup per partial-sum slot, so it covers N <= 253,952 rows;
+    16 clips x 16,000 columns = 256,000 rows per GPU is a plausible batch.  wn_head_xent_supported takes N (ABI 5) and
+    WaveNet.head_cross_entropy runs wn_pointwise_fwd + wn_softmax_xent there (no row limit) instead of raising: loss and
+    d loss / d skip against float64 numpy at N = 254,000, and the same call one row below the limit stays fused."""
+    over = dict(quantization_steps=256, causal_conv_channels=[32], residual_conv_channels=[32] * 2, residual_num_blocks=1,
+                softmax_conv_channels=[32, 256])
+    p, w, net = build(over, bias_scale=0.2)
+    rs = np.random.RandomState(9)
+    for N, fused in ((254000, False), (253952, True)):
+        s = torch.as_tensor(rs.standard_normal((1, 32, 1, N)).astype(np.float32)).cuda().requires_grad_(True)
+        lab = rs.randint(0, 256, (1, N)).astype(np.int32)
+        with _lib.profile() as prof:
+            loss = net.head_cross_entropy(s, lab)
+            net.zero_grads()
+            loss.backward()
+            torch.cuda.synchronize()
+        names = set(prof.result())
+        assert ("wn_head_xent" in names) == fused and ("wn_pointwise_fwd" in names) == (not fused), sorted(names)
+        W = w["softmax_0/W"][:, :, 0, 0].astype(np.float64)
+        b = w["softmax_0/b"].astype(np.float64)
+        h = np.maximum(to_np(s)[0, :, 0, :].astype(np.float64), 0.0)                      # ReLU before the conv (wavenet.py:588)
+        lg = W @ h + b[:, None]
+        lg -= lg.max(axis=0, keepdims=True)
+        lse = np.log(np.exp(lg).sum(axis=0))
+        want = float((lse - lg[lab[0], np.arange(N)]).mean())
+        assert abs(float(loss.detach()) - want) < 1e-5
+        sm = np.exp(lg - lse)
+        sm[lab[0], np.arange(N)] -= 1.0
+        dh = (W.T @ sm) / N * (to_np(s)[0, :, 0, :] > 0)
+        np.testing.assert_allclose(to_np(s.grad)[0, :, 0, :], dh, atol=2e-9 + 1e-4 * np.abs(dh).max())

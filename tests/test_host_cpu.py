@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = {ln.split()[-1] for ln in nm.splitlines() if ln.strip()}
     assert exported == declared, sorted(exported ^ declared)
-    assert _lib.lib().wn_abi_version() == 4 == int(re.search(r"#define WN_ABI_VERSION (\d+)", hdr).group(1))
+    assert _lib.lib().wn_abi_version() == 5 == int(re.search(r"#define WN_ABI_VERSION (\d+)", hdr).group(1))
     assert not hasattr(lib, "wn_set_gemm_precision")          # ABI v2: no process-wide arithmetic mode
     # ABI v3: no switch read from the process environment inside the library (they are WnExec.flags / fields now)
     csrc = os.path.join(ROOT, "wavenet_amd", "csrc")
@@ -302,3 +302,30 @@ def test_get_optimizer_names_and_the_setters():
             assert opt.alpha == 0.5 and opt.beta1 == 0.3
     with pytest.raises(Exception):
         WaveNet(Params(dict(base, optimizer="lion")))
+
+
+def test_load_after_save_reads_the_npz_without_an_hdf5_library(tmp_path, capsys, monkeypatch):
+    """save() writes the HDF5 copy FIRST and the .npz last, so after every save() the .npz is the newer file:
+    load() takes it, says nothing about "both", and works on a box with no HDF5 library; a newer HDF5 file that cannot be read
+    for want of a library falls back to the .npz next to it with a warning."""
+    _need_hdf5()
+    from wavenet_amd import Params, WaveNet
+    a = WaveNet(Params(_TINY), seed=8)
+    a.save(str(tmp_path))
+    assert os.path.getmtime(str(tmp_path / "wavenet.model.npz")) >= os.path.getmtime(str(tmp_path / "wavenet.model"))
+    capsys.readouterr()
+
+    def no_lib(self, filename):
+        raise ImportError("no HDF5 library (test)")
+    monkeypatch.setattr(WaveNet, "load_hdf5", no_lib)
+    b = WaveNet(Params(_TINY), seed=9)
+    b.load(str(tmp_path))
+    out = capsys.readouterr().out
+    assert "both" not in out and "wavenet.model.npz" in out
+    assert all(np.array_equal(b.state_dict()[k], v) for k, v in a.state_dict().items())
+    t0 = os.path.getmtime(str(tmp_path / "wavenet.model.npz"))
+    os.utime(str(tmp_path / "wavenet.model"), (t0 + 10,) * 2)
+    c = WaveNet(Params(_TINY), seed=10)
+    c.load(str(tmp_path))
+    assert "OLDER" in capsys.readouterr().out
+    assert all(np.array_equal(c.state_dict()[k], v) for k, v in a.state_dict().items())

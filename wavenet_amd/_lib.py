@@ -10,7 +10,7 @@ from typing import Dict, Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("WAVENET_HIP_LIB") or os.path.join(_HERE, "libwavenet_hip.so")   # (override: same-box A/B of two builds)
-ABI_VERSION = 4
+ABI_VERSION = 5
 XENT_LOSS_WORDS = 2056      # WN_XENT_LOSS_WORDS: loss[0] + per-workgroup sums of wn_softmax_xent
 SQNORM_WORDS = 1040          # WN_SQNORM_WORDS: out[0] + per-workgroup partial sums of wn_sqnorm
 
@@ -77,7 +77,7 @@ _SIGS = {
     "wn_exec_workspace_bytes": (C.c_size_t, [C.POINTER(WnStackDesc), _i, _i, _i, _ip, _i, _i, _i]),
     "wn_softmax_fwd": (_i, [_p, _p, _i, _i, _p]),
     "wn_softmax_xent": (_i, [_p, _p, _p, _p, _i, _i, _i64, _p]),
-    "wn_head_xent_supported": (_i, [_i, _i, C.POINTER(WnExec)]),
+    "wn_head_xent_supported": (_i, [C.c_int64, _i, _i, C.POINTER(WnExec)]),
     "wn_head_xent": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i64, C.POINTER(WnExec), _p]),
     "wn_nchw_to_btc": (_i, [_p, _p, _i, _i, _i, _p]),
     "wn_btc_to_nchw": (_i, [_p, _p, _i, _i, _i, _p]),
@@ -169,6 +169,9 @@ class profile(object):
                 res[name] = (int(calls), float(tot), float(mn), float(mx))
             self._res = res
         return self._res
+
+
+WN_OK, WN_EARG, WN_ESHAPE, WN_EHIP, WN_ETIMEOUT = 0, -1, -2, -3, -4      # include/wavenet_hip.h
 
 
 def check(rc: int, what: str = "") -> None:

@@ -280,9 +280,9 @@ int wn_softmax_xent(const float* logits, const int32_t* target, float* loss, flo
     return generic_softmax_xent(logits, target, loss, dlogits, N, Q, n_norm, as_stream(stream));
 }
 
-int wn_head_xent_supported(int Cin, int Cout, const WnExec* ex) {
+int wn_head_xent_supported(int64_t N, int Cin, int Cout, const WnExec* ex) {
     wn::ExecScope exec__(ex);
-    return (!force_generic() && gemm_mode() == WN_GEMM_FP16X2 && Cout == 256 && Cin > 0 && Cin % 32 == 0 && mfma_pointwise_supported(Cin, Cout)) ? 1 : 0;
+    return (N > 0 && (N + 127) / 128 <= wn::kXentBlocks && !force_generic() && gemm_mode() == WN_GEMM_FP16X2 && Cout == 256 && Cin > 0 && Cin % 32 == 0 && mfma_pointwise_supported(Cin, Cout)) ? 1 : 0;
 }
 
 int wn_head_xent(const float* x, const float* W, const float* bias, const int32_t* target, float* loss, float* dlogits,
@@ -292,8 +292,8 @@ int wn_head_xent(const float* x, const float* W, const float* bias, const int32_
     wn::ProfScope prof__("wn_head_xent", stream);
     NN(x); NN(W); NN(target); NN(loss); NN(dlogits); POS(N); POS(Cin); POS(Cout);
     WN_CHECK_ARG(act >= WN_ACT_NONE && act <= WN_ACT_ELU, "wn_head_xent: bad act %d", act);
-    WN_CHECK_SHAPE(wn_head_xent_supported(Cin, Cout, ex), "wn_head_xent: needs WN_GEMM_FP16X2, 256 outputs and a multiple of 32 "
-                                                          "inputs (run wn_pointwise_fwd + wn_softmax_xent instead)");
+    WN_CHECK_SHAPE(wn_head_xent_supported(N, Cin, Cout, ex), "wn_head_xent: needs WN_GEMM_FP16X2, 256 outputs, a multiple of 32 "
+                                                          "inputs and at most 253,952 rows (run wn_pointwise_fwd + wn_softmax_xent instead)");
     hipStream_t s = as_stream(stream);
     const long long nn = n_norm > 0 ? n_norm : (n_norm == 0 ? N : -1);
     int ncnt = 0, rc;

@@ -42,6 +42,8 @@ struct Decoder {
     int head_bias_off = -1;
     bool three_wgs = true;        // wn_decoder_run on nine workgroups (decoder_fast.hip); WN_DECODER_ONE_WORKGROUP clears it
     bool ran_multi = false;       // a nine-workgroup run has been launched (its error entry is meaningful)
+    unsigned long long src_key = 0;   // hash of the caller's weight POINTERS at the last pack: two handles packed from the same
+                                      // model carry the same key (wn_decoder_run_batch's same_weights check)
 };
 
 // the shape decoder_fast.hip is written for (BASELINE.json config 4 with the reference's default biases)
@@ -290,6 +292,17 @@ static inline long long align64(long long x) { return (x + 63) & ~63ll; }
 
 static int pack_weights(Decoder* D, const WnDecoderDesc* d, hipStream_t s) {
     const int T = 256;
+    {   // FNV-1a over every weight / bias pointer of the description, in a fixed order
+        unsigned long long h = 1469598103934665603ull;
+        auto mix = [&](const void* p) { h = (h ^ (unsigned long long)(uintptr_t)p) * 1099511628211ull; };
+        for (int i = 0; i < d->n_causal; ++i) { mix(d->causal_W[i]); mix(d->causal_b ? d->causal_b[i] : nullptr); }
+        for (int j = 0; j < (int)D->layers.size(); ++j) {
+            mix(d->Wf[j]); mix(d->Wg[j]); mix(d->Wp[j]); mix(d->Ws[j]);
+            mix(d->bf ? d->bf[j] : nullptr); mix(d->bg ? d->bg[j] : nullptr); mix(d->bp ? d->bp[j] : nullptr); mix(d->bs ? d->bs[j] : nullptr);
+        }
+        for (int i = 0; i < d->n_head; ++i) { mix(d->head_W[i]); mix(d->head_b ? d->head_b[i] : nullptr); }
+        D->src_key = h;
+    }
     for (int i = 0; i < d->n_causal; ++i) {
         const DecCausal& L = D->causal[i];
         int n = L.cout * L.cin * d->fw_causal;
@@ -544,8 +557,17 @@ int wn_decoder_run_batch(void* const* handles, int n_handles, const int32_t* fir
         for (int v = 0; v < u; ++v) WN_CHECK_ARG(handles[v] != handles[u], "wn_decoder_run_batch: handle %d given twice", u);
         WN_CHECK_SHAPE(D->fastP && D->three_wgs, "wn_decoder_run_batch: needs the specialised decoder (config 4's shape) "
                                                  "without WN_DECODER_ONE_WORKGROUP");
-        WN_CHECK_SHAPE(D->meta.nlayers == D0->meta.nlayers && D->meta.head_act == D0->meta.head_act,
-                       "wn_decoder_run_batch: the utterances' models differ");
+        WN_CHECK_SHAPE(D->meta.nlayers == D0->meta.nlayers && D->meta.head_act == D0->meta.head_act && D->meta.Q == D0->meta.Q &&
+                           D->meta.Cr == D0->meta.Cr && D->meta.Cs == D0->meta.Cs && D->meta.fw == D0->meta.fw &&
+                           D->layers.size() == D0->layers.size(),
+                       "wn_decoder_run_batch: the utterances' models differ (layers, channels, Q or head activation)");
+        for (size_t l = 0; l < D->layers.size(); ++l)
+            WN_CHECK_SHAPE(D->layers[l].d == D0->layers[l].d && D->layers[l].cd == D0->layers[l].cd,
+                           "wn_decoder_run_batch: layer %d of utterance %d has another dilation / width than utterance 0's", (int)l, u);
+        // same_weights = 1 reads ONE copy of the packed weights (handle 0's) for every utterance: only sound when every
+        // handle was packed from the same model -- the same weight pointers at its last create / update_weights
+        WN_CHECK_ARG(!same_weights || D->src_key == D0->src_key,
+                     "wn_decoder_run_batch: same_weights = 1 but utterance %d's handle was packed from other weights than utterance 0's", u);
         WN_CHECK_ARG(first_tokens[u] >= 0 && first_tokens[u] < D->meta.Q, "wn_decoder_run_batch: token outside [0,Q)");
         WN_CHECK_ARG(D->step + n < (1ll << 31), "wn_decoder_run_batch: step counter overflow");
         P[u] = D->fastP; hb[u] = D->head_bias_off >= 0 ? D->arena + D->head_bias_off : nullptr;

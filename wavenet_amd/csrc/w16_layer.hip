@@ -876,6 +876,13 @@ __device__ __forceinline__ bool dx_phase(char* lds, const DxP& P, MSync& ms, boo
     if (HAS_Z) {
         // this workgroup's partial of dWp: [cr][cd] fp32, summed over workgroups by k16_reduce_parts
         float* o = dwp_part + (long long)blockIdx.x * kDwpPart;
+        if constexpr (MULTI) {
+            // a dataflow wait that gave up means this launch's results are void (tiles were consumed before they were produced):
+            // make that LOUD, like the fp32 chain does (mfma_layer_bwd.hip, acc_to_lds) -- a NaN in this layer's dWp, so the
+            // gradient norm is not finite and wn_adam_step skips the step (ABI 4's rule) instead of applying it silently.
+            // gave_up is sticky: every layer after the wait that failed is poisoned.  (sync[0] = 1 says the same.)
+            if (ms.gave_up) wp[0][0] = __builtin_nanf("");
+        }
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll

@@ -251,8 +251,18 @@ class FasterWaveNet(WaveNet):
             raise Exception("uniforms must be (N, >= n_samples)")
         N = u_np.shape[0]
         lib = _lib.lib()
-        if N < 1 or N > lib.wn_decoder_batch_max():
-            raise Exception("1 .. %d utterances per batch" % lib.wn_decoder_batch_max())
+        if n_samples < 1:
+            raise Exception("generate_batch: n_samples must be positive")
+        # what the batched launch does not cover runs as a loop over generate() -- same tokens, one utterance at a time --
+        # decided BEFORE any work is done: n_samples == 2 (the launch runs two steps or more), more utterances than
+        # wn_decoder_batch_max(), a model the specialised decoder does not take, or WN_DECODER_ONE_WORKGROUP
+        flags = _lib.default_exec_flags() if self.exec_flags is None else int(self.exec_flags)
+        batched = (1 <= N <= lib.wn_decoder_batch_max() and n_samples != 2 and self.storage != "bf16" and
+                   not (flags & (_lib.WN_DECODER_ONE_WORKGROUP | _lib.WN_EXEC_FORCE_GENERIC)))
+        if N < 1:
+            raise Exception("generate_batch: no utterance")
+        if not batched:
+            return self._generate_batch_loop(n_samples, u_np, initial_tokens)
         if initial_tokens is None:
             initial_tokens = np.full((iw,), 127 if Q > 127 else Q // 2, dtype=np.int32)   # generate.py:21
         tok = torch.as_tensor(np.asarray(initial_tokens, dtype=np.int32).reshape(1, -1)).to(self.device)
@@ -289,16 +299,22 @@ class FasterWaveNet(WaveNet):
               "wn_sample_categorical")
         out[:, 0] = first
         if n_samples > 1:
-            if n_samples < 3:
-                raise Exception("generate_batch: at least 3 samples (the batched launch runs two steps or more)")
             firsts = (C.c_int32 * N)(*[int(v) for v in first.cpu().tolist()])
             handles = (C.c_void_p * N)(*[h.value for h in self._batch_decs[:N]])
             rest = [u[i, 1:].contiguous() for i in range(N)]
             outs = [torch.empty((n_samples - 1,), device=self.device, dtype=torch.int32) for _ in range(N)]
             same = 0 if os.environ.get("WAVENET_HIP_BATCH_OWN_WEIGHTS") == "1" else 1      # the handles ARE copies of this model's weights
-            check(lib.wn_decoder_run_batch(handles, N, firsts, ptr_array(rest), n_samples - 1, ptr_array(outs), None, same,
-                                           stream_ptr()), "wn_decoder_run_batch")
+            rc = lib.wn_decoder_run_batch(handles, N, firsts, ptr_array(rest), n_samples - 1, ptr_array(outs), None, same,
+                                          stream_ptr())
+            if rc == _lib.WN_ESHAPE:         # a shape the batched launch does not take (e.g. not config 4's): one by one
+                return self._generate_batch_loop(n_samples, u_np, initial_tokens)
+            check(rc, "wn_decoder_run_batch")
             for i in range(N):
                 check(lib.wn_decoder_status(self._batch_decs[i], stream_ptr()), "wn_decoder_status")
                 out[i, 1:] = outs[i]
         return out
+
+    def _generate_batch_loop(self, n_samples, u_np, initial_tokens):
+        """generate_batch for what ``wn_decoder_run_batch`` does not cover: ``generate()`` per utterance (row u is
+        ``generate(n_samples, uniforms[u])`` by definition)."""
+        return torch.stack([self.generate(n_samples, u_np[i], initial_tokens=initial_tokens) for i in range(u_np.shape[0])])

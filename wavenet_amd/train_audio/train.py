@@ -15,6 +15,9 @@ from . import args as _args
 from . import model as _model
 
 
+HEALTH_EVERY = 100      # updates between two reads of WaveNet.last_update_applied() (a host synchronisation each)
+
+
 def input_width_of(params) -> int:
     """train.py:36-44: receptive field of the residual stack plus one column per causal layer."""
     per_block = params.residual_conv_filter_width ** len(params.residual_conv_channels)
@@ -49,6 +52,7 @@ def train_audio(net, params, path_to_file, batch_size=16, train_width=16, repeat
     crops = _Crops(signals, iw, train_width, net.device)
     sum_loss = torch.zeros((), device=net.device, dtype=torch.float64)
     graph = None
+    skipped = 0
     name = os.path.basename(path_to_file)
     for batch_index in range(repeat):
         x, tgt = crops.draw(batch_size)
@@ -65,6 +69,19 @@ def train_audio(net, params, path_to_file, batch_size=16, train_width=16, repeat
             net.backprop(loss)
             loss = loss.detach()
         sum_loss += loss                                            # on the device: no host sync per update
+        # health check (one word read back, every HEALTH_EVERY updates and after the last one): a step whose gradient norm was
+        # not finite is SKIPPED on the device (wn_adam_step, ABI 4) -- say so instead of training on in silence.  The guard
+        # lives in the clipping hook: with gradient_clipping <= 0 there is no norm and nothing is ever skipped.
+        if (batch_index % HEALTH_EVERY == HEALTH_EVERY - 1 or batch_index == repeat - 1) and not net.last_update_applied():
+            skipped += 1
+            sys.stdout.write("\n\twarning: update {} of {} was skipped on the device (gradient norm not finite; loss {}); "
+                             "{} such checks failed so far\n".format(batch_index, name, float(loss), skipped))
+            if skipped >= 5:
+                raise Exception("the gradient norm was not finite at {} consecutive health checks: the run is doing no work "
+                                "(lower --lr, or set exec_flags |= WN_EXEC_NO_MULTI_LAYER_BWD if another process shares the "
+                                "GPU)".format(skipped))
+        elif batch_index % HEALTH_EVERY == HEALTH_EVERY - 1:
+            skipped = 0
         if batch_index % 10 == 0:
             sys.stdout.write("\r\t{} - {} width; {}/{}".format(name, signals.size, batch_index, repeat))
             sys.stdout.flush()

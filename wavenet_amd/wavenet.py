@@ -847,7 +847,11 @@ class WaveNet(object):
         (a host synchronisation): for the training loop's occasional health check, not for every step.  A caller that sees
         False after a step of the multi-layer backward can set ``exec_flags |= WN_EXEC_NO_MULTI_LAYER_BWD`` and go on --
         the only thing in the library that produces a NaN on purpose is a dataflow wait of that launch that gave up
-        (workgroups not co-resident: another process on the GPU, a CU mask)."""
+        (workgroups not co-resident: another process on the GPU, a CU mask).  Two things to know: the guard lives in the
+        clipping hook, so with ``gradient_clipping <= 0`` no norm exists and a NaN gradient reaches m and v as in Chainer; and
+        the host-side step counter ``t`` (Adam's bias correction) advances for a skipped step too -- un-advancing it would cost
+        a host synchronisation per step; the effect is a step size off by the factor sqrt(1-b2^(t+1))/sqrt(1-b2^t) ~ 1.
+        ``train_audio.train`` calls this every 100 updates and stops a run whose checks keep failing."""
         nrm = getattr(self.optimizer, "_norm", None)
         if nrm is None or not self.params.gradient_clipping or self.params.gradient_clipping <= 0:
             return True                                                  # no clipping hook, no norm: nothing is ever skipped
@@ -1015,8 +1019,9 @@ class WaveNet(object):
         if tensor_target and target_signal_data.requires_grad:
             raise Exception("target_signal_data cannot be Variable")
         lay = self.softmax_conv_layers[-1]
+        n_rows = int(x.shape[0]) * int(x.shape[-1])                 # (B, C, 1, T') -> B * T' rows of the loss
         fused = (self.storage != "bf16" and self.fuse_head_loss and
-                 _lib.lib().wn_head_xent_supported(lay.W.shape[1], lay.W.shape[0], self._exec()) == 1)
+                 _lib.lib().wn_head_xent_supported(n_rows, lay.W.shape[1], lay.W.shape[0], self._exec()) == 1)
         if not fused:
             return self.cross_entropy(self.forward_softmax_block(x, apply_softmax=False), target_signal_data)
         act = ACT[self.head_activation]
@@ -1047,15 +1052,16 @@ class WaveNet(object):
     #    HDF5 container for the weights (read and written through h5py when importable, else through the HDF5 C library:
     #    hdf5_io.py) --
     def save(self, model_dir="./"):
-        """``wavenet.model.npz`` + ``wavenet.opt.npz`` (what :meth:`load` reads first), and -- when an HDF5 library is at hand --
-        the weights once more as ``wavenet.model`` in the reference's own container, the file its ``load`` opens
-        (wavenet.py:627-633)."""
+        """When an HDF5 library is at hand, the weights as ``wavenet.model`` in the reference's own container -- the file its
+        ``load`` opens (wavenet.py:627-633) -- and THEN ``wavenet.model.npz`` + ``wavenet.opt.npz``: written last, the .npz is
+        the newer of the two weight files, so :meth:`load` takes it after every ``save`` and needs no HDF5 library for a
+        checkpoint this package wrote."""
         os.makedirs(model_dir, exist_ok=True)
-        np.savez(os.path.join(model_dir, "wavenet.model.npz"), **self.state_dict())
-        np.savez(os.path.join(model_dir, "wavenet.opt.npz"), **self.optimizer.state_dict())
         from . import hdf5_io
         if hdf5_io.available():
             self.save_hdf5(os.path.join(model_dir, "wavenet.model"))
+        np.savez(os.path.join(model_dir, "wavenet.model.npz"), **self.state_dict())
+        np.savez(os.path.join(model_dir, "wavenet.opt.npz"), **self.optimizer.state_dict())
 
     def save_hdf5(self, filename):
         """The weights in the file format and layout of the reference's ``serializers.save_hdf5(model_dir +
@@ -1089,18 +1095,27 @@ class WaveNet(object):
 
     def load(self, model_dir="./"):
         """wavenet.py:627-639.  Two weight files may sit in the directory: the reference's own HDF5 ``wavenet.model`` and this
-        package's ``wavenet.model.npz``; the NEWER one (modification time) is loaded, and it is said which when both exist --
-        a reference-written checkpoint dropped next to an older .npz must not be ignored silently."""
+        package's ``wavenet.model.npz``.  The HDF5 file is loaded when it is the only one or the NEWER one (modification time:
+        a reference-written checkpoint dropped next to an older .npz must not be ignored silently -- that case is announced);
+        :meth:`save` writes the .npz last, so a directory this package saved loads from the .npz without a word and without an
+        HDF5 library.  If the HDF5 file is newer but no HDF5 library can be found, the .npz next to it is loaded with a
+        warning instead of failing."""
         h5 = os.path.join(model_dir, "wavenet.model")
         nz = os.path.join(model_dir, "wavenet.model.npz")
         have_h5, have_nz = os.path.isfile(h5), os.path.isfile(nz)
         use_h5 = have_h5 and (not have_nz or os.path.getmtime(h5) > os.path.getmtime(nz))
-        if have_h5 and have_nz:
-            print("both %s and %s exist: loading the newer one (%s)" % (h5, nz, h5 if use_h5 else nz))
+        if use_h5 and have_nz:
+            print("both %s and %s exist: loading the newer one (%s)" % (h5, nz, h5))
         if use_h5:
             print("loading", h5, "...")
-            self.load_hdf5(h5)
-        elif have_nz:                                              # silently skipped when absent, like the reference
+            try:
+                self.load_hdf5(h5)
+            except ImportError as e:
+                if not have_nz:
+                    raise
+                print("cannot read %s (%s): loading the OLDER %s instead" % (h5, e, nz))
+                use_h5 = False
+        if not use_h5 and have_nz:                                              # silently skipped when absent, like the reference
             print("loading", nz, "...")
             with np.load(nz) as z:
                 self.load_state_dict({k: z[k] for k in z.files})
