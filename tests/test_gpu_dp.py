@@ -246,3 +246,108 @@ def test_two_rank_reduced_gradient_equals_the_oracle_on_the_global_batch(tmp_pat
     port = _free_port()
     mp.spawn(_oracle_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert os.path.exists(tmp_path / "oracle_ok"), "rank 0 did not finish the comparison"
+
+
+def _multi_gpu_worker(rank, world, port, tmp, backend="nccl", share_gpu=False):
+    """One rank per DEVICE over RCCL (`nccl`): the data-parallel step of SURVEY 8(e) as BASELINE configs[2] runs it.
+    (backend="gloo", share_gpu=True: the one-GPU rehearsal of exactly this code -- every rank on cuda:0.)"""
+    import hashlib
+    import json
+    import torch.distributed as dist
+    from oracle import wavenet_ref as R
+    from wavenet_amd import Params, TrainStepGraph, WaveNet
+    from wavenet_amd.graph import default_loss
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    device = 0 if share_gpu else rank
+    torch.cuda.set_device(device)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        assert dist.get_backend() == backend and dist.get_world_size() == world
+        p = R.make_params(**CFG2)
+        w = R.init_weights(p, 21)
+        net = WaveNet(Params(p), seed=100 + rank)            # every rank starts elsewhere: the broadcast must fix that
+        if rank == 0:
+            net.load_state_dict(w)
+        net.to_gpu()
+        net.update_laerning_rate(0.01)
+        net.optimizer.eps = 1e-3
+        dp = net.enable_data_parallel()
+        assert dp.world == world and net._arena.device.index == device
+        iw = net.input_width
+        rs = np.random.RandomState(9)
+        B, EXTRA = world, 120                                 # one clip per rank
+        x = rs.randint(0, 256, (B, iw + EXTRA)).astype(np.int32)
+        t = rs.randint(0, 256, (B, EXTRA)).astype(np.int32)
+        lo, hi = dp.shard(B)
+        dev = lambda a: torch.as_tensor(a).cuda()
+        # (1) reduced gradient == the ORACLE's gradient on the global batch
+        loss = default_loss(net, dev(x[lo:hi]), dev(t[lo:hi]))
+        net.zero_grads()
+        loss.backward()
+        mult = dp.all_reduce_grads(net._grad_arena)
+        torch.cuda.synchronize()
+        got = net._grad_arena.detach().cpu().numpy() * mult
+        ml = dp.mean_loss(float(loss.detach()))
+        worst = 0.0
+        if rank == 0:
+            torch.set_num_threads(min(16, os.cpu_count() or 1))
+            loss_ref, _, g = R.train_step_grads(p, w, x, t)
+            for ln, kind, off, n, shape in net._spans:
+                want = np.asarray(g["%s/%s" % (ln.name, kind)], np.float64).reshape(-1)
+                err = float(np.abs(got[off:off + n] - want).max())
+                scale = max(float(np.abs(want).max()), 1e-12)
+                worst = max(worst, err / scale)
+                assert err <= 1e-4 * scale + 1e-7, (ln.name, kind, err, scale)
+            assert abs(ml - loss_ref) < 1e-4, (ml, loss_ref)
+        # (2) three replayed two-graph steps (fwd+bwd graph -> ncclAllReduce -> optimiser graph): every rank's weights bit-equal
+        g2 = TrainStepGraph(net, dev(x[lo:hi]), dev(t[lo:hi]))
+        assert g2._g2 is not None
+        w0 = net._arena.detach().clone()
+        for _ in range(STEPS):
+            g2.step(dev(x[lo:hi]), dev(t[lo:hi]))
+        torch.cuda.synchronize()
+        assert float((net._arena.detach() - w0).abs().max()) > 1e-4
+        digest = hashlib.sha256(net._arena.detach().cpu().numpy().tobytes()).hexdigest()
+        # (3) the `dist` record: what RCCL saw
+        rec = [None] * world
+        dist.all_gather_object(rec, {"rank": rank, "device": torch.cuda.current_device(),
+                                     "name": torch.cuda.get_device_name(device), "weights_sha256": digest})
+        assert len({r["weights_sha256"] for r in rec}) == 1, rec                            # bit-equal weights on every rank
+        if rank == 0:
+            assert sorted(r["device"] for r in rec) == ([0] * world if share_gpu else list(range(world)))   # distinct devices
+            json.dump({"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks": rec,
+                       "grad_worst_rel_err_vs_oracle": worst}, open(os.path.join(tmp, "dist.json"), "w"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: arms itself on a multi-GPU node (SURVEY 8(e), BASELINE configs[2])")
+def test_rccl_ranks_on_distinct_gpus_reduce_to_the_oracle_gradient_and_stay_bit_equal(tmp_path):
+    """RCCL at N >= 2 the moment a node has the devices -- min(device_count, 8) ranks, ONE PER GPU, backend
+    `nccl` (RCCL over xGMI).  On BASELINE configs[1]'s 4 x 10 stack (the 614,656-float arena): (1) all-reduce(SUM) of the
+    shard gradients x 1/world equals the ORACLE's gradient on the global batch (every tensor within 1e-4 of its largest
+    entry) and the all-reduced mean loss the oracle's loss; (2) after three replayed two-graph steps (forward/backward graph
+    -> ncclAllReduce -> optimiser graph) every rank holds the same weights BIT FOR BIT although every rank was initialised
+    differently (the broadcast of weights + optimiser state); (3) the `dist` record shows the world size as RCCL saw it and
+    one distinct device per rank.  Skipped on a one-GPU box; the single-device baseline is train_audio/model.py:57-59."""
+    import json
+    import torch.multiprocessing as mp
+    world = min(torch.cuda.device_count(), 8)
+    mp.spawn(_multi_gpu_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rec = json.load(open(tmp_path / "dist.json"))
+    assert rec["backend"] == "nccl" and rec["world_size"] == world and len(rec["ranks"]) == world
+
+
+def test_the_multi_gpu_rccl_test_rehearsed_with_two_ranks_on_one_gpu(tmp_path):
+    """The worker of the self-arming test above, line for line, with the one difference a one-GPU box forces: backend gloo and
+    both ranks on cuda:0.  Keeps that test's code exercised (and correct) until a node with two devices runs it over RCCL."""
+    import json
+    import torch.multiprocessing as mp
+    mp.spawn(_multi_gpu_worker, args=(2, _free_port(), str(tmp_path), "gloo", True), nprocs=2, join=True)
+    rec = json.load(open(tmp_path / "dist.json"))
+    assert rec["backend"] == "gloo" and rec["world_size"] == 2 and rec["grad_worst_rel_err_vs_oracle"] < 1e-4
