@@ -390,6 +390,13 @@ def main():
         torch.cuda.synchronize()
         eager_dt = (time.perf_counter() - t0) / args.steps
     per_step = {k: v[1] / args.steps for k, v in prof.result().items()}  # ms of each entry point per step
+    # what ONE replayed step launches: the node counts of the same step captured once more with the hipGraph_t kept
+    graph_nodes = None
+    if graph is not None:
+        try:
+            graph_nodes = TrainStepGraph(net, x, tgt, keep_graph=True).node_counts()
+        except Exception as e:
+            graph_nodes = {"error": "%s: %s" % (type(e).__name__, e)}
     samples = world * B_PER_GPU * T
     value = samples / dt
 
@@ -418,7 +425,7 @@ def main():
                               "(bar 1e-4); `loss` is the loss after the %d optimiser steps of this run" % (spinup + args.warmup + args.steps),
         "launch": ("hipGraph replay, one graph launch per step" + (" (fwd+bwd graph, RCCL all-reduce, optimiser graph)"
                    if world > 1 or force_dist else "")) if graph is not None else "op-by-op launches from Python",
-        "eager_ms_per_step": eager_dt * 1e3,
+        "eager_ms_per_step": eager_dt * 1e3, "graph_nodes_per_step": graph_nodes,
         "entry_point_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
     }
 

@@ -81,7 +81,9 @@ def test_cfg2_topology_train_step_loss_and_every_gradient(B, extra, t1, prec):
         _ORACLE[key] = (mask, R.train_step_grads(p, w, idx, tgt, first_relu_mask=mask, keep=keep), keep["skip"])
     _, (loss_ref, logits_ref, g), skip_ref = _ORACLE[key]
     np.testing.assert_allclose(to_np(s), skip_ref, atol=1e-4)
-    assert int(((skip_ref > 0) != (mask > 0)).sum()) <= 8
+    # (a skip value lands within rounding distance, ~1e-6, of 0 with probability ~1e-6: at most 8 flips per 6.3 M elements --
+    #  the bound of rounds 4-5 at B = 2, the same DENSITY at B = 8's 25.2 M elements)
+    assert int(((skip_ref > 0) != (mask > 0)).sum()) <= 8 * int(np.ceil(mask.size / 6.3e6))
     logits = net.forward_softmax_block(s, apply_softmax=False)
     loss = net.cross_entropy(logits, t)
     net.zero_grads()
@@ -265,8 +267,9 @@ def test_bench_two_ranks_on_one_gpu_runs_the_n_gt_1_branch():
     assert out["config"]["global_batch"] == 16 and out["scaling"] == "weak"
 
 
+@pytest.mark.parametrize("prec", ["fp16x2", "bf16x3", "fp32"])
 @pytest.mark.parametrize("B,extra,window_only", [(2, 200, False), (1, 333, True), (3, 1333, False), (2, 12290, False), (8, 12290, False)])
-def test_multi_layer_backward_launch_equals_the_per_layer_launches(B, extra, window_only):
+def test_multi_layer_backward_launch_equals_the_per_layer_launches(B, extra, window_only, prec):
     """k_layer_bwd_chain_multi: every layer below the top one of the 4 x 10 stack in ONE launch of co-resident workgroups,
     synchronised per tile through dataflow words (no grid barrier), the deal of tiles to waves rotated from layer to layer.
     Same tile code and the same per-tile arithmetic as the per-layer launches (WN_EXEC_NO_MULTI_LAYER_BWD); what differs is
@@ -275,9 +278,11 @@ def test_multi_layer_backward_launch_equals_the_per_layer_launches(B, extra, win
     and is O(1e-2) -- and the multi-layer launch is BIT-reproducible: three repetitions agree exactly (its schedule is
     static; only the waiting is dynamic).  Small and ragged windows (idle waves, live ranges that differ per layer, a
     batch that is no multiple of 8: the non-XCD deal), the bench's window at B = 2, and the bench's full batch (256
-    workgroups, one per CU)."""
+    workgroups, one per CU).  In every arithmetic mode (round 6: the exact-fp32-MFMA form of the launch,
+    k_layer_bwd_chain_multi<true, false>, serves bf16x3 and fp32)."""
     from wavenet_amd import _lib
     net = WaveNet(Params(R.make_params(**CFG2)), seed=1234)
+    net.gemm_precision = prec
     net.to_gpu()
     iw = net.input_width
     T = iw + extra
@@ -299,8 +304,15 @@ def test_multi_layer_backward_launch_equals_the_per_layer_launches(B, extra, win
             del c, s, loss
     ref = got[("per-layer", 0)]
     assert np.isfinite(ref).all() and np.abs(ref).max() > 0
+    # (exact-fp32 mode: the skip / head weight gradients come from k_wgrad_mfma, which adds its time slabs with float atomics --
+    # those tensors are reproducible to summation order only, in either launch form; everything the layer backward itself
+    # produces -- wf, wg, projection_block, and the causal table through dx -- must repeat exactly in every mode)
     for rep in (1, 2):
-        np.testing.assert_array_equal(got[("multi", 0)], got[("multi", rep)])
+        if prec != "fp32":
+            np.testing.assert_array_equal(got[("multi", 0)], got[("multi", rep)])
+        for ln, kind, off, n, shape in net._spans:
+            if not ("projection_softmax" in ln.name or ln.name.startswith("softmax")):
+                np.testing.assert_array_equal(got[("multi", 0)][off:off + n], got[("multi", rep)][off:off + n], err_msg=ln.name)
     m = got[("multi", 0)]
     for ln, kind, off, n, shape in net._spans:
         a, b = ref[off:off + n], m[off:off + n]

@@ -1462,7 +1462,8 @@ int mfma_layer_bwd_chain(const float* x, const float* f, const float* g, const f
 }
 
 // Entries 0 .. n-1 (stack layers layer[0] > layer[1] > ...) in ONE launch of co-resident workgroups that follow per-tile
-// dataflow words -- no grid barrier -- (k_layer_bwd_chain_multi).  Only the fp16 x 2 form reading z and sigmoid (FROM_Z), every layer with V, U
+// dataflow words -- no grid barrier -- (k_layer_bwd_chain_multi).  The form reading z and sigmoid (FROM_Z), in the arithmetic of the call
+// (fp16 x 2 split products, or exact fp32 MFMA under WN_GEMM_BF16X3 / WN_GEMM_FP32: round 6), every layer with V, U
 // and dz_skip inputs.  `sync` points at mfma_chain_multi_sync_words(B, T) words of device memory (zeroed here).  *nwg receives the number of partial tiles
 // every layer writes (= the grid).
 __global__ void k_chain_zero_sync(unsigned* sync, int n) {
@@ -1476,7 +1477,7 @@ int mfma_layer_bwd_chain_multi(int n, const int* layer, const float* const* Wf, 
                                const float* dz, float* const* V, float* const* U, float* part, size_t part_stride,
                                unsigned* sync, int B, int T, int dz_t0, int* nwg, hipStream_t s) {
     WN_CHECK_ARG(n >= 1 && n <= kChainMaxL, "mfma_layer_bwd_chain_multi: 1..%d layers", kChainMaxL);
-    WN_CHECK_ARG(gemm_mode() == WN_GEMM_FP16X2, "mfma_layer_bwd_chain_multi: fp16x2 only");
+    const bool h2w = gemm_mode() == WN_GEMM_FP16X2;           // else: every product on exact fp32 MFMA (bf16x3 / fp32 modes)
     const int tiles_all = (T + 31) / 32;
     ChainArgs a{};
     int blocks = 1;
@@ -1500,18 +1501,21 @@ int mfma_layer_bwd_chain_multi(int n, const int* layer, const float* const* Wf, 
     {
         int dev = 0;
         WN_HIP(hipGetDevice(&dev));
-        static int capacity[64];                        // per device; 0 = not asked yet (a benign race: every thread writes the same value)
+        static int capacity[2][64];                     // per arithmetic and device; 0 = not asked yet (a benign race: every thread writes the same value)
         if (dev < 0 || dev >= 64) { wn::set_error("mfma_layer_bwd_chain_multi: device index %d", dev); return WN_ESHAPE; }
-        if (!capacity[dev]) {
+        int& cap = capacity[h2w ? 1 : 0][dev];
+        if (!cap) {
             int n_cu = 0, per_cu = 0;
             WN_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_layer_bwd_chain_multi<true, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kCLdsBytes));
-            WN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_layer_bwd_chain_multi<true, true>, 256, kCLdsBytes));
-            capacity[dev] = n_cu * per_cu > 0 ? n_cu * per_cu : -1;
+            const void* fn = h2w ? reinterpret_cast<const void*>(k_layer_bwd_chain_multi<true, true>)
+                                 : reinterpret_cast<const void*>(k_layer_bwd_chain_multi<true, false>);
+            WN_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kCLdsBytes));
+            if (h2w) WN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_layer_bwd_chain_multi<true, true>, 256, kCLdsBytes));
+            else WN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_layer_bwd_chain_multi<true, false>, 256, kCLdsBytes));
+            cap = n_cu * per_cu > 0 ? n_cu * per_cu : -1;
         }
-        if (blocks > capacity[dev]) {
-            wn::set_error("mfma_layer_bwd_chain_multi: %d workgroups, %d resident on device %d", blocks, capacity[dev], dev);
+        if (blocks > cap) {
+            wn::set_error("mfma_layer_bwd_chain_multi: %d workgroups, %d resident on device %d", blocks, cap, dev);
             return WN_ESHAPE;
         }
     }
@@ -1537,7 +1541,8 @@ int mfma_layer_bwd_chain_multi(int n, const int* layer, const float* const* Wf, 
     const int nsync = (int)mfma_chain_multi_sync_words(B, T);
     hipLaunchKernelGGL(k_chain_zero_sync, dim3(cdiv(nsync, 256)), dim3(256), 0, s, sync, nsync);
     WN_LAUNCH_CHECK();
-    hipLaunchKernelGGL((k_layer_bwd_chain_multi<true, true>), dim3(blocks), dim3(256), kCLdsBytes, s, a);
+    if (h2w) hipLaunchKernelGGL((k_layer_bwd_chain_multi<true, true>), dim3(blocks), dim3(256), kCLdsBytes, s, a);
+    else hipLaunchKernelGGL((k_layer_bwd_chain_multi<true, false>), dim3(blocks), dim3(256), kCLdsBytes, s, a);
     WN_LAUNCH_CHECK();
     return WN_OK;
 }

@@ -245,7 +245,7 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
         // one) runs in ONE launch of co-resident workgroups following per-tile dataflow words (k_layer_bwd_chain_multi: no grid
         // barrier); the per-layer loop below
         // then only collects their parameters
-        const bool multi = gemm_mode() == WN_GEMM_FP16X2 && f == nullptr && dskip && d->Cs % 32 == 0 && L >= 3 &&
+        const bool multi = gemm_mode() != WN_GEMM_BF16 && f == nullptr && dskip && d->Cs % 32 == 0 && L >= 3 &&
                            L - 1 <= mfma_chain_multi_max_layers() && !exec_flag(WN_EXEC_NO_MULTI_LAYER_BWD);
         std::vector<int> m_layer, m_d, m_Z, m_live, m_vu_t0, m_dU;
         std::vector<const float*> m_Wf, m_Wg, m_Wp;

@@ -31,7 +31,9 @@ class TrainStepGraph(object):
     """``g = TrainStepGraph(net, x, tgt); loss = g.step(x, tgt)`` -- same result as
     ``net.backprop(default_loss(net, x, tgt))`` for batches of the captured shape."""
 
-    def __init__(self, net, x, tgt, loss_fn=default_loss, warmup: int = 2):
+    def __init__(self, net, x, tgt, loss_fn=default_loss, warmup: int = 2, keep_graph: bool = False):
+        """``keep_graph``: keep the captured hipGraph_t next to the executable graph so that :meth:`node_counts` can walk it
+        (measurement aid: bench.py counts the kernel nodes of the step it times)."""
         if not (net.gpu_enabled and x.is_cuda and tgt.is_cuda):
             raise _lib.WaveNetHipError("TrainStepGraph needs the network and the batch on a HIP device")
         self.net, self.loss_fn = net, loss_fn
@@ -46,7 +48,8 @@ class TrainStepGraph(object):
         # training state back: the warm-up steps are not training steps
         keep = (net._arena.clone(), opt.m.clone(), opt.v.clone(), opt.t)
         self._stream = torch.cuda.Stream(device=x.device)
-        self._g1 = torch.cuda.CUDAGraph()
+        self._keep_graph = bool(keep_graph)
+        self._g1 = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()
         self._g2 = None
         try:
             self._stream.wait_stream(torch.cuda.current_stream())
@@ -67,7 +70,7 @@ class TrainStepGraph(object):
                 if not dp:
                     self._opt()
             if dp:
-                self._g2 = torch.cuda.CUDAGraph()
+                self._g2 = torch.cuda.CUDAGraph(keep_graph=True) if keep_graph else torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self._g2, stream=self._stream, pool=self._g1.pool(),
                                       capture_error_mode="thread_local"):
                     self._opt()
@@ -122,3 +125,29 @@ class TrainStepGraph(object):
             self._g2.replay()
         net._weights_changed()
         return self.loss
+
+    def node_counts(self):
+        """{"kernel": n, "memcpy": n, "memset": n, "other": n, "total": n} over the captured graph(s) -- what ONE replayed step
+        launches (hipGraphGetNodes / hipGraphNodeGetType on the hipGraph_t torch kept: needs ``keep_graph=True``)."""
+        import ctypes as C
+        if not self._keep_graph:
+            raise _lib.WaveNetHipError("node_counts() needs TrainStepGraph(..., keep_graph=True)")
+        hip = C.CDLL("libamdhip64.so")
+        out = {"kernel": 0, "memcpy": 0, "memset": 0, "other": 0, "total": 0}
+        for g in (self._g1, self._g2):
+            if g is None:
+                continue
+            graph = C.c_void_p(g.raw_cuda_graph())
+            n = C.c_size_t(0)
+            if hip.hipGraphGetNodes(graph, None, C.byref(n)) != 0:
+                raise _lib.WaveNetHipError("hipGraphGetNodes failed")
+            nodes = (C.c_void_p * max(1, n.value))()
+            if hip.hipGraphGetNodes(graph, nodes, C.byref(n)) != 0:
+                raise _lib.WaveNetHipError("hipGraphGetNodes failed")
+            for i in range(n.value):
+                t = C.c_int(-1)
+                hip.hipGraphNodeGetType(C.c_void_p(nodes[i]), C.byref(t))
+                # hipGraphNodeType: 0 kernel, 1 memcpy, 2 memset, 3 host, 4 graph, 5 empty, ...
+                out[{0: "kernel", 1: "memcpy", 2: "memset"}.get(t.value, "other")] += 1
+                out["total"] += 1
+        return out
