@@ -82,6 +82,7 @@ const char* wn_last_error(void);
  * fwd_t1_min_blocks: launch size (workgroups of four 32-column tiles) from which the fused 32-channel layer forward takes its
  * one-tile-per-wave form; 0 = the library's default (512: every CU gets two to four workgroups), n > 0 = n (1 = always:
  * parity tests of that kernel at small sizes), < 0 = never.
+ * plan (ABI 5): a step plan or NULL ("step plan" at the end of this header).
  * ex == NULL means { WN_GEMM_BF16X3, 0, NULL, 0, 0 }: fine for calls that need no scratch, WN_EARG (with the byte count)
  * otherwise. */
 enum { WN_GEMM_FP32 = 0, WN_GEMM_BF16X3 = 1, WN_GEMM_BF16 = 2, WN_GEMM_FP16X2 = 3 };
@@ -113,6 +114,7 @@ typedef struct WnExec {
     size_t ws_bytes;
     int fwd_t1_min_blocks;
     int reserved;                     /* 0 */
+    void* plan;                       /* ABI 5: a step plan (wn_plan_create) or NULL -- see "step plan" below */
 } WnExec;
 /* 1 if the fused MFMA kernels cover this residual-layer shape (a pure shape query; a call with WN_EXEC_FORCE_GENERIC
  * runs the generic kernels whatever this says), 0 if the generic / wide paths run */
@@ -426,6 +428,32 @@ size_t wn16_pointwise_bwd_workspace_bytes(int64_t N, int Cout);
 int wn16_pointwise_bwd(const uint16_t* x, const uint16_t* WbT, const uint16_t* dout, const float* dout_f32,
                        uint16_t* dout_scratch, uint16_t* dx, float* dW, float* dbias, int64_t N, int Cin, int Cout,
                        int act, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- step plan (ABI 5): the weight-only preparation of a training step in two launches -------------------------------
+ * Between the optimiser step and the next one the weights do not change, but every entry point that holds a channel GEMM
+ * prepares its operand images per call: zero a range word, measure max |W|, split -- three launch-floor kernels per GEMM --
+ * and the stack packs its fp16 x 2 layer images, zeroes the multi-layer backward's dataflow words, measures max |dskip| ...:
+ * ~16 of the 63 kernels of BASELINE config 2's step, ~0.1 ms of its 2.8.  A plan hoists them (wavenet.py:515-519 is the step):
+ *   wn_plan_create(&plan, dev_mem, bytes)     caller-owned device memory (256-byte aligned; 16 MB covers config 2), no hipMalloc
+ *   wn_plan_record(plan)                      then run ONE step whose WnExec carry .plan = plan: it runs as without a plan and
+ *                                             every preparation that depends on weights only is registered (launcher arguments)
+ *   wn_plan_finish(plan, stream)              lays the images out and uploads the job table (blocking; not under capture)
+ *   wn_plan_prepare(plan, zero, n, stream)    FIRST call of every later step: all images, range words and plan-owned words in
+ *                                             two launches; also zeroes `zero[0..n)` (the gradient arena: n % 4 == 0, 16-byte
+ *                                             aligned; NULL / 0: nothing)
+ * A READY plan makes an entry point skip its own preparation when the plan holds it (same weight pointers, same form) --
+ * results are bit-identical to the per-call preparation -- so a call that carries one ASSERTS that wn_plan_prepare ran on the
+ * same stream since the weights last changed.  Weight POINTERS are the keys: a plan belongs to one model.  Plan-owned words:
+ * the dataflow words of the multi-layer backward, and the range word of the head's dx, filled by the GEMM that writes dx and
+ * read by the dz contraction instead of a 100 MB pass over dskip.  wn_plan_stats: out[0..7] = state (0 idle, 1 recording,
+ * 2 ready), weight images, layer images (layers), plan-owned words, device bytes used, prepare calls, look-ups served,
+ * look-ups not served. */
+int wn_plan_create(void** plan, void* dev_mem, size_t dev_bytes);
+int wn_plan_destroy(void* plan);
+int wn_plan_record(void* plan);
+int wn_plan_finish(void* plan, void* stream);
+int wn_plan_prepare(void* plan, float* zero, int64_t zero_floats, void* stream);
+int wn_plan_stats(void* plan, int64_t* out8);
 
 /* ---- measurement aid (bench.py): per-entry-point HIP-event timing on the caller's stream ------- */
 int wn_prof_enable(int on);                    /* 1: clear + start recording, 0: stop               */

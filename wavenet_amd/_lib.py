@@ -41,7 +41,7 @@ class WnDecoderDesc(C.Structure):
 class WnExec(C.Structure):
     """Per-call options of the entry points that hold a channel GEMM or need scratch (include/wavenet_hip.h)."""
     _fields_ = [("precision", _i), ("flags", C.c_uint), ("ws", _p), ("ws_bytes", C.c_size_t),
-                ("fwd_t1_min_blocks", _i), ("reserved", _i)]
+                ("fwd_t1_min_blocks", _i), ("reserved", _i), ("plan", _p)]
 
 
 _ex = C.POINTER(WnExec)
@@ -114,6 +114,12 @@ _SIGS = {
     "wn16_pointwise_fwd": (_i, [_p, _p, _p, _p, _i, _i64, _i, _i, _i, _p]),
     "wn16_pointwise_bwd_workspace_bytes": (C.c_size_t, [_i64, _i]),
     "wn16_pointwise_bwd": (_i, [_p] * 8 + [_i64, _i, _i, _i, _p, C.c_size_t, _p]),
+    "wn_plan_create": (_i, [C.POINTER(_p), _p, C.c_size_t]),
+    "wn_plan_destroy": (_i, [_p]),
+    "wn_plan_record": (_i, [_p]),
+    "wn_plan_finish": (_i, [_p, _p]),
+    "wn_plan_prepare": (_i, [_p, _p, _i64, _p]),
+    "wn_plan_stats": (_i, [_p, C.POINTER(C.c_int64)]),
     "wn_prof_enable": (_i, [_i]),
     "wn_prof_report": (_i, [C.c_char_p, _i]),
 }

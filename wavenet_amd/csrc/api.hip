@@ -28,7 +28,10 @@ int gemm_mode() {
     const int m = g_exec ? g_exec->precision : WN_GEMM_BF16X3;
     return (m < WN_GEMM_FP32 || m > WN_GEMM_FP16X2) ? WN_GEMM_BF16X3 : m;
 }
+StepPlan* exec_plan() { return g_exec ? reinterpret_cast<StepPlan*>(g_exec->plan) : nullptr; }
 const unsigned* exec_absmax(const float* x, long long n, hipStream_t s) {
+    // a READY step plan: the GEMM that wrote x left max |x| in a plan-owned word (the head's dx = dskip): no pass over x
+    if (const unsigned* w = plan_xmax_consumer(x)) return w;
     if (!g_exec || !g_exec->ws || g_exec->ws_bytes < kExecTail) {
         set_error("this call needs WnExec scratch (the fp16 split scales its operands by their measured range)");
         return nullptr;

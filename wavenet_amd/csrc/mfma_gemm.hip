@@ -305,6 +305,9 @@ int mfma_pointwise_bwd_dx(const float* x, const float* W, const float* dout, flo
     if (N >= (1ll << 30)) { wn::set_error("pointwise: N too large"); return WN_ESHAPE; }
     a.rows_out_per_b = (int)N; a.rows_src_per_b = (int)N; a.off = 0;
     a.act = WN_ACT_NONE; a.gate_x = (act == WN_ACT_NONE) ? nullptr : x; a.gate_act = act; a.accumulate = 0;
+    // step plan: the next consumer of dx (the dz contraction of the skip path, whose fp16 split needs max |dskip|) finds the
+    // range in a plan-owned word instead of making a pass over the array (exec_absmax -> plan_xmax_consumer)
+    a.outmax_dev = plan_xmax_producer();
     return launch_colgemm<false>(a, 1, s);
 }
 

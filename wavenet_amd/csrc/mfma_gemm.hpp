@@ -40,6 +40,7 @@ struct CGArgs {
     int h2_ok;                       // X is provably within the fp16 split's static range (z = tanh * sigmoid)
     const unsigned* xmax_dev;        // else: device word with the bits of max |X| (exec_absmax) -> dynamic power-of-two scale
     const unsigned* wmax_dev;        // fp16 split: bits of max |W| over the launch's weight tiles (launch_colgemm_b3 fills it)
+    unsigned* outmax_dev;            // mode 0, k_colgemm_b3 only: atomicMax of the bits of max |out| (a step plan's word), or NULL
     const float* proj_W;             // Wp[128][128], row-major
     const float* proj_bias;
     // head + loss mode (mode 6, fp16 split, exactly 8 m-tiles = 256 outputs): the GEMM result + bias are a column's logits; the

@@ -13,131 +13,26 @@
 // (global_load_lds, no staging registers) into a double buffer: the copy of chunk c+1 lands while chunk c
 // computes.  X columns are split in registers right after their (prefetched) float4 loads.
 #include "mfma_gemm.hpp"
+#include "split_w.hpp"
 #include "h2_ops.hpp"
 #include <type_traits>
 
 namespace wn {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-static constexpr int kTileElems = 2 * 3 * 64 * 8;          // bf16 elements of one tile image: [ks][comp][lane][8]
-static constexpr int kTileBytes = kTileElems * 2;          // 6144
-
 bool gemm_b3_enabled() { return gemm_mode() >= 1; }
 static bool one_term() { return gemm_mode() == 2; }
 static bool half2_mode() { return gemm_mode() == 3; }
 
-// fp16 two-way split (WN_GEMM_FP16X2): x S = h + m with h, m in fp16 (11 significant bits each, |x S - h - m| <= 2^-22 |x S|
-// while m is a normal number), products wh xh + (wh xm + wm xh): the dropped wm xm term is 2^-22 relative, so the result
-// is fp32-accurate like the six-term bf16 split at HALF the matrix instructions.  fp16's narrow exponent range is what
-// restricts it: operands are scaled by a power of two (exact) and must stay below 65504 after scaling, which is known for
-// the forward contractions (z = tanh * sigmoid in [-1, 1]; weights; the skip sum in front of the head) and is not for
-// gradients, whose magnitude follows the batch size and any loss scaling -- those keep the bf16 split.
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-static constexpr float kH2ScaleW = 256.f;        // weights without a measured range (never used by the launchers below)
-static constexpr float kH2ScaleX = 16384.f;      // z = tanh * sigmoid in [-1, 1] (the only operand with a static range): 2^14,
-                                                 // so that values down to ~1e-8 keep their two parts (with 2^4 a residual
-                                                 // stream 4,096 times smaller than usual lost them: 1e-3 relative in the skip sum)
-// power-of-two scale that brings max |x| just below 2^14 (mx_dev = bits of max |x|); `fixed` when the range is static
-__device__ __forceinline__ float h2_scale(const unsigned* mx_dev, float fixed) {
-    if (!mx_dev) return fixed;
-    const float m = __uint_as_float(*mx_dev);
-    if (!(m > 0.f) || !(m < 3e38f)) return 1.f;
-    int e;
-    (void)frexpf(m, &e);                                  // m = f 2^e, f in [0.5, 1)
-    return ldexpf(1.f, 14 - e);
-}
-__device__ __forceinline__ void split2h(float x, _Float16& h, _Float16& m) {
-    x = fminf(fmaxf(x, -65000.f), 65000.f);
-    h = (_Float16)x;
-    m = (_Float16)(x - (float)h);
-}
-
-__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)x;
-    const float r1 = x - (float)h;
-    m = (__bf16)r1;
-    l = (__bf16)(r1 - (float)m);
-}
-
-// ---- weight image: tile (chunk c, m-tile t) at img + (c*mtiles + t)*kTileElems -----------------------------
-//   element [ks][comp][lane = i + 32*hh][j]  =  comp-part of  W_tile[i][16*ks + 8*hh + j]
-// mode 0: chunk c = (source, 32-wide k slice), m-tile t = rows 32t.. of that source's W[m][k]
-// mode 2: m-tile t = problem t (32 rows), chunk c = k slice of W[t]
-// one != 0 (one-term products): only the h parts are stored, 2 KB per tile instead of 6
-// WMAX: only the largest |w| of the launch's weight tiles, into *a.wmax_dev (atomicMax of the bits: a positive float orders
-// like an unsigned) -- the fp16 split scales the weights by the power of two that brings that maximum just below 2^14
+// the weight tiles of one launch (see split_w.hpp); WMAX: only the largest |w|, into *a.wmax_dev (atomicMax of the bits: a
+// positive float orders like an unsigned)
 template <bool WMAX>
 __global__ void k_split_w(CGArgs a, int mode, int mtiles, int chunks_per_src, __bf16* __restrict__ img, int one) {
-    // one: 1 = h parts only (one-term bf16), 3 = fp16 two-way split of W * h2_scale(max |W|), 0 = bf16 three-way split
-    const int tile = blockIdx.x;
-    const int c = tile / mtiles, t = tile - c * mtiles;
-    const int i = threadIdx.x & 31, c4 = threadIdx.x >> 5;           // row, group of 4 consecutive k
-    const float* W;
-    int wsm, k0;
-    if (mode == 0 || mode == 4 || mode == 6) {
-        const int src = c / chunks_per_src;
-        k0 = (c - src * chunks_per_src) * 32;
-        W = a.W[src] + (long long)(t * 32) * a.wsm[src];
-        wsm = a.wsm[src];
-    } else if (mode == 3 || mode == 5) {   // m-tile 2i = filter rows 32i.., m-tile 2i+1 = gate rows 32i..
-        const int src = c / chunks_per_src;
-        k0 = (c - src * chunks_per_src) * 32;
-        W = ((t & 1) ? a.W2[src] : a.W[src]) + (long long)((t >> 1) * 32) * a.wsm[src];
-        wsm = a.wsm[src];
-    } else {
-        k0 = c * 32;
-        W = a.W[t];
-        wsm = a.wsm[t];
-    }
-    const float* wp = W + (long long)i * wsm + (long long)(k0 + 4 * c4) * a.wsk;
-    float w[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) w[e] = wp[(long long)e * a.wsk];
     if (WMAX) {
-        float mw = fmaxf(fmaxf(fabsf(w[0]), fabsf(w[1])), fmaxf(fabsf(w[2]), fabsf(w[3])));
-        for (int o = 32; o >= 1; o >>= 1) mw = fmaxf(mw, __shfl_xor(mw, o));
-        __shared__ float red[4];
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mw;
-        __syncthreads();
-        if (threadIdx.x == 0)
-            atomicMax(const_cast<unsigned*>(a.wmax_dev), __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
-        return;
+        const float mw = split_w_tile<true>(a, mode, mtiles, chunks_per_src, img, one, (int)blockIdx.x, 1.f);
+        if (threadIdx.x == 0) atomicMax(const_cast<unsigned*>(a.wmax_dev), __float_as_uint(mw));
+    } else {
+        split_w_tile<false>(a, mode, mtiles, chunks_per_src, img, one, (int)blockIdx.x, one == 3 ? h2_scale(a.wmax_dev, kH2ScaleW) : 1.f);
     }
-    bf16x4 h, m, l;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        __bf16 hh, mm, ll;
-        split3(w[e], hh, mm, ll);
-        h[e] = hh; m[e] = mm; l[e] = ll;
-    }
-    const int ks = c4 >> 2, hh = (c4 >> 1) & 1, jo = 4 * (c4 & 1);
-    if (one == 3) {
-        const float h2sw = h2_scale(a.wmax_dev, kH2ScaleW);
-        f16x4 fh, fm;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            _Float16 a0, a1;
-            split2h(w[e] * h2sw, a0, a1);
-            fh[e] = a0; fm[e] = a1;
-        }
-        __bf16* d = img + (long long)tile * (kTileElems * 2 / 3) + (i + 32 * hh) * 8 + jo;
-        *reinterpret_cast<f16x4*>(d + (ks * 2 + 0) * 512) = fh;
-        *reinterpret_cast<f16x4*>(d + (ks * 2 + 1) * 512) = fm;
-        return;
-    }
-    if (one) {
-        __bf16* d = img + (long long)tile * (kTileElems / 3) + (i + 32 * hh) * 8 + jo;
-        *reinterpret_cast<bf16x4*>(d + ks * 512) = h;
-        return;
-    }
-    __bf16* d = img + (long long)tile * kTileElems + (i + 32 * hh) * 8 + jo;
-    *reinterpret_cast<bf16x4*>(d + (ks * 3 + 0) * 512) = h;
-    *reinterpret_cast<bf16x4*>(d + (ks * 3 + 1) * 512) = m;
-    *reinterpret_cast<bf16x4*>(d + (ks * 3 + 2) * 512) = l;
 }
 
 __device__ __forceinline__ int b3_ch(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -658,6 +553,7 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
         }
         return;
     }
+    float omax = 0.f;                                              // MODE 0 with a.outmax_dev: max |out| of this wave's tiles
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         if (t0 + mt >= mtiles) break;
@@ -687,7 +583,22 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
 #pragma unroll
             for (int q = 0; q < 4; ++q) { t[q].x += u[q].x; t[q].y += u[q].y; t[q].z += u[q].z; t[q].w += u[q].w; }
         }
+        if (MODE == 0 && a.outmax_dev && nvalid) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                omax = fmaxf(omax, fmaxf(fmaxf(fabsf(t[q].x), fabsf(t[q].y)), fmaxf(fabsf(t[q].z), fabsf(t[q].w))));
+        }
         tile_store_rows(patch, lane, t, og, a.ldo, col, rm);
+    }
+    if (MODE == 0 && a.outmax_dev) {
+        // the range of the output for a later call of the step (step plan: the head's dx is the dz contraction's operand): one
+        // atomic per wave, and none once the word already holds a larger value (bits of a non-negative float order like an
+        // unsigned; a NaN -- bits above every finite value -- sticks, as it must)
+        for (int o = 32; o >= 1; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+        if (lane == 0) {
+            const unsigned bits = __float_as_uint(omax);
+            if (bits > __hip_atomic_load(a.outmax_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.outmax_dev, bits);
+        }
     }
 }
 
@@ -949,8 +860,16 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
     const bool h2 = half2_mode() && ((a.h2_ok || a.xmax_dev) && (mode == 0 || mode == 2) || mode == 6);
     const size_t bytes = (size_t)nchunks * mtiles * (one ? kTileBytes / 3 : (h2 ? kTileBytes * 2 / 3 : kTileBytes));
     const size_t bytes2 = mode == 5 ? (size_t)16 * (kTileBytes / 3) : 0;        // Wp's image behind the gate image
-    __bf16* img = reinterpret_cast<__bf16*>(exec_scratch(bytes + bytes2, "the split weight image"));
+    // a READY step plan holds this launch's image (and its range word) already: wn_plan_prepare built them at the start of the
+    // step; a recording plan notes the job, and this call prepares its own image as ever (plan.hip)
+    const __bf16* pimg = nullptr; const unsigned* pwmax = nullptr;
+    const bool planned = plan_split_image(a, mode, mtiles, cps, nchunks, one ? 1 : (h2 ? 3 : 0), bytes, &pimg, &pwmax);
+    __bf16* img = planned ? const_cast<__bf16*>(pimg)
+                          : reinterpret_cast<__bf16*>(exec_scratch(bytes + bytes2, "the split weight image"));
     if (!img) return WN_EARG;
+    if (planned) {
+        a.wmax_dev = pwmax;
+    } else {
     if (h2) {
         // the weights' own range: |w| <= 2^7 was an assumption (a weight above ~254 saturated the fp16 parts silently); one
         // pass of the same grid over the weight tiles measures it, per entry-point call and weight set
@@ -963,6 +882,7 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
         if (fresh) hipLaunchKernelGGL(k_split_w<true>, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img, 3);
     }
     hipLaunchKernelGGL(k_split_w<false>, dim3(nchunks * mtiles), dim3(256), 0, s, a, mode, mtiles, cps, img, one ? 1 : (h2 ? 3 : 0));
+    }
     if (mode == 5) {
         if (!a.proj_W || !a.residual || !a.gate_z || a.act != WN_ACT_NONE || mtiles != 8) {
             wn::set_error("colgemm_b3: fused-layer mode needs Wp, the residual input, z and 128 gate channels");
@@ -1053,6 +973,8 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
         if (a.act != WN_ACT_NONE || !a.gate_z || !a.gate_f || !a.gate_s) { wn::set_error("colgemm_b3: gate-backward mode needs f, s and the output"); return WN_EARG; }
         CG_LAUNCH(4, WN_ACT_NONE);
     } else if (mode == 0) {
+        // (k_colgemm_b3's epilogue is the one that fills a.outmax_dev: only now may the plan hand the word to a consumer)
+        if (a.outmax_dev) plan_xmax_written(a.out[0]);
         if (a.act == WN_ACT_RELU) CG_LAUNCH(0, WN_ACT_RELU);
         else if (a.act == WN_ACT_ELU) CG_LAUNCH(0, WN_ACT_ELU);
         else if (a.act == WN_ACT_NONE) CG_LAUNCH(0, WN_ACT_NONE);

@@ -1475,7 +1475,7 @@ int mfma_layer_bwd_chain_multi(int n, const int* layer, const float* const* Wf, 
                                const float* const* Wp, const int* d, const int* Z, const int* t_live, const int* vu_t0,
                                const int* dU, const float* x0, const float* xs, const float* z, const float* g,
                                const float* dz, float* const* V, float* const* U, float* part, size_t part_stride,
-                               unsigned* sync, int B, int T, int dz_t0, int* nwg, hipStream_t s) {
+                               unsigned* sync, int B, int T, int dz_t0, int* nwg, hipStream_t s, bool sync_zeroed) {
     WN_CHECK_ARG(n >= 1 && n <= kChainMaxL, "mfma_layer_bwd_chain_multi: 1..%d layers", kChainMaxL);
     const bool h2w = gemm_mode() == WN_GEMM_FP16X2;           // else: every product on exact fp32 MFMA (bf16x3 / fp32 modes)
     const int tiles_all = (T + 31) / 32;
@@ -1538,8 +1538,9 @@ int mfma_layer_bwd_chain_multi(int n, const int* layer, const float* const* Wf, 
     // ordered before it when graph replays follow each other without a host synchronisation -- the launch then saw the
     // previous replay's words, every wait was open, and the layers raced on the nearly-right (V, U) of the step before
     // (fast, and wrong in the fourth digit of the loss after a hundred steps)
+    // (sync_zeroed: the words are a step plan's, zeroed by wn_plan_prepare -- a kernel too, at the start of the same graph)
     const int nsync = (int)mfma_chain_multi_sync_words(B, T);
-    hipLaunchKernelGGL(k_chain_zero_sync, dim3(cdiv(nsync, 256)), dim3(256), 0, s, sync, nsync);
+    if (!sync_zeroed) hipLaunchKernelGGL(k_chain_zero_sync, dim3(cdiv(nsync, 256)), dim3(256), 0, s, sync, nsync);
     WN_LAUNCH_CHECK();
     if (h2w) hipLaunchKernelGGL((k_layer_bwd_chain_multi<true, true>), dim3(blocks), dim3(256), kCLdsBytes, s, a);
     else hipLaunchKernelGGL((k_layer_bwd_chain_multi<true, false>), dim3(blocks), dim3(256), kCLdsBytes, s, a);

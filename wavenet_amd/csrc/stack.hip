@@ -105,9 +105,13 @@ int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, floa
         for (int l = 0; l < L && ok; ++l)
             ok = d->cd[l] == 32 && !(d->bf && d->bf[l]) && !(d->bg && d->bg[l]) && !(d->bp && d->bp[l]);
         if (ok) {
-            void* img = exec_scratch(mfma_layer_h2_image_bytes(L), "the fp16 x 2 layer weight images");
-            if ((rc = mfma_layer_pack_h2(L, d->Wf, d->Wg, d->Wp, img, as_stream(stream)))) return rc;
-            h2img = img;
+            // (a READY step plan built the images at the start of the step: plan.hip)
+            h2img = plan_layer_h2_images(L, d->Wf, d->Wg, d->Wp);
+            if (!h2img) {
+                void* img = exec_scratch(mfma_layer_h2_image_bytes(L), "the fp16 x 2 layer weight images");
+                if ((rc = mfma_layer_pack_h2(L, d->Wf, d->Wg, d->Wp, img, as_stream(stream)))) return rc;
+                h2img = img;
+            }
         }
     }
     {
@@ -230,6 +234,9 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
         // are through; with three the readers are two layers back
         unsigned* sync = reinterpret_cast<unsigned*>(parts + (size_t)L * mfma_chain_part_floats());
         float* vu3 = reinterpret_cast<float*>(sync) + ((mfma_chain_multi_sync_words(B, T) + 63) / 64) * 64;
+        // a READY step plan owns the dataflow words and zeroed them at the start of the step (no k_chain_zero_sync launch)
+        bool sync_zeroed = false;
+        if (unsigned* ps = plan_sync_words((int)mfma_chain_multi_sync_words(B, T))) { sync = ps; sync_zeroed = true; }
         float* Vb[3] = {vu, vu + n * d->Cr, vu3};
         float* Ub[3] = {vu + 2 * n * d->Cr, vu + 3 * n * d->Cr, vu3 + n * d->Cr};
         const float* Vin = dout;
@@ -275,7 +282,7 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
             rc = mfma_layer_bwd_chain_multi((int)m_layer.size(), m_layer.data(), m_Wf.data(), m_Wg.data(), m_Wp.data(),
                                             m_d.data(), m_Z.data(), m_live.data(), m_vu_t0.data(), m_dU.data(), x, xs, z, g,
                                             ws /* dz of layer l at ws + l n 32 */, Vb, Ub, parts, mfma_chain_part_floats(),
-                                            sync, B, T, t_off, &grid, as_stream(stream));
+                                            sync, B, T, t_off, &grid, as_stream(stream), sync_zeroed);
             if (rc == WN_ESHAPE) {                  // not every workgroup would be resident on this device: one launch per layer after all
                 wn::set_error("");
                 for (size_t i = 0; i < m_layer.size(); ++i) {

@@ -62,6 +62,19 @@ const unsigned* exec_absmax(const float* x, long long n, hipStream_t s);
 // whether the word is new in this entry-point call (then it has been zeroed on the stream and must be filled) or was
 // handed out for the same key before
 unsigned* exec_word(const void* key, bool* fresh, hipStream_t s);
+// ---- the step plan (plan.hip, ABI 5): weight-only preparation hoisted to the start of a training step -------------------
+struct StepPlan;
+struct CGArgs;
+StepPlan* exec_plan();                 // WnExec.plan of the current call, or NULL
+// launch_colgemm_b3: true + the prepared image / range word when a READY plan holds this launch's weight tiles (a recording
+// plan registers the job and returns false)
+bool plan_split_image(const CGArgs& a, int mode, int mtiles, int cps, int nchunks, int one, size_t bytes,
+                      const __bf16** img, const unsigned** wmax);
+const void* plan_layer_h2_images(int L, const float* const* Wf, const float* const* Wg, const float* const* Wp);
+unsigned* plan_sync_words(int nwords);                  // the multi-layer backward's dataflow words, zeroed by wn_plan_prepare
+unsigned* plan_xmax_producer();                         // word that receives max |out| of a GEMM (zeroed by wn_plan_prepare)
+void plan_xmax_written(const void* out);                // ... called by the launcher whose kernel really fills it
+const unsigned* plan_xmax_consumer(const void* x);      // ... for the call that needs the range of the same array
 int generic_absmax(const float* x, long long n, unsigned* slot, hipStream_t s);
 int generic_zero_word(unsigned* w, hipStream_t s);        // by a kernel: see generic_kernels.hip
 int generic_scale_by_dev(float* x, const float* sdev, long long n, hipStream_t s);
@@ -102,7 +115,7 @@ int mfma_layer_bwd_chain_multi(int n, const int* layer, const float* const* Wf, 
                                const float* const* Wp, const int* d, const int* Z, const int* t_live, const int* vu_t0,
                                const int* dU, const float* x0, const float* xs, const float* z, const float* g,
                                const float* dz, float* const* V, float* const* U, float* part, size_t part_stride,
-                               unsigned* sync, int B, int T, int dz_t0, int* nwg, hipStream_t s);
+                               unsigned* sync, int B, int T, int dz_t0, int* nwg, hipStream_t s, bool sync_zeroed = false);
 size_t mfma_chain_multi_sync_words(int B, int T);
 size_t mfma_chain_part_floats();
 int mfma_chain_reduce_all(const float* part, int L, const int* nwg, float* const* dWf, float* const* dWg,

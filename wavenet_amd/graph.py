@@ -53,7 +53,18 @@ class TrainStepGraph(object):
         self._g2 = None
         try:
             self._stream.wait_stream(torch.cuda.current_stream())
+            # step plan (fp32 storage): the first warm-up step RECORDS the step's weight-only preparation work, every later
+            # step -- the captured one included -- starts with wn_plan_prepare (two launches: all weight images, range words,
+            # dataflow words, cleargrads) and its entry points launch no preparation of their own
+            self._use_plan = bool(getattr(net, "use_step_plan", False)) and net.storage != "bf16"
             with torch.cuda.stream(self._stream):
+                if self._use_plan:
+                    self._plan = net.plan_begin()          # this object's own plan: the graph keeps pointers into its memory
+                    self._planned = False
+                    self._fwd_bwd()
+                    self._opt()
+                    net.plan_finish()
+                    self._planned = True
                 for _ in range(max(1, warmup)):
                     self._fwd_bwd()
                     self._opt()
@@ -83,6 +94,9 @@ class TrainStepGraph(object):
                 net._arena.copy_(keep[0]); opt.m.copy_(keep[1]); opt.v.copy_(keep[2])
             opt.t = keep[3]
             net._weights_changed()
+            # outside this object's graphs nobody runs wn_plan_prepare: eager calls must not take the plan's (stale) images
+            if getattr(self, "_use_plan", False):
+                net.plan_off()
 
     def _hyper(self):
         """Everything a captured kernel node took BY VALUE: replaying after one of these changed would silently train with
@@ -92,7 +106,17 @@ class TrainStepGraph(object):
             (p.gradient_clipping, p.weight_decay, self.net.gemm_precision or _lib.get_gemm_precision())
 
     def _fwd_bwd(self):
-        self.net.zero_grads()
+        if getattr(self, "_use_plan", False) and self._planned:
+            self.net.plan_prepare(zero_grads=True)
+        else:
+            self.net.zero_grads()
+        self.net._unit_upstream = True                 # loss.backward(self._one): d loss = 1, the scale launch is skipped
+        try:
+            return self._fwd_bwd_body()
+        finally:
+            self.net._unit_upstream = False
+
+    def _fwd_bwd_body(self):
         loss = self.loss_fn(self.net, self.x, self.tgt)
         # the upstream gradient of the loss is a tensor made ONCE (in the warm-up pass, outside the capture): `loss.backward()`
         # would fill a fresh one in every replay -- a kernel at the launch floor (4.6 us) for one float

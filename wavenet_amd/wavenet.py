@@ -267,8 +267,9 @@ class _HeadXentFn(_Fn):
         W, b = ctx.W, ctx.b
         Cout, Cin = W.shape[0], x2.shape[1]
         lib = _lib.lib()
-        d = dloss.to(torch.float32).reshape(1).contiguous()
-        check(lib.wn_scale_by_dev(ptr(dlog), ptr(d), dlog.numel(), stream_ptr()), "wn_scale_by_dev")
+        if not ctx.net._unit_upstream:       # (TrainStepGraph backpropagates a constant 1: not even the launch that would find that out)
+            d = dloss.to(torch.float32).reshape(1).contiguous()
+            check(lib.wn_scale_by_dev(ptr(dlog), ptr(d), dlog.numel(), stream_ptr()), "wn_scale_by_dev")
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
         check(lib.wn_pointwise_bwd(ptr(x2), ptr(W), ptr(dlog), ptr(dx), ptr(W.grad), ptr(None if b is None else b.grad),
                                    x2.shape[0], Cin, Cout, ctx.act, ctx.net._exec(), stream_ptr()), "wn_pointwise_bwd")
@@ -571,6 +572,22 @@ class ResidualConvLayer(object):
 # ----------------------------------------------------------------------------------------------
 # the model
 # ----------------------------------------------------------------------------------------------
+class _StepPlan(object):
+    """A step plan handle (include/wavenet_hip.h, "step plan") and the device memory it lays its images out in."""
+
+    def __init__(self, device, nbytes: int):
+        self.mem = torch.empty((nbytes,), device=device, dtype=torch.uint8)
+        h = C.c_void_p()
+        check(_lib.lib().wn_plan_create(C.byref(h), self.mem.data_ptr(), nbytes), "wn_plan_create")
+        self.handle = h
+
+    def __del__(self):
+        try:
+            _lib.lib().wn_plan_destroy(self.handle)
+        except Exception:
+            pass
+
+
 class WaveNet(object):
     """Drop-in for wavenet.py:370-639."""
 
@@ -589,6 +606,9 @@ class WaveNet(object):
         self.fuse_head_loss = os.environ.get("WAVENET_HIP_NO_FUSED_HEAD_LOSS") != "1"      # head_cross_entropy: one launch when covered
         self.fwd_t1_min_blocks = None       # None: _lib.default_fwd_t1_min_blocks() (WnExec.fwd_t1_min_blocks)
         self._scratch, self._scratch_keep = {}, []
+        self._plan, self._plan_obj, self._plan_on = None, None, False     # step plan (wn_plan_*): see plan_begin
+        self.use_step_plan = os.environ.get("WAVENET_HIP_NO_STEP_PLAN") != "1"   # TrainStepGraph: weight preparation in two launches
+        self._unit_upstream = False         # True while a caller guarantees d loss = 1 (TrainStepGraph)
         self._pack16 = None
         self._w16_stale = True
         self.compat_zero_prefix = compat_zero_prefix
@@ -736,7 +756,44 @@ class WaveNet(object):
         ex.ws, ex.ws_bytes = ent[0].data_ptr(), ent[0].numel()
         ex.fwd_t1_min_blocks = (_lib.default_fwd_t1_min_blocks() if self.fwd_t1_min_blocks is None
                                 else int(self.fwd_t1_min_blocks))
+        ex.plan = self._plan if self._plan_on else None
         return C.byref(ex)
+
+    # -- step plan (include/wavenet_hip.h, "step plan"): the weight-only preparation of a training step in two launches --------
+    def plan_begin(self, nbytes: int = 16 << 20):
+        """A NEW plan (its own device memory: a captured graph keeps pointers into it) in the RECORDING state: the next training
+        step runs as ever and registers its weight-only preparation work.  Returns the plan object; the model's entry points carry
+        it until :meth:`plan_off`."""
+        self._plan_obj = _StepPlan(self._arena.device, nbytes)
+        self._plan = self._plan_obj.handle
+        check(_lib.lib().wn_plan_record(self._plan), "wn_plan_record")
+        self._plan_on = True
+        return self._plan_obj
+
+    def plan_use(self, plan_obj):
+        """Carry an existing plan again (the caller vouches that wn_plan_prepare opens every step that does)."""
+        self._plan_obj, self._plan, self._plan_on = plan_obj, plan_obj.handle, True
+
+    def plan_finish(self):
+        check(_lib.lib().wn_plan_finish(self._plan, stream_ptr()), "wn_plan_finish")
+
+    def plan_prepare(self, zero_grads: bool = True):
+        """First call of a step that carries the READY plan: every weight image of the step, and (``zero_grads``) cleargrads."""
+        n = self._grad_arena.numel() if zero_grads else 0
+        n4 = n // 4 * 4
+        check(_lib.lib().wn_plan_prepare(self._plan, ptr(self._grad_arena) if n4 else None, n4, stream_ptr()), "wn_plan_prepare")
+        if n4 < n:
+            self._grad_arena[n4:].zero_()
+
+    def plan_off(self):
+        """Entry points stop carrying the plan (its images go stale with the next weight update a prepare does not follow)."""
+        self._plan_on = False
+
+    def plan_stats(self):
+        out = (C.c_int64 * 8)()
+        check(_lib.lib().wn_plan_stats(self._plan, out), "wn_plan_stats")
+        return dict(zip(("state", "weight_images", "layer_images", "plan_words", "device_bytes", "prepare_calls", "served", "not_served"),
+                        [int(v) for v in out]))
 
     def _pack16_if_stale(self):
         """bf16 operand images of the current weights (one pack per optimiser step; captured with the step in a graph)."""
