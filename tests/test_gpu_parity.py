@@ -611,8 +611,9 @@ def test_fast_generation_vs_oracle_golden(act):
     np.testing.assert_array_equal(buf[iw:], z["tokens"][:12])
 
 
+@pytest.mark.parametrize("prec", ["fp16x2"])
 @pytest.mark.parametrize("B,T", [(1, 40), (2, 333), (3, 1000), (2, 2048), (8, 16384)])
-def test_grouped_layer_forward_is_the_per_layer_forward_bit_for_bit(B, T):
+def test_grouped_layer_forward_is_the_per_layer_forward_bit_for_bit(B, T, prec):
     """k_layer_fwd_h2_grp (the d = 1 .. 16 layers of a block in one launch: inputs of the inner layers stay on chip, one
     halo tile per seven recomputed) against the per-layer kernel k_layer_fwd_h2_t1 (WN_EXEC_NO_FWD_GROUPS): every
     layer's output, z and sigmoid and the skip sum are IDENTICAL bit for bit -- same MFMAs, same per-tile scales -- at
@@ -621,7 +622,7 @@ def test_grouped_layer_forward_is_the_per_layer_forward_bit_for_bit(B, T):
     if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1":
         pytest.skip("generic kernels only")
     p, w, net = build(CFG2)
-    net.gemm_precision = "fp16x2"
+    net.gemm_precision = prec
     net.fwd_t1_min_blocks = 1
     idx = dev(np.random.RandomState(T).randint(0, 256, (B, T)).astype(np.int32))
     got = {}

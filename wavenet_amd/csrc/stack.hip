@@ -121,6 +121,9 @@ int wn_stack_fwd(const WnStackDesc* d, const float* x, float* xs, float* z, floa
             int Z = compat_zero_prefix ? zero_prefix(T, d->dilation[l], d->fw) : 0;
             // consecutive layers whose dilations add up to <= 32 (d = 1 .. 16 of every block): ONE launch, the inner layers'
             // inputs never leave the chip (k_layer_fwd_h2_grp)
+            // (fp16 x 2 only.  The same group on exact fp32 MFMA -- k_layer_fwd_f32_grp, round 6 -- was built, bit-identical to
+            // the per-layer launches, and 3.5 % SLOWER on the bf16x3 step (3.844 against 3.712 ms, same box): 80 fp32 MFMAs per
+            // tile-layer are MFMA-bound at the per-layer kernel's 16 waves per CU already, and the halo tile adds 12.5 %)
             int ng = (h2img && !exec_flag(WN_EXEC_NO_FWD_GROUPS) && mfma_layer_fwd_h2_ok(B, T, 0))
                          ? mfma_layer_fwd_group_len(d->dilation, l, L) : 0;
             for (int k = 0; k < ng; ++k)
