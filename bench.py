@@ -390,6 +390,16 @@ def main():
         torch.cuda.synchronize()
         eager_dt = (time.perf_counter() - t0) / args.steps
     per_step = {k: v[1] / args.steps for k, v in prof.result().items()}  # ms of each entry point per step
+    # the step plan of the timed graph (wn_plan_*: the weight-only preparation of the step in two launches)
+    step_plan = None
+    if graph is not None and getattr(graph, "_use_plan", False):
+        try:
+            net.plan_use(graph._plan)
+            step_plan = net.plan_stats()
+        except Exception as e:
+            step_plan = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            net.plan_off()
     # what ONE replayed step launches: the node counts of the same step captured once more with the hipGraph_t kept
     graph_nodes = None
     if graph is not None:
@@ -426,6 +436,7 @@ def main():
         "launch": ("hipGraph replay, one graph launch per step" + (" (fwd+bwd graph, RCCL all-reduce, optimiser graph)"
                    if world > 1 or force_dist else "")) if graph is not None else "op-by-op launches from Python",
         "eager_ms_per_step": eager_dt * 1e3, "graph_nodes_per_step": graph_nodes,
+        "step_plan": step_plan,
         "entry_point_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
     }
 
@@ -558,7 +569,7 @@ def main():
             "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl, [r"wn::k_layer_fwd_h2\w*<2\b", r"wn::k_layer_fwd_mfma32_t1<2\b"]),
             "wn_skip_sum_fwd": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, [r"wn::k_colgemm_h2q<0, 0", r"wn::k_colgemm_b3<0, 0,"]),
             "wn_skip_sum_bwd_dw": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, [r"wn::k_wgrad_h2p<0", r"wn::k_wgrad_b3w<false, 0,"]),
-            "wn_skip_sum_bwd_dz": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, [r"wn::k_colgemm_b3<2, 0,"]),
+            "wn_skip_sum_bwd_dz": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, [r"wn::k_dz_xs", r"wn::k_colgemm_b3<2, 0,"]),
         }
         dom = max(units, key=lambda k: per_step.get(k, 0.0))
         bound, amount, launches, knames = units[dom]

@@ -8,7 +8,7 @@
 # Every pass runs under `timeout`: a profiler pass that hangs must not take the box with it.
 # Results land in gpurun_out/prof_<tag>/ ; the summaries are copied to profiles/ by hand afterwards.
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
