@@ -569,7 +569,7 @@ def main():
             "wn_layer_fwd": ("hbm", es * (2 * Cr + 2 * Cs + 2 * Cd) * n_col, nl, [r"wn::k_layer_fwd_h2\w*<2\b", r"wn::k_layer_fwd_mfma32_t1<2\b"]),
             "wn_skip_sum_fwd": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, [r"wn::k_colgemm_h2q<0, 0", r"wn::k_colgemm_b3<0, 0,"]),
             "wn_skip_sum_bwd_dw": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, [r"wn::k_wgrad_h2p<0", r"wn::k_wgrad_b3w<false, 0,"]),
-            "wn_skip_sum_bwd_dz": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, [r"wn::k_dz_xs", r"wn::k_colgemm_b3<2, 0,"]),
+            "wn_skip_sum_bwd_dz": ("mfma", 2.0 * Cs * Cd * nl * n_colw, 1, [r"wn::k_colgemm_b3<2, 0,"]),
         }
         dom = max(units, key=lambda k: per_step.get(k, 0.0))
         bound, amount, launches, knames = units[dom]

@@ -723,40 +723,6 @@ def test_pipelined_skip_weight_gradient_is_the_older_kernel_bit_for_bit(B, T, tw
     assert float((old.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) + 1e-9
 
 
-@pytest.mark.parametrize("B,T,tw,L", [(1, 300, 300, 40), (2, 1000, 777, 4), (3, 4099, 2050, 12), (8, 16384, 12290, 40)])
-def test_x_stationary_dz_is_the_older_kernel_bit_for_bit(B, T, tw, L):
-    """Round 6: k_dz_xs -- a wave loads and splits its 32 columns of dskip ONCE and walks all L problems
-    (dz_l = Ws_l^T dskip, wavenet.py:363-364 backward) in groups of four -- against k_colgemm_b3<2, 0, 3, 8>
-    (WN_EXEC_NO_PIPELINED_GEMM: eight problems per workgroup, X fetched and split once per group) through wn_skip_sum_bwd_dz:
-    same products in the same order, IDENTICAL bit for bit, three times in a row; rows before the window are zero; ragged
-    column counts (a last workgroup of one wave, windows that start inside a clip), 4 / 12 / 40 layers, the bench's own shape;
-    and equal to a float64 contraction to fp32 rounding."""
-    if os.environ.get("WAVENET_HIP_FORCE_GENERIC") == "1":
-        pytest.skip("generic kernels only")
-    from wavenet_amd._lib import ptr, ptr_array, int_array, stream_ptr
-    lib = _lib.lib()
-    Cd, Cs = 32, 256
-    g = torch.Generator(device="cuda").manual_seed(T + tw + L)
-    Ws = [torch.randn(Cs, Cd, device="cuda", generator=g) / 16 for _ in range(L)]
-    dskip = torch.randn(B, tw, Cs, device="cuda", generator=g) * 1e-3
-
-    def run(flags):
-        dz = [torch.full((B, T, Cd), 7.0, device="cuda") for _ in range(L)]
-        rc = lib.wn_skip_sum_bwd_dz(L, ptr_array(Ws), int_array([Cd] * L), ptr(dskip), ptr_array(dz), B, T, T - tw, tw, Cs,
-                                    EX("fp16x2", flags=flags), stream_ptr())
-        assert rc == 0, lib.wn_last_error()
-        torch.cuda.synchronize()
-        return torch.stack(dz)
-
-    old = run(_lib.WN_EXEC_NO_PIPELINED_GEMM)
-    for _ in range(3):
-        assert torch.equal(run(0), old)
-    assert float(old[:, :, :T - tw].abs().max()) == 0 if tw < T else True
-    ref = torch.einsum("btc,lcd->lbtd", dskip.double(), torch.stack(Ws).double())
-    err = float((old[:, :, T - tw:].double() - ref).abs().max())
-    assert err <= 2e-6 * float(ref.abs().max()) + 1e-12, err
-
-
 def test_fast_step_full_window_output_is_the_references_shape_and_values():
     """faster_wavenet.py:105-113 returns the softmax of the WHOLE rolled window, (1, Q, 1, W), every cached column under
     the ELU head; the default face reproduces that from a device-side ring of logits (``keep_window``, on by default): all W

@@ -603,143 +603,6 @@ __global__ __launch_bounds__(256, MT == 8 ? 2 : 3) void k_colgemm_b3(CGArgs a, c
 }
 
 // =============================================================================================
-// k_dz_xs: the multi-problem contraction (mode 2: nprob problems of 32 rows sharing X -- dz_l = Ws_l^T dskip of every layer)
-// with X STATIONARY.  k_colgemm_b3<2, ., 3, 8> gives a workgroup eight problems: with K = 256 that is eight chunks between a
-// cold prologue (the first X round trip and split) and a 128 KB epilogue -- of a workgroup's ~50 k cycles the chunk loop is 27 k
-//  -- and X is fetched and split once per group of eight problems, five times for config 2's 40 layers.
-// Here a wave loads and splits its 32 columns of X ONCE (K = 256: 128 registers of fp16 parts) and walks ALL the problems in
-// groups of four: per group four steps of two 32-deep chunks, the weight tiles of a step (2 chunks x 4 tiles x 4 KB = 32 KB,
-// contiguous in the chunk-major image) by LDS-DMA into the other half of a 64 KB ring one step ahead, 48 MFMAs per wave and
-// barrier, then the group's four 32 x 32 tiles leave through the wave's LDS patch as whole rows.  Same products in the same
-// order per output element as k_colgemm_b3: results are identical bit for bit.  Requirements (the launcher checks): fp16 x 2
-// split with a measured X range, one source, K = 256, a multiple of four problems, no activation / gate / residual /
-// accumulate.  LDS: 64 KB ring + 4 x 4 KB patches = 80 KB: two workgroups per CU.
-// =============================================================================================
-static constexpr int kXsG = 4, kXsTB = kTileBytes * 2 / 3, kXsStep = kXsG * kXsTB, kXsRing = 4, kXsLds = kXsRing * kXsStep + 4 * 4096;
-__global__ __launch_bounds__(256, 2) void k_dz_xs(CGArgs a, const __bf16* __restrict__ img, int mtiles) {
-    constexpr int TB = kXsTB, G = kXsG, NCH = 8;
-    extern __shared__ __attribute__((aligned(1024))) char xs_lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j = lane & 31, h = lane >> 5;
-    const float h2sx = h2_scale(a.xmax_dev, kH2ScaleX);
-    const float h2sw = h2_scale(a.wmax_dev, kH2ScaleW);
-    const long long n = ((long long)blockIdx.x * 4 + wave) * 32 + j;
-    const bool nvalid = n < a.N;
-    long long rb0 = 0;
-    int rbase = -(1 << 30);
-    long long no = n;
-    if (nvalid) {
-        const long long b = n / a.rows_out_per_b;
-        rbase = (int)(n - b * a.rows_out_per_b) + a.off;
-        rb0 = b * a.rows_src_per_b;
-        if (a.out_rows_per_b) no = b * a.out_rows_per_b + a.out_row0 + (n - b * a.rows_out_per_b);
-    }
-    const char* const imgb = reinterpret_cast<const char*>(img);
-    const int ngroups = mtiles / G;
-    const int nsteps = ngroups * NCH;
-    // step s = (group s / 8, chunk s % 8): the four tiles of the group in that chunk, 16 KB contiguous in the chunk-major image:
-    // 16 pieces of 1 KB, four per wave, into ring slot s % 4.  Steps past the end wrap around (the requests are issued all the
-    // same, so that every wait below counts the same number of younger operations; nobody reads what they fetch).
-    auto dma_step = [&](int st) {
-        const int sw = st < nsteps ? st : st - nsteps;
-        const int g = sw >> 3, c = sw & 7;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int q = wave * 4 + i;
-            const char* src = imgb + ((long long)c * mtiles + (long long)G * g) * TB + q * 1024 + lane * 16;
-            lds_dma16(src, xs_lds + (st & (kXsRing - 1)) * kXsStep + q * 1024);
-        }
-    };
-    dma_step(0); dma_step(1); dma_step(2);
-    // X: this lane's column, all K = 256, split once
-    f16x8 xh[NCH][2], xm[NCH][2];
-    {
-        const int rs = rbase + a.soff[0];
-        const bool rv = rs >= 0 && rs < a.rows_src_per_b;
-        const float ms = rv ? h2sx : 0.f;
-        const float* __restrict__ Xb = a.X[0] + (rb0 + (rv ? rs : 0)) * (a.ldx ? a.ldx : a.K[0]) + 8 * h;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float4 xr[4][4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float* p = Xb + (4 * half + c) * 32;
-                xr[c][0] = *reinterpret_cast<const float4*>(p);
-                xr[c][1] = *reinterpret_cast<const float4*>(p + 4);
-                xr[c][2] = *reinterpret_cast<const float4*>(p + 16);
-                xr[c][3] = *reinterpret_cast<const float4*>(p + 20);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const float v[8] = {xr[c][2 * ks].x, xr[c][2 * ks].y, xr[c][2 * ks].z, xr[c][2 * ks].w,
-                                        xr[c][2 * ks + 1].x, xr[c][2 * ks + 1].y, xr[c][2 * ks + 1].z, xr[c][2 * ks + 1].w};
-                    f16x8 fh, fm;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        _Float16 a0, a1;
-                        split2h(v[e] * ms, a0, a1);
-                        fh[e] = a0; fm[e] = a1;
-                    }
-                    xh[4 * half + c][ks] = fh; xm[4 * half + c][ks] = fm;
-                }
-        }
-    }
-    float* const patch = reinterpret_cast<float*>(xs_lds + kXsRing * kXsStep) + wave * 1024;
-    const RowMap rm = row_map(no, nvalid, lane);
-    const float unscale = 1.f / (h2sw * h2sx);                     // exact: a power of two
-    int step = 0;
-    for (int g = 0; g < ngroups; ++g) {
-        f32x16 acc[G];
-#pragma unroll
-        for (int mt = 0; mt < G; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-#pragma unroll
-        for (int c = 0; c < NCH; ++c, ++step) {
-            // Vector-memory operations retire in issue order.  Younger than this step's four requests are the eight of the next
-            // two steps and -- for the first three chunks of a group but the first -- the 16 row stores the previous group's tiles
-            // left in flight on purpose.  (The X loads of the prologue are older.)
-            if (c < 3) {
-                if (g > 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            }
-            // every wave's pieces of this step have landed; everybody is through with step - 1, whose slot takes step + 3
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            dma_step(step + 3);
-            const char* Ab = xs_lds + (step & (kXsRing - 1)) * kXsStep + lane * 16;
-#pragma unroll
-            for (int mt = 0; mt < G; ++mt) {
-                const char* p = Ab + mt * TB;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const f16x8 fah = *reinterpret_cast<const f16x8*>(p + ks * (TB / 2));
-                    const f16x8 fam = *reinterpret_cast<const f16x8*>(p + ks * (TB / 2) + 1024);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam, xh[c][ks], acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, xm[c][ks], acc[mt], 0, 0, 0);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, xh[c][ks], acc[mt], 0, 0, 0);
-                }
-            }
-        }
-        // the group's four tiles: whole 128-byte rows through the wave's own patch (no barrier: the patch is the wave's);
-        // the 16 stores stay in flight under the next group's first chunks
-#pragma unroll
-        for (int mt = 0; mt < G; ++mt) {
-            float4 t[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                t[q] = make_float4(acc[mt][4 * q] * unscale, acc[mt][4 * q + 1] * unscale, acc[mt][4 * q + 2] * unscale,
-                                   acc[mt][4 * q + 3] * unscale);
-            tile_store_rows(patch, lane, t, a.out[G * g + mt], a.ldo, 0, rm);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the wrapped requests past the end must land before the LDS goes
-}
-
-// =============================================================================================
 // k_colgemm_h2q: the fp16-split multi-source contraction (mode 0, eight m-tiles per workgroup: the skip sum) with every
 // fetch three HALF-chunks ahead.  DESIGN.md ("what bounds the skip contractions") has the measurements behind each choice:
 //   * the loop of k_colgemm_b3 waits ~2 us per chunk for requests issued one chunk ago (and its __syncthreads() drains
@@ -1034,18 +897,11 @@ int launch_colgemm_b3(CGArgs& a, int mode, int nprob, hipStream_t s) {
         WN_LAUNCH_CHECK();
         return WN_OK;
     }
-    // mode 2 on the fp16 split with K = 256 (the skip path's dz): X stationary, every problem in one workgroup pass (k_dz_xs)
-    if (mode == 2 && h2 && a.K[0] == 256 && a.nsrc == 1 && mtiles % kXsG == 0 && a.act == WN_ACT_NONE && !a.gate_x &&
-        !a.residual && !a.accumulate && !exec_flag(WN_EXEC_NO_PIPELINED_GEMM)) {
-        static bool attr_xs = false;
-        if (!attr_xs) {
-            WN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dz_xs), hipFuncAttributeMaxDynamicSharedMemorySize, kXsLds));
-            attr_xs = true;
-        }
-        hipLaunchKernelGGL(k_dz_xs, dim3(cdiv(a.N, 128)), dim3(256), kXsLds, s, a, (const __bf16*)img, mtiles);
-        WN_LAUNCH_CHECK();
-        return WN_OK;
-    }
+    // (mode 2 with X STATIONARY -- k_dz_xs, round 6: a wave splits its 32 columns of dskip once and walks all 40 layers' tiles,
+    // weight tiles through a 3/4-slot LDS ring with counted waits, the row stores left in flight -- was built, bit-identical, and
+    // measured: HBM fetch 179 -> 131 MB, the call - 2 ... - 6 % stand-alone, the training step +- 0 (2.888 against 2.882 ms, same
+    // box); without its stores it still took 180 of 225 us against 84 us of MFMA time: neither the writes nor the re-split bound
+    // this contraction.  Not kept.  DESIGN.md, round 6.)
     const bool mt8 = (one || h2) && mtiles >= 8;
     dim3 grid(cdiv(a.N, 128) * cdiv(mtiles, mt8 ? 8 : 4));
     if (mode == 6) {
