@@ -445,7 +445,10 @@ int wn16_pointwise_bwd(const uint16_t* x, const uint16_t* WbT, const uint16_t* d
  * results are bit-identical to the per-call preparation -- so a call that carries one ASSERTS that wn_plan_prepare ran on the
  * same stream since the weights last changed.  Weight POINTERS are the keys: a plan belongs to one model.  Plan-owned words:
  * the dataflow words of the multi-layer backward, and the range word of the head's dx, filled by the GEMM that writes dx and
- * read by the dz contraction instead of a 100 MB pass over dskip.  wn_plan_stats: out[0..7] = state (0 idle, 1 recording,
+ * read by the dz contraction instead of a 100 MB pass over dskip.  A plan is a host object for ONE thread at a time;
+ * wn_plan_record on a finished plan forgets its jobs and lays the images out anew at the next finish -- launches captured
+ * into a graph against the old layout are void from then on (one plan per captured graph: wavenet_amd.TrainStepGraph).
+ * wn_plan_stats: out[0..7] = state (0 idle, 1 recording,
  * 2 ready), weight images, layer images (layers), plan-owned words, device bytes used, prepare calls, look-ups served,
  * look-ups not served. */
 int wn_plan_create(void** plan, void* dev_mem, size_t dev_bytes);
