@@ -999,7 +999,7 @@ int decode_fast_status(const float* P, int nlayers, hipStream_t s, int* gave_up)
 }  // namespace wn
 
 #ifdef WN_DEC3_STAMPS
-extern "C" int wn_debug_dec3_stamps(unsigned long long* dst) {
+extern "C" __attribute__((visibility("default"))) int wn_debug_dec3_stamps(unsigned long long* dst) {
     if (!wn::g_dbg_decX) return -1;
     return (int)hipMemcpy(dst, wn::g_dbg_decX + wn::g_dbg_decL * 64 + 8 * 256, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
 }

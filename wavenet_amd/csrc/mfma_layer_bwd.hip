@@ -1577,19 +1577,19 @@ int mfma_chain_combine(const float* V, const float* U, float* dx, int B, int T, 
 }  // namespace wn
 
 #ifdef WN_MULTI_STAMPS
-extern "C" int wn_debug_multi_stamps(unsigned long long* dst) {
+extern "C" __attribute__((visibility("default"))) int wn_debug_multi_stamps(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wn::g_multi_stamps), sizeof(unsigned long long) * (wn::kChainMaxL + 1) * 256 * 4);
 }
-extern "C" int wn_debug_multi_seg(unsigned long long* dst, int zero) {
+extern "C" __attribute__((visibility("default"))) int wn_debug_multi_seg(unsigned long long* dst, int zero) {
     if (zero) { static unsigned long long z[256 * 4 * 8]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(wn::g_multi_seg), z, sizeof(z)); }
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wn::g_multi_seg), sizeof(unsigned long long) * 256 * 4 * 8);
 }
-extern "C" int wn_debug_multi_spins(unsigned long long* dst) {
+extern "C" __attribute__((visibility("default"))) int wn_debug_multi_spins(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wn::g_multi_spins), sizeof(unsigned long long) * (wn::kChainMaxL + 1) * 256 * 4);
 }
 #endif
 #ifdef WN_BWD_STAMPS
-extern "C" int wn_debug_bwd_stamps(unsigned long long* dst) {
+extern "C" __attribute__((visibility("default"))) int wn_debug_bwd_stamps(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(wn::g_bwd_stamps), sizeof(unsigned long long) * 1024 * 8);
 }
 #endif

@@ -1180,10 +1180,10 @@ int debug_stamps(unsigned long long* dst, int n) {
 }  // namespace w16
 
 #ifdef WN16_MSTAMPS
-extern "C" int wn16_debug_mstamps(unsigned long long* dst) {
+extern "C" __attribute__((visibility("default"))) int wn16_debug_mstamps(unsigned long long* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(w16::g_mstamps), sizeof(unsigned long long) * 100 * 256 * 4);
 }
 #endif
 #ifdef WN16_STAMPS
-extern "C" int wn16_debug_stamps(unsigned long long* dst, int n) { return w16::debug_stamps(dst, n); }
+extern "C" __attribute__((visibility("default"))) int wn16_debug_stamps(unsigned long long* dst, int n) { return w16::debug_stamps(dst, n); }
 #endif
