@@ -303,13 +303,7 @@ __global__ void k_colsum_reduce(const float* __restrict__ part, int ny, int M, f
     }
 }
 
-// out[m] += sum over the ny rows of part[y][m], rows added in the fixed tree of k_colsum_reduce (also the tail of the
-// column sums that the wide weight-gradient kernel takes along: mfma_gemm_b3.hip)
-int colsum_reduce_launch(const float* part, int ny, int M, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_colsum_reduce, dim3(cdiv(M, 64)), dim3(64, 16), 0, s, part, ny, M, out);
-    WN_LAUNCH_CHECK();
-    return WN_OK;
-}
+// (the wide weight-gradient kernel's column sums are reduced by the same tree inside k_wgrad_b3w_reduce: mfma_gemm_b3.hip)
 
 static int launch_colsum(const float* A, long long a_bs, int a_t0, int lda, int nB, int tmin, int nT,
                          int M, float* out, hipStream_t s) {

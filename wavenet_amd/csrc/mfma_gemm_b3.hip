@@ -1511,6 +1511,28 @@ __global__ __launch_bounds__(512, 1) void k_wgrad_h2p(WGArgs a) {
 // Sum of the partial tiles of k_wgrad_b3w: one thread per output element, the workgroups' tiles of one (problem, mt, r)
 // are 256-byte rows `stride` floats apart.  dW += sum (sole writer of its element).
 __global__ void k_wgrad_b3w_reduce(WGArgs a, int nwg_x) {
+    if ((int)blockIdx.y == a.nprob) {
+        // the extra grid row (launched only with a column-sum request): the bias gradient's 2 x nwg_x partial rows, in the fixed
+        // tree of k_colsum_reduce (generic_kernels.hip) -- row lane y adds rows y, y + 16, ... in order, the 16 lane sums are added
+        // in index order -- so the result is that kernel's bit for bit; it used to be a launch of its own (one workgroup per 64
+        // columns, 11 us at the launch floor's mercy)
+        __shared__ float red[16][16];
+        const int c = threadIdx.x & 15, y = threadIdx.x >> 4;
+        const int m = blockIdx.x * 16 + c;
+        if (m >= 256) return;                                   // (whole blocks: blockIdx.x >= 16)
+        const int ny = 2 * nwg_x;
+        float sacc = 0.f;
+        for (int r = y; r < ny; r += 16) sacc += a.colsum_part[(long long)r * 256 + m];
+        red[y][c] = sacc;
+        __syncthreads();
+        if (y == 0) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k][c];
+            a.colsum[m] += t;
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // (mt, r) of this wave: 0 .. 127
     const int p = blockIdx.y;                                              // problem
@@ -1612,13 +1634,10 @@ int launch_wgrad_b3w(WGArgs& a_io, hipStream_t s) {
 #undef W_LAUNCH_A
 #undef W_LAUNCH
     WN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_wgrad_b3w_reduce, dim3(128 / 4, a.nprob), dim3(256), 0, s, a, (int)grid.x);
+    // (+ one grid row for the column sums' partial rows when they were asked for: see the kernel)
+    hipLaunchKernelGGL(k_wgrad_b3w_reduce, dim3(128 / 4, a.nprob + (cs ? 1 : 0)), dim3(256), 0, s, a, (int)grid.x);
     WN_LAUNCH_CHECK();
-    if (cs) {
-        const int rc = colsum_reduce_launch(a.colsum_part, 2 * (int)grid.x, 256, a.colsum, s);
-        if (rc) return rc;
-        a_io.colsum_done = 1;
-    }
+    if (cs) a_io.colsum_done = 1;
     return WN_OK;
 }
 

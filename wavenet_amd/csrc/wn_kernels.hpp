@@ -154,6 +154,5 @@ int mfma_skip_bwd_dw(int L, const float* const* z, const int* cd, const float* d
 // dbias != NULL: dbias[o] += sum_n dout[n][o] is taken along where the kernel can (then *dbias_done = true)
 int mfma_pointwise_bwd_dw(const float* x, const float* dout, float* dW, long long N, int Cin, int Cout, int act,
                           float* dbias, bool* dbias_done, hipStream_t s);
-int colsum_reduce_launch(const float* part, int ny, int M, float* out, hipStream_t s);
 
 }  // namespace wn
