@@ -1236,20 +1236,7 @@ __global__ __launch_bounds__(256, 1) void k_layer_bwd_chain_multi(const ChainArg
 
 // dx[t] = V[t] + U[t + dU]   (the split gradient of the stack input, materialised once at the bottom)
 __global__ void k_chain_combine(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ dx,
-                                int B, int T, int dU, int vu_t0) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index
-    const long long n4 = (long long)B * T * 8;
-    if (i >= n4) return;
-    const long long col = i >> 3;
-    const int t = (int)(col % T);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);          // rows below vu_t0 were not written: exact zeros
-    if (t >= vu_t0) v = reinterpret_cast<const float4*>(V)[i];
-    if (t + dU < T && t + dU >= vu_t0) {
-        const float4 u = reinterpret_cast<const float4*>(U)[i + (long long)dU * 8];
-        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-    }
-    reinterpret_cast<float4*>(dx)[i] = v;
-}
+                                int B, int T, int dU, int vu_t0);
 
 // dW += sum over workgroups of the partial tiles.  Thread = one element of the five tiles; blockIdx.y
 // splits the workgroup range so that enough loads are in flight; kRedParts light atomics per address.
@@ -1280,7 +1267,28 @@ static constexpr int kRedAllMax = 64;
 struct RedAllArgs { float* dWf[kRedAllMax]; float* dWg[kRedAllMax]; float* dWp[kRedAllMax]; int nwg[kRedAllMax]; };
 // Deterministic: a block owns 64 elements; its four waves each sum a quarter of the workgroups' tiles (whole 256-byte rows
 // per load), the quarters are added in a fixed order through LDS, and the owner adds the total to dW without an atomic.
-__global__ void k_layer_bwd_reduce_all(const float* __restrict__ part, long long layer_stride, RedAllArgs a) {
+// (gridDim.z = layers + 1 when the stack's input gradient is wanted: the last z-slice materialises dx = V + U[t + dU] -- the
+// k_chain_combine pass, grid-stride -- under the reduction instead of behind it as a launch of its own)
+struct CombineArgs { const float* V; const float* U; float* dx; int B, T, dU, vu_t0; };
+__device__ __forceinline__ void chain_combine_at(const CombineArgs& c, long long i) {
+    const long long col = i >> 3;
+    const int t = (int)(col % c.T);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);          // rows below vu_t0 were not written: exact zeros
+    if (t >= c.vu_t0) v = reinterpret_cast<const float4*>(c.V)[i];
+    if (t + c.dU < c.T && t + c.dU >= c.vu_t0) {
+        const float4 u = reinterpret_cast<const float4*>(c.U)[i + (long long)c.dU * 8];
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    reinterpret_cast<float4*>(c.dx)[i] = v;
+}
+__global__ void k_layer_bwd_reduce_all(const float* __restrict__ part, long long layer_stride, RedAllArgs a, int nlayers,
+                                       CombineArgs cmb) {
+    if ((int)blockIdx.z == nlayers) {
+        const long long n4 = (long long)cmb.B * cmb.T * 8;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+            chain_combine_at(cmb, i);
+        return;
+    }
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, sp = threadIdx.x >> 6;
     const int e = blockIdx.x * 64 + lane;                    // kPartFloats is a multiple of 64
@@ -1552,18 +1560,30 @@ size_t mfma_chain_part_floats() { return (size_t)kCMaxBlocks * kPartFloats; }
 
 // Sum the partial tiles of L layers (layer l: nwg[l] tiles at part + l * mfma_chain_part_floats()) into their weight
 // gradients.  dWp[l] == NULL: that layer had no gradient through its output (the top layer of the stack).
+__global__ void k_chain_combine(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ dx,
+                                int B, int T, int dU, int vu_t0) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // float4 index
+    if (i >= (long long)B * T * 8) return;
+    chain_combine_at(CombineArgs{V, U, dx, B, T, dU, vu_t0}, i);
+}
+
+// dx != NULL: also materialise dx = V + U[t + dU] (the stack's input gradient) in the same launch (stacks of <= kRedAllMax layers)
 int mfma_chain_reduce_all(const float* part, int L, const int* nwg, float* const* dWf, float* const* dWg,
-                          float* const* dWp, hipStream_t s) {
+                          float* const* dWp, hipStream_t s, const float* V, const float* U, float* dx, int B, int T,
+                          int dU, int vu_t0) {
+    const bool fold = dx != nullptr && L <= kRedAllMax;
     for (int l0 = 0; l0 < L; l0 += kRedAllMax) {
         const int n = L - l0 < kRedAllMax ? L - l0 : kRedAllMax;
         RedAllArgs a{};
         for (int l = 0; l < n; ++l) {
             a.dWf[l] = dWf[l0 + l]; a.dWg[l] = dWg[l0 + l]; a.dWp[l] = dWp[l0 + l]; a.nwg[l] = nwg[l0 + l];
         }
-        hipLaunchKernelGGL(k_layer_bwd_reduce_all, dim3(kPartFloats / 64, 1, n), dim3(256), 0, s,
-                           part + (size_t)l0 * mfma_chain_part_floats(), (long long)mfma_chain_part_floats(), a);
+        const CombineArgs c{V, U, dx, B, T, dU, vu_t0};
+        hipLaunchKernelGGL(k_layer_bwd_reduce_all, dim3(kPartFloats / 64, 1, n + (fold ? 1 : 0)), dim3(256), 0, s,
+                           part + (size_t)l0 * mfma_chain_part_floats(), (long long)mfma_chain_part_floats(), a, n, c);
         WN_LAUNCH_CHECK();
     }
+    if (dx && !fold) return mfma_chain_combine(V, U, dx, B, T, dU, vu_t0, s);
     return WN_OK;
 }
 

@@ -303,10 +303,8 @@ int wn_stack_bwd(const WnStackDesc* d, const float* x, const float* xs, const fl
             if (grid)
                 for (int l : m_layer) nwg[l] = grid;
         }
-        rc = mfma_chain_reduce_all(parts, L, nwg.data(), dWf, dWg, dWp_eff.data(), as_stream(stream));
-        if (rc) return rc;
-        if (dx) return mfma_chain_combine(Vin, Uin, dx, B, T, dU, vu_t0, as_stream(stream));
-        return WN_OK;
+        // (+ dx = V + U[t + dU], the stack's input gradient, in the same launch)
+        return mfma_chain_reduce_all(parts, L, nwg.data(), dWf, dWg, dWp_eff.data(), as_stream(stream), Vin, Uin, dx, B, T, dU, vu_t0);
     }
     const float* gout = dout;
     for (int l = L - 1; l >= 0; --l) {

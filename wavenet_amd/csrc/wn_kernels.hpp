@@ -119,7 +119,8 @@ int mfma_layer_bwd_chain_multi(int n, const int* layer, const float* const* Wf, 
 size_t mfma_chain_multi_sync_words(int B, int T);
 size_t mfma_chain_part_floats();
 int mfma_chain_reduce_all(const float* part, int L, const int* nwg, float* const* dWf, float* const* dWg,
-                          float* const* dWp, hipStream_t s);
+                          float* const* dWp, hipStream_t s, const float* V = nullptr, const float* U = nullptr,
+                          float* dx = nullptr, int B = 0, int T = 0, int dU = 0, int vu_t0 = 0);
 int mfma_chain_combine(const float* V, const float* U, float* dx, int B, int T, int dU, int vu_t0, hipStream_t s);
 int generic_layer_bwd_biases(const float* dab, const float* dout, float* dbf, float* dbg, float* dbp, int B,
                              int T, int Cr, int Cd, int Z, hipStream_t s);
