@@ -1267,9 +1267,11 @@ static constexpr int kRedAllMax = 64;
 struct RedAllArgs { float* dWf[kRedAllMax]; float* dWg[kRedAllMax]; float* dWp[kRedAllMax]; int nwg[kRedAllMax]; };
 // Deterministic: a block owns 64 elements; its four waves each sum a quarter of the workgroups' tiles (whole 256-byte rows
 // per load), the quarters are added in a fixed order through LDS, and the owner adds the total to dW without an atomic.
-// (gridDim.z = layers + 1 when the stack's input gradient is wanted: the last z-slice materialises dx = V + U[t + dU] -- the
-// k_chain_combine pass, grid-stride -- under the reduction instead of behind it as a launch of its own)
+// (gridDim.z = layers + kCombineSlices when the stack's input gradient is wanted: the extra z-slices materialise dx = V + U[t + dU]
+// -- the k_chain_combine pass, grid-stride -- under the reduction instead of behind it as a launch of its own; with ONE slice of
+// 80 blocks the pass took 66 us and the launch with it: it needs the blocks of a launch of its own)
 struct CombineArgs { const float* V; const float* U; float* dx; int B, T, dU, vu_t0; };
+static constexpr int kCombineSlices = 24;               // x 80 blocks x 256 threads: two float4 per thread at config 2
 __device__ __forceinline__ void chain_combine_at(const CombineArgs& c, long long i) {
     const long long col = i >> 3;
     const int t = (int)(col % c.T);
@@ -1283,9 +1285,10 @@ __device__ __forceinline__ void chain_combine_at(const CombineArgs& c, long long
 }
 __global__ void k_layer_bwd_reduce_all(const float* __restrict__ part, long long layer_stride, RedAllArgs a, int nlayers,
                                        CombineArgs cmb) {
-    if ((int)blockIdx.z == nlayers) {
+    if ((int)blockIdx.z >= nlayers) {                        // kCombineSlices z-slices of the grid: enough blocks for a 50 MB pass
         const long long n4 = (long long)cmb.B * cmb.T * 8;
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+        const long long nthr = (long long)(gridDim.z - nlayers) * gridDim.x * blockDim.x;
+        for (long long i = ((long long)(blockIdx.z - nlayers) * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += nthr)
             chain_combine_at(cmb, i);
         return;
     }
@@ -1579,7 +1582,7 @@ int mfma_chain_reduce_all(const float* part, int L, const int* nwg, float* const
             a.dWf[l] = dWf[l0 + l]; a.dWg[l] = dWg[l0 + l]; a.dWp[l] = dWp[l0 + l]; a.nwg[l] = nwg[l0 + l];
         }
         const CombineArgs c{V, U, dx, B, T, dU, vu_t0};
-        hipLaunchKernelGGL(k_layer_bwd_reduce_all, dim3(kPartFloats / 64, 1, n + (fold ? 1 : 0)), dim3(256), 0, s,
+        hipLaunchKernelGGL(k_layer_bwd_reduce_all, dim3(kPartFloats / 64, 1, n + (fold ? kCombineSlices : 0)), dim3(256), 0, s,
                            part + (size_t)l0 * mfma_chain_part_floats(), (long long)mfma_chain_part_floats(), a, n, c);
         WN_LAUNCH_CHECK();
     }
