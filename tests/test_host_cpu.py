@@ -329,3 +329,26 @@ def test_load_after_save_reads_the_npz_without_an_hdf5_library(tmp_path, capsys,
     c.load(str(tmp_path))
     assert "OLDER" in capsys.readouterr().out
     assert all(np.array_equal(c.state_dict()[k], v) for k, v in a.state_dict().items())
+
+
+def test_step_plan_argument_errors_do_not_need_a_gpu():
+    """ABI 5's step plan (wn_plan_*): the host-side state machine refuses misuse with a message before any HIP call -- NULL /
+    misaligned / too little device memory, preparing or finishing a plan that is not in the right state, an array to zero that is
+    not 16-byte aligned or not a multiple of four floats -- and wn_plan_stats reports the state (0 idle, 1 recording)."""
+    import ctypes as C
+    lib = _lib.lib()
+    h = C.c_void_p()
+    assert lib.wn_plan_create(C.byref(h), None, 1 << 20) == -1
+    assert lib.wn_plan_create(C.byref(h), 0x1000100, 1 << 20) == 0                      # (never dereferenced on the host)
+    out = (C.c_int64 * 8)()
+    assert lib.wn_plan_stats(h, out) == 0 and list(out)[:3] == [0, 0, 0]
+    assert lib.wn_plan_prepare(h, None, 0, None) == -1 and b"not ready" in lib.wn_last_error()
+    assert lib.wn_plan_finish(h, None) == -1 and b"not recording" in lib.wn_last_error()
+    assert lib.wn_plan_record(h) == 0
+    assert lib.wn_plan_stats(h, out) == 0 and out[0] == 1
+    assert lib.wn_plan_prepare(h, None, 0, None) == -1                                    # recording, not ready
+    assert lib.wn_plan_destroy(h) == 0
+    h2 = C.c_void_p()
+    assert lib.wn_plan_create(C.byref(h2), 0x1000101, 1 << 20) == -1 and b"aligned" in lib.wn_last_error()
+    assert lib.wn_plan_create(C.byref(h2), 0x1000100, 1024) == -1
+    assert lib.wn_plan_create(None, 0x1000100, 1 << 20) == -1
